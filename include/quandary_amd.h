@@ -1,0 +1,277 @@
+/*
+ * quandary_amd.h — C ABI of the MI355X-native forward/adjoint propagator.
+ *
+ * This is the drop-in boundary for ONE hot path of LLNL/quandary: propagate a
+ * batch of initial conditions through the Lindblad/Schroedinger time stepper,
+ * sweep the discrete adjoint backwards and accumulate the control-parameter
+ * gradient.  All entry points are extern "C", take plain pointers and sizes,
+ * return 0 on success and a negative QD_ERR_* code on failure (the message is
+ * available from qd_last_error()).  Nothing here calls exit().
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference repository):
+ *
+ *   qd_create / qd_destroy      MasterEq ctor + MatShellCtx  (src/mastereq.cpp:14-155,
+ *                               include/mastereq.hpp:20-42), Oscillator ctor
+ *                               (src/oscillator.cpp:10-214), ImplMidpoint ctor
+ *                               (src/timestepper.cpp:522-556)
+ *   qd_set_params               MasterEq::setControlAmplitudes (src/mastereq.cpp:693-707)
+ *   qd_eval_controls            Oscillator::evalControl (src/oscillator.cpp:281-337)
+ *   qd_apply_rhs                MatMult / MatMultTranspose on the MATSHELL, i.e.
+ *                               applyRHS_matfree<...> and ..._transpose<...>
+ *                               (src/mastereq.cpp:1278-2893, dispatch :2976-3239),
+ *                               preceded by MasterEq::assemble_RHS(t) (:657-678)
+ *   qd_forward                  TimeStepper::solveODE over the local batch
+ *                               (src/timestepper.cpp:96-181) incl. the in-loop
+ *                               penalties (:256-298, :342-369, :444-455)
+ *   qd_adjoint                  TimeStepper::solveAdjointODE over the local batch
+ *                               (src/timestepper.cpp:184-253), ImplMidpoint::evolveBWD
+ *                               (:631-694), compute_dRHS_dParams_matfree
+ *                               (src/mastereq.cpp:970-1276)
+ *   qd_optim_*                  OptimProblem::evalF / evalGradF (src/optimproblem.cpp:224-538)
+ *                               with OptimTarget (src/optimtarget.cpp:325-897) and
+ *                               Gate::assembleGate/applyGate (src/gate.cpp:88-283)
+ *
+ * State layout (same as the reference, docs/mkdocs/user_guide.md:305-306): one
+ * state is 2*dim doubles, blocked [u ; v] (all real parts, then all imaginary
+ * parts); dim = N (Schroedinger) or N^2 (Lindblad, column-major vectorisation
+ * vec index = row + col*N, src/util.cpp:150-152); oscillator 0 is the slowest
+ * index inside a Hilbert-space index.  A batch is nb states back to back.
+ *
+ * Units follow the reference config file: frequencies in GHz (multiplied by
+ * 2*pi inside, src/mastereq.cpp:29-37, src/oscillator.cpp:15-21), times in ns.
+ */
+#ifndef QUANDARY_AMD_H
+#define QUANDARY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_MAX_OSC 8
+#define QD_MAX_PAIRS (QD_MAX_OSC * (QD_MAX_OSC - 1) / 2)
+
+/* error codes */
+#define QD_OK 0
+#define QD_ERR_INVALID (-1)   /* bad argument / inconsistent description           */
+#define QD_ERR_UNSUPPORTED (-2) /* valid in the reference but not built here       */
+#define QD_ERR_DEVICE (-3)    /* HIP runtime error (no device, launch failure ...) */
+#define QD_ERR_NOMEM (-4)     /* host or device allocation failed                  */
+#define QD_ERR_STATE (-5)     /* call order violated (e.g. adjoint before forward) */
+
+/* LindbladType, include/defs.hpp */
+enum { QD_LINDBLAD_NONE = 0, QD_LINDBLAD_DECAY = 1, QD_LINDBLAD_DEPHASE = 2, QD_LINDBLAD_BOTH = 3 };
+/* ControlType, include/defs.hpp; only BSPLINE and BSPLINE0 carry a gradient in the reference */
+enum { QD_CTRL_NONE = 0, QD_CTRL_BSPLINE = 1, QD_CTRL_BSPLINE0 = 2 };
+/* timestepper = IMR | IMR4 | IMR8 | EE, src/main.cpp:357-366 */
+enum { QD_STEPPER_IMR = 0, QD_STEPPER_IMR4 = 1, QD_STEPPER_IMR8 = 2, QD_STEPPER_EE = 3 };
+/* linearsolver_type = gmres | neumann, src/main.cpp:342-350 */
+enum { QD_LINSOLVE_GMRES = 0, QD_LINSOLVE_NEUMANN = 1 };
+/* InitialConditionType, include/defs.hpp / src/optimtarget.cpp:42-53 */
+enum {
+  QD_INIT_FROMFILE = 0, QD_INIT_PURE = 1, QD_INIT_ENSEMBLE = 2, QD_INIT_DIAGONAL = 3,
+  QD_INIT_BASIS = 4, QD_INIT_THREESTATES = 5, QD_INIT_NPLUSONE = 6, QD_INIT_PERFORMANCE = 7
+};
+/* TargetType / ObjectiveType, include/defs.hpp */
+enum { QD_TARGET_GATE = 0, QD_TARGET_PURE = 1, QD_TARGET_FROMFILE = 2 };
+enum { QD_OBJ_JFROBENIUS = 0, QD_OBJ_JTRACE = 1, QD_OBJ_JMEASURE = 2 };
+
+/* Physical system: the MatShellCtx parameter block (include/mastereq.hpp:20-42)
+ * in config-file units (src/main.cpp:191-316).  Pair order is 01,02,...,0(Q-1),12,...
+ * (src/mastereq.cpp:2432-2441). */
+typedef struct qd_system {
+  int32_t nosc;
+  int32_t lindblad_type;               /* QD_LINDBLAD_*                      */
+  int32_t nlevels[QD_MAX_OSC];
+  int32_t nessential[QD_MAX_OSC];
+  double transfreq[QD_MAX_OSC];        /* GHz                                */
+  double rotfreq[QD_MAX_OSC];          /* GHz                                */
+  double selfkerr[QD_MAX_OSC];         /* GHz                                */
+  double crosskerr[QD_MAX_PAIRS];      /* GHz                                */
+  double Jkl[QD_MAX_PAIRS];            /* GHz                                */
+  double decay_time[QD_MAX_OSC];       /* T1 in ns, <=1e-14 disables         */
+  double dephase_time[QD_MAX_OSC];     /* T2 in ns, <=1e-14 disables         */
+} qd_system;
+
+/* Control parameterisation (src/oscillator.cpp:45-132, src/controlbasis.cpp).
+ * Segments are listed oscillator by oscillator; design vector layout per
+ * oscillator is [segment][carrier][2*nsplines] (src/controlbasis.cpp:58-59). */
+typedef struct qd_controls {
+  int32_t enforce_bc;                  /* control_enforceBC                  */
+  int32_t nseg_total;
+  const int32_t* seg_osc;              /* [nseg_total] owning oscillator     */
+  const int32_t* seg_type;             /* [nseg_total] QD_CTRL_*             */
+  const int32_t* seg_nsplines;         /* [nseg_total]                       */
+  const double* seg_tstart;            /* [nseg_total] ns                    */
+  const double* seg_tstop;             /* [nseg_total] ns                    */
+  const int32_t* ncarrier;             /* [nosc]                             */
+  const double* carrier_freq;          /* concatenated, GHz                  */
+  int32_t npipulse;                    /* apply_pipulse entries, already expanded
+                                          to every oscillator (src/main.cpp:249-277) */
+  const int32_t* pipulse_osc;          /* [npipulse]                         */
+  const double* pipulse_tstart;        /* [npipulse]                         */
+  const double* pipulse_tstop;         /* [npipulse]                         */
+  const double* pipulse_amp;           /* [npipulse] (0 for non-target osc)  */
+} qd_controls;
+
+typedef struct qd_time {
+  int32_t ntime;
+  double dt;
+} qd_time;
+
+typedef struct qd_solver {
+  int32_t stepper;                     /* QD_STEPPER_*                       */
+  int32_t linsolve;                    /* QD_LINSOLVE_*                      */
+  int32_t maxiter;                     /* linearsolver_maxiter               */
+  double abstol;                       /* reference: 1e-10 (timestepper.cpp:536) */
+  double reltol;                       /* reference: 1e-20 (timestepper.cpp:535) */
+} qd_solver;
+
+/* What the forward sweep needs to evaluate objective-dependent terms inside
+ * the time loop (weighted-J penalty, src/timestepper.cpp:262-270) and at the
+ * end (OptimTarget::evalJ, src/optimtarget.cpp:712-799). */
+typedef struct qd_target {
+  int32_t target_type;                 /* QD_TARGET_*                        */
+  int32_t objective_type;              /* QD_OBJ_*                           */
+  int32_t purestate_id;                /* Hilbert-space index m for PURE     */
+  const double* target_states;         /* [nb][2*dim] for GATE/FROMFILE, else NULL */
+  const double* purity;                /* [nb] Tr(rho0^2) (optimtarget.cpp:705-707) */
+} qd_target;
+
+typedef struct qd_penalty {
+  double gamma_penalty;                /* optim_penalty                      */
+  double penalty_param;                /* optim_penalty_param                */
+  double gamma_penalty_dpdm;           /* optim_penalty_dpdm (Schroedinger)  */
+  double gamma_penalty_energy;         /* optim_penalty_energy               */
+} qd_penalty;
+
+/* Per-initial-condition results of one forward sweep. */
+typedef struct qd_forward_out {
+  double* final_states;                /* [nb][2*dim] or NULL                */
+  double* penalty_integral;            /* [nb] TimeStepper::penalty_integral */
+  double* penalty_dpdm;                /* [nb] TimeStepper::penalty_dpdm     */
+  double* energy_penalty;              /* [1]  TimeStepper::energy_penalty_integral */
+  double* J_re;                        /* [nb] OptimTarget::evalJ            */
+  double* J_im;                        /* [nb]                               */
+  double* fid_re;                      /* [nb] HilbertSchmidtOverlap(.,false) */
+  double* fid_im;                      /* [nb]                               */
+} qd_forward_out;
+
+typedef struct qd_handle qd_handle;
+
+const char* qd_last_error(void);
+const char* qd_version(void);
+/* number of HIP devices visible, or a negative QD_ERR_DEVICE */
+int qd_device_count(void);
+
+int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_time* tg, const qd_solver* sol,
+              int device_ordinal, qd_handle** out);
+void qd_destroy(qd_handle* h);
+
+/* sizes derived from the description */
+int qd_dim(const qd_handle* h);        /* dim = N or N^2                       */
+int qd_dim_rho(const qd_handle* h);    /* N                                    */
+int qd_dim_ess(const qd_handle* h);    /* prod nessential                      */
+int qd_ndesign(const qd_handle* h);    /* number of control parameters         */
+
+int qd_set_params(qd_handle* h, const double* alpha, int ndesign);
+/* p_k(t), q_k(t) for every oscillator at nt times; pq is [nt][nosc][2] */
+int qd_eval_controls(qd_handle* h, const double* times, int nt, double* pq);
+/* y = M(t) x (transpose=0) or M(t)^T x (transpose=1) for nb states */
+int qd_apply_rhs(qd_handle* h, double t, int transpose, const double* x, double* y, int nb);
+
+/* Trajectory access after qd_forward(..., store_trajectory=1): copies state n
+ * (0..ntime) of every local initial condition, [nb][2*dim]. */
+int qd_get_state(qd_handle* h, int timestep, double* x);
+
+int qd_set_target(qd_handle* h, const qd_target* tgt, int nb);
+int qd_set_penalty(qd_handle* h, const qd_penalty* pen);
+
+int qd_forward(qd_handle* h, const double* x0, int nb, int store_trajectory, qd_forward_out* out);
+/* xbarT: [nb][2*dim] terminal adjoint seed; jbar: [nb][3] = beta_i*{gamma_penalty,
+ * gamma_dpdm, gamma_energy} as passed to solveAdjointODE; jbar_weightedJ: [nb][2]
+ * (Jbar_re, Jbar_im from finalizeJ_diff per state, used by the weighted-J penalty);
+ * grad: [ndesign] summed over the local batch (overwritten). */
+int qd_adjoint(qd_handle* h, const double* xbarT, const double* jbar, int nb, double* grad);
+
+/* Mean number of RHS applications per time step and initial condition in the
+ * last forward sweep (1 + linear-solver iterations). */
+double qd_last_mean_applies(const qd_handle* h);
+/* Milliseconds spent in device kernels of the last forward / adjoint sweep
+ * (hipEvent bracket on the handle's stream). */
+double qd_last_forward_ms(const qd_handle* h);
+double qd_last_adjoint_ms(const qd_handle* h);
+
+/* ---------------------------------------------------------------------------
+ * Objective level: OptimProblem::evalF / evalGradF over the local shard of
+ * initial conditions (src/optimproblem.cpp:224-538).
+ * ------------------------------------------------------------------------- */
+typedef struct qd_objective {
+  int32_t initcond_type;               /* QD_INIT_*                          */
+  int32_t n_init_ids;                  /* entries after the keyword          */
+  int32_t init_ids[QD_MAX_OSC];        /* oscillator ids (or levels for PURE) */
+  const double* init_data;             /* FROMFILE: file content, 2*dim_ess(^2) */
+  int32_t target_type;                 /* QD_TARGET_*                        */
+  int32_t target_pure_levels[QD_MAX_OSC]; /* PURE: level per oscillator      */
+  const double* gate_re;               /* GATE: V (dim_ess x dim_ess, row-major), lab frame */
+  const double* gate_im;
+  double gate_rot_freq[QD_MAX_OSC];    /* GHz                                */
+  const double* target_data;           /* FROMFILE: file content             */
+  int32_t objective_type;              /* QD_OBJ_*                           */
+  int32_t nweights;                    /* optim_weights entries              */
+  const double* weights;
+  double gamma_tik;                    /* optim_regul                        */
+  int32_t tik0;                        /* optim_regul_tik0                   */
+  const double* alpha0;                /* [ndesign] initial guess for tik0   */
+  qd_penalty penalty;
+  double gamma_penalty_variation;      /* optim_penalty_variation            */
+} qd_objective;
+
+/* The seven partial sums the reference all-reduces over comm_init
+ * (src/optimproblem.cpp:292-298, :454-460), in this order. */
+enum { QD_SUM_PENALTY = 0, QD_SUM_DPDM = 1, QD_SUM_ENERGY = 2, QD_SUM_COST_RE = 3,
+       QD_SUM_COST_IM = 4, QD_SUM_FID_RE = 5, QD_SUM_FID_IM = 6, QD_NSUMS = 7 };
+
+typedef struct qd_objective_value {
+  double objective;                    /* getObjective                       */
+  double cost;                         /* getCostT                           */
+  double regul;                        /* getRegul                           */
+  double penalty;                      /* getPenalty                         */
+  double penalty_dpdm;                 /* getPenaltyDpDm                     */
+  double penalty_energy;               /* getPenaltyEnergy                   */
+  double penalty_variation;            /* getPenaltyVariation                */
+  double fidelity;                     /* getFidelity                        */
+} qd_objective_value;
+
+typedef struct qd_optim qd_optim;
+
+/* ninit_global initial conditions are sharded contiguously over nranks
+ * (iinit_global = rank*ninit_local + iinit, src/optimproblem.cpp:248). */
+int qd_optim_create(qd_handle* h, const qd_objective* obj, int rank, int nranks, qd_optim** out);
+void qd_optim_destroy(qd_optim* o);
+int qd_optim_ninit(const qd_optim* o);        /* global                        */
+int qd_optim_ninit_local(const qd_optim* o);
+/* initial state / id of local initial condition i: x0 is [2*dim] */
+int qd_optim_initial_state(qd_optim* o, int iinit_local, double* x0, int* initid);
+int qd_optim_target_state(qd_optim* o, int iinit_local, double* xtarget);
+
+/* Forward sweep of the local shard; partial[QD_NSUMS] are this rank's sums. */
+int qd_optim_forward_local(qd_optim* o, const double* alpha, int store_trajectory, double* partial);
+/* Objective from the globally reduced sums. */
+int qd_optim_finalize(qd_optim* o, const double* alpha, const double* global_sums, qd_objective_value* val);
+/* Adjoint sweep of the local shard seeded from the GLOBAL sums
+ * (src/optimproblem.cpp:495-519); grad_local[ndesign] still has to be summed
+ * over ranks (:527).  Rank 0 adds the Tikhonov / variation terms (:356-372). */
+int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const double* global_sums, double* grad_local);
+
+/* Single-rank convenience wrappers (nranks must be 1). */
+int qd_optim_evalF(qd_optim* o, const double* alpha, qd_objective_value* val);
+int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective_value* val, double* grad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUANDARY_AMD_H */

@@ -1,0 +1,1882 @@
+/*
+ * qd_oracle.c — CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing in the product (quandary_amd/, include/) may import, link or call
+ * this file.  It exists so that tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg have a scalar, one-initial-condition-at-a-time
+ * CPU statement of what LLNL/quandary computes on the path
+ *   MasterEq RHS  ->  TimeStepper (IMR/IMR4/IMR8/EE)  ->  OptimProblem evalF/evalGradF
+ * to check the HIP path against.  Parity status: PINNED — checked against the
+ * reference's own golden regression files (tests/regression/<case>/base, copied as numbers
+ * into tests/golden/) by tests/test_oracle_golden.py.
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * the reference repository).  PETSc itself (Vec container, KSPGMRES) is a
+ * third-party dependency that is not vendored in the reference; GMRES is
+ * restated here from its published algorithm (Saad & Schultz 1986: Arnoldi
+ * with modified Gram-Schmidt, Givens rotations, zero initial guess, no
+ * preconditioner, no restart within maxiter <= 30, stop when the recurrence
+ * residual norm <= max(rtol*||b||, abstol)), which is what KSPGMRES with
+ * PCNONE and the tolerances set at src/timestepper.cpp:541-550 computes.
+ *
+ * The input structs are the public ones from include/quandary_amd.h so the
+ * checker and the product are driven with byte-identical descriptions.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "quandary_amd.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define QO_MAXQ QD_MAX_OSC
+
+/* ------------------------------------------------------------------------- */
+/* system description                                                         */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int Q, lindblad, addT1, addT2;
+  int n[QO_MAXQ], ness[QO_MAXQ], post[QO_MAXQ];
+  int N, dim, dim_ess;
+  double detune[QO_MAXQ], xi[QO_MAXQ], g1[QO_MAXQ], g2[QO_MAXQ];
+  double xikl[QD_MAX_PAIRS], J[QD_MAX_PAIRS], eta[QD_MAX_PAIRS];
+  double* sq; /* sqrt table 0..maxn */
+} osys;
+
+typedef struct {
+  int type, nsplines, skip;
+  double tstart, tstop, dtknot, width;
+  double* tcenter;
+} oseg;
+
+typedef struct {
+  int nseg, ncar, nparams, npulse, offset;
+  oseg* seg;
+  double* car; /* rad/ns */
+  double *pt0, *pt1, *pamp;
+} oosc;
+
+typedef struct qo_ctx {
+  osys s;
+  oosc osc[QO_MAXQ];
+  int enforce_bc, ndesign;
+  int ntime;
+  double dt, Tfinal;
+  qd_solver sol;
+  double* params; /* [ndesign] */
+  /* scratch for the steppers, all 2*dim */
+  double *rhs, *stage, *stage_adj, *tmp, *err, *aux;
+  double* gm_V; /* GMRES basis (maxiter+1) x 2dim */
+  double *gm_H, *gm_cs, *gm_sn, *gm_g, *gm_y;
+  /* statistics */
+  long n_apply, n_steps;
+  /* control evaluated by assemble_RHS */
+  double p[QO_MAXQ], q[QO_MAXQ], cosj[QD_MAX_PAIRS], sinj[QD_MAX_PAIRS];
+} qo_ctx;
+
+static char qo_err[512];
+const char* qo_last_error(void) { return qo_err; }
+
+static int fail(const char* msg) {
+  snprintf(qo_err, sizeof qo_err, "%s", msg);
+  return -1;
+}
+
+/* src/mastereq.cpp:14-60 (dimensions, 2*pi scaling), src/oscillator.cpp:15-23,
+ * src/main.cpp:299-307 (eta), src/mastereq.cpp:1490-1497 (decay/dephase switches) */
+static int osys_init(osys* s, const qd_system* in) {
+  memset(s, 0, sizeof *s);
+  if (in->nosc < 1 || in->nosc > QO_MAXQ) return fail("nosc out of range");
+  s->Q = in->nosc;
+  s->lindblad = in->lindblad_type != QD_LINDBLAD_NONE;
+  s->addT1 = in->lindblad_type == QD_LINDBLAD_DECAY || in->lindblad_type == QD_LINDBLAD_BOTH;
+  s->addT2 = in->lindblad_type == QD_LINDBLAD_DEPHASE || in->lindblad_type == QD_LINDBLAD_BOTH;
+  s->N = 1;
+  s->dim_ess = 1;
+  int maxn = 0;
+  for (int k = 0; k < s->Q; k++) {
+    s->n[k] = in->nlevels[k];
+    s->ness[k] = in->nessential[k];
+    if (s->n[k] < 1) return fail("nlevels must be >= 1");
+    if (s->ness[k] > s->n[k] || s->ness[k] < 1) s->ness[k] = s->n[k];
+    s->N *= s->n[k];
+    s->dim_ess *= s->ness[k];
+    if (s->n[k] > maxn) maxn = s->n[k];
+  }
+  for (int k = 0; k < s->Q; k++) {
+    s->post[k] = 1;
+    for (int j = k + 1; j < s->Q; j++) s->post[k] *= s->n[j];
+  }
+  s->dim = s->lindblad ? s->N * s->N : s->N;
+  for (int k = 0; k < s->Q; k++) {
+    s->detune[k] = 2.0 * M_PI * (in->transfreq[k] - in->rotfreq[k]);
+    s->xi[k] = 2.0 * M_PI * in->selfkerr[k];
+    s->g1[k] = (in->decay_time[k] > 1e-14 && s->addT1) ? 1.0 / in->decay_time[k] : 0.0;
+    s->g2[k] = (in->dephase_time[k] > 1e-14 && s->addT2) ? 1.0 / in->dephase_time[k] : 0.0;
+  }
+  int idx = 0;
+  for (int k = 0; k < s->Q; k++)
+    for (int l = k + 1; l < s->Q; l++) {
+      s->xikl[idx] = 2.0 * M_PI * in->crosskerr[idx];
+      s->J[idx] = 2.0 * M_PI * in->Jkl[idx];
+      s->eta[idx] = 2.0 * M_PI * (in->rotfreq[k] - in->rotfreq[l]);
+      idx++;
+    }
+  s->sq = (double*)malloc(sizeof(double) * (size_t)(maxn + 2) * (size_t)(maxn + 2));
+  for (int i = 0; i < (maxn + 2) * (maxn + 2); i++) s->sq[i] = sqrt((double)i);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* controls: src/oscillator.cpp:45-132, :281-381; src/controlbasis.cpp:20-96, :219-254 */
+/* ------------------------------------------------------------------------- */
+static double bspline2_basis(const oseg* g, int id, double t) { /* controlbasis.cpp:81-96 */
+  double tau = (t - g->tcenter[id]) / g->width;
+  if (tau < -1. / 2. || tau >= 1. / 2.) return 0.0;
+  double val = 0.0;
+  if (-1. / 2. <= tau && tau < -1. / 6.) val = 9. / 8. + 9. / 2. * tau + 9. / 2. * tau * tau;
+  else if (-1. / 6. <= tau && tau < 1. / 6.) val = 3. / 4. - 9. * tau * tau;
+  else if (1. / 6. <= tau && tau < 1. / 2.) val = 9. / 8. - 9. / 2. * tau + 9. / 2. * tau * tau;
+  return val;
+}
+
+static void seg_evaluate(const qo_ctx* c, const oseg* g, const double* coeff, int f, double t, double* b1, double* b2) {
+  if (g->type == QD_CTRL_BSPLINE) { /* controlbasis.cpp:48-66 */
+    double s1 = 0.0, s2 = 0.0;
+    for (int l = 0; l < g->nsplines; l++) {
+      if (c->enforce_bc && (l <= 1 || l >= g->nsplines - 2)) continue;
+      double B = bspline2_basis(g, l, t);
+      s1 += coeff[g->skip + f * g->nsplines * 2 + l] * B;
+      s2 += coeff[g->skip + f * g->nsplines * 2 + l + g->nsplines] * B;
+    }
+    *b1 = s1;
+    *b2 = s2;
+  } else { /* BSpline0, controlbasis.cpp:230-243 */
+    int id = (int)ceil((t - g->tstart) / g->dtknot - 0.5);
+    if (id < 0 || id >= g->nsplines) {
+      *b1 = 0.0;
+      *b2 = 0.0;
+    } else {
+      *b1 = coeff[g->skip + f * g->nsplines * 2 + id];
+      *b2 = coeff[g->skip + f * g->nsplines * 2 + id + g->nsplines];
+    }
+  }
+}
+
+static void seg_derivative(const qo_ctx* c, const oseg* g, double* cd, double v1, double v2, int f, double t) {
+  if (g->type == QD_CTRL_BSPLINE) { /* controlbasis.cpp:68-79 */
+    for (int l = 0; l < g->nsplines; l++) {
+      if (c->enforce_bc && (l <= 1 || l >= g->nsplines - 2)) continue;
+      double B = bspline2_basis(g, l, t);
+      cd[g->skip + f * g->nsplines * 2 + l] += B * v1;
+      cd[g->skip + f * g->nsplines * 2 + l + g->nsplines] += B * v2;
+    }
+  } else { /* controlbasis.cpp:245-254 */
+    int id = (int)ceil((t - g->tstart) / g->dtknot - 0.5);
+    if (id >= 0 && id < g->nsplines) {
+      cd[g->skip + f * g->nsplines * 2 + id] += v1;
+      cd[g->skip + f * g->nsplines * 2 + id + g->nsplines] += v2;
+    }
+  }
+}
+
+/* Oscillator::evalControl, src/oscillator.cpp:281-337 */
+static int eval_control(const qo_ctx* c, int k, double t, double* p, double* q) {
+  const oosc* o = &c->osc[k];
+  *p = 0.0;
+  *q = 0.0;
+  if (t > c->Tfinal) return fail("evalControl: t > Tfinal");
+  if (o->nparams > 0) {
+    const double* coeff = c->params + o->offset;
+    for (int b = 0; b < o->nseg; b++) {
+      const oseg* g = &o->seg[b];
+      if (g->tstart <= t && g->tstop >= t) {
+        double sp = 0.0, sqv = 0.0;
+        for (int f = 0; f < o->ncar; f++) {
+          double b1, b2;
+          seg_evaluate(c, g, coeff, f, t, &b1, &b2);
+          double co = cos(o->car[f] * t), si = sin(o->car[f] * t);
+          sp += co * b1 - si * b2;
+          sqv += si * b1 + co * b2;
+        }
+        *p = sp;
+        *q = sqv;
+        break;
+      }
+    }
+  }
+  for (int i = 0; i < o->npulse; i++)
+    if (o->pt0[i] <= t && t <= o->pt1[i]) {
+      double a = o->pamp[i] / sqrt(2.0);
+      *p = a;
+      *q = a;
+    }
+  return 0;
+}
+
+/* Oscillator::evalControl_diff, src/oscillator.cpp:339-381; grad points at this oscillator's block */
+static void eval_control_diff(const qo_ctx* c, int k, double t, double* grad, double pbar, double qbar) {
+  const oosc* o = &c->osc[k];
+  if (o->nparams > 0) {
+    for (int b = 0; b < o->nseg; b++) {
+      const oseg* g = &o->seg[b];
+      if (g->tstart <= t && g->tstop >= t) {
+        for (int f = 0; f < o->ncar; f++) {
+          double co = cos(o->car[f] * t), si = sin(o->car[f] * t);
+          double b1 = si * qbar + co * pbar;
+          double b2 = co * qbar - si * pbar;
+          seg_derivative(c, g, grad, b1, b2, f, t);
+        }
+        break;
+      }
+    }
+  }
+}
+
+/* BSpline0::computeVariation(_diff), src/controlbasis.cpp:257-312; base class returns 0 */
+static double control_variation(const qo_ctx* c) {
+  double var = 0.0;
+  for (int k = 0; k < c->s.Q; k++) {
+    const oosc* o = &c->osc[k];
+    if (o->nparams == 0) continue;
+    const double* pr = c->params + o->offset;
+    for (int b = 0; b < o->nseg; b++) {
+      const oseg* g = &o->seg[b];
+      if (g->type != QD_CTRL_BSPLINE0) continue;
+      int ns = g->nsplines;
+      for (int f = 0; f < o->ncar; f++) {
+        for (int lc = 1; lc < ns; lc++) {
+          double d = pr[g->skip + 2 * f * ns + lc] - pr[g->skip + 2 * f * ns + lc - 1];
+          var += d * d;
+        }
+        for (int lc = 1; lc < ns; lc++) {
+          double d = pr[g->skip + (2 * f + 1) * ns + lc] - pr[g->skip + (2 * f + 1) * ns + lc - 1];
+          var += d * d;
+        }
+        if (c->enforce_bc) {
+          double a;
+          a = pr[g->skip + 2 * f * ns]; var += a * a;
+          a = pr[g->skip + 2 * f * ns + ns - 1]; var += a * a;
+          a = pr[g->skip + (2 * f + 1) * ns]; var += a * a;
+          a = pr[g->skip + (2 * f + 1) * ns + ns - 1]; var += a * a;
+        }
+      }
+    }
+  }
+  return var;
+}
+
+static void control_variation_diff(const qo_ctx* c, double* G, double var_bar) {
+  for (int k = 0; k < c->s.Q; k++) {
+    const oosc* o = &c->osc[k];
+    if (o->nparams == 0) continue;
+    const double* pr = c->params + o->offset;
+    double* gr = G + o->offset;
+    double fact = 2.0 * var_bar;
+    for (int b = 0; b < o->nseg; b++) {
+      const oseg* g = &o->seg[b];
+      if (g->type != QD_CTRL_BSPLINE0) continue;
+      int ns = g->nsplines;
+      for (int f = 0; f < o->ncar; f++) {
+        for (int part = 0; part < 2; part++) {
+          int base = g->skip + (2 * f + part) * ns;
+          gr[base] += fact * (pr[base] - pr[base + 1]);
+          for (int lc = 1; lc < ns - 1; lc++) gr[base + lc] += fact * (2 * pr[base + lc] - pr[base + lc - 1] - pr[base + lc + 1]);
+          gr[base + ns - 1] += fact * (pr[base + ns - 1] - pr[base + ns - 2]);
+        }
+        if (c->enforce_bc) {
+          int b0 = g->skip + 2 * f * ns;
+          gr[b0] += fact * pr[b0];
+          gr[b0 + ns - 1] += fact * pr[b0 + ns - 1];
+          gr[b0 + ns] += fact * pr[b0 + ns];
+          gr[b0 + 2 * ns - 1] += fact * pr[b0 + 2 * ns - 1];
+        }
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* RHS: src/mastereq.cpp:657-678 (assemble), :1464-1709 (apply / transpose),   */
+/* include/mastereq.hpp:316-912 (stencil inlines), generic in Q.              */
+/* ------------------------------------------------------------------------- */
+static int assemble_rhs(qo_ctx* c, double t) {
+  for (int k = 0; k < c->s.Q; k++)
+    if (eval_control(c, k, t, &c->p[k], &c->q[k])) return -1;
+  int np = c->s.Q * (c->s.Q - 1) / 2;
+  for (int k = 0; k < np; k++) {
+    c->cosj[k] = cos(c->s.eta[k] * t);
+    c->sinj[k] = sin(c->s.eta[k] * t);
+  }
+  return 0;
+}
+
+/* y = M x or M^T x with the controls/cos/sin currently held in the context */
+static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
+  const osys* s = &c->s;
+  const int Q = s->Q, N = s->N, dim = s->dim;
+  const double* sq = s->sq;
+  int i[QO_MAXQ], ip[QO_MAXQ];
+  int np[QO_MAXQ]; /* primed level counts: n (Lindblad) or 1 (Schroedinger), mastereq.cpp:1512-1517 */
+  int stp[QO_MAXQ];
+  for (int k = 0; k < Q; k++) {
+    i[k] = 0;
+    ip[k] = 0;
+    np[k] = s->lindblad ? s->n[k] : 1;
+    stp[k] = N * s->post[k];
+  }
+  c->n_apply++;
+  for (int it = 0; it < dim; it++) {
+    const double xre = x[it], xim = x[it + dim];
+    /* diagonal: mastereq.hpp:316-433, mastereq.cpp:1526-1551 / :1650-1675 */
+    double hd = 0.0, hdp = 0.0, dd = 0.0;
+    int pair = 0;
+    for (int k = 0; k < Q; k++) {
+      hd += s->detune[k] * i[k] - s->xi[k] / 2.0 * i[k] * (i[k] - 1);
+      for (int l = k + 1; l < Q; l++) hd -= s->xikl[pair++] * i[k] * i[l];
+    }
+    if (s->lindblad) {
+      pair = 0;
+      for (int k = 0; k < Q; k++) {
+        hdp += s->detune[k] * ip[k] - s->xi[k] / 2.0 * ip[k] * (ip[k] - 1);
+        for (int l = k + 1; l < Q; l++) hdp -= s->xikl[pair++] * ip[k] * ip[l];
+        dd += s->g2[k] * (i[k] * ip[k] - 0.5 * (i[k] * i[k] + ip[k] * ip[k])) - s->g1[k] / 2.0 * (i[k] + ip[k]);
+      }
+    }
+    double yre, yim;
+    if (!transpose) {
+      yre = (hd - hdp) * xim;
+      yim = (-hd + hdp) * xre;
+    } else {
+      yre = (-hd + hdp) * xim;
+      yim = (hd - hdp) * xre;
+    }
+    if (s->lindblad) {
+      yre += dd * xre;
+      yim += dd * xim;
+    }
+    /* dipole-dipole coupling: mastereq.hpp:632-741 */
+    pair = 0;
+    for (int k = 0; k < Q; k++)
+      for (int l = k + 1; l < Q; l++, pair++) {
+        const double Jij = s->J[pair];
+        if (!(fabs(Jij) > 1e-10)) continue;
+        const double co = c->cosj[pair], si = c->sinj[pair];
+        const int ni = s->n[k], nj = s->n[l], nip = np[k], njp = np[l];
+        const int a = i[k], b = i[l], ap = ip[k], bp = ip[l];
+        const int sk = s->post[k], sl = s->post[l], skp = stp[k], slp = stp[l];
+        if (!transpose) {
+          if (a > 0 && b < nj - 1) {
+            int itx = it - sk + sl; double ur = x[itx], ui = x[itx + dim], sv = sq[a * (b + 1)];
+            yre += Jij * sv * (co * ui + si * ur);
+            yim += Jij * sv * (-co * ur + si * ui);
+          }
+          if (a < ni - 1 && b > 0) {
+            int itx = it + sk - sl; double ur = x[itx], ui = x[itx + dim], sv = sq[b * (a + 1)];
+            yre += Jij * sv * (co * ui - si * ur);
+            yim += Jij * sv * (-co * ur - si * ui);
+          }
+          if (ap > 0 && bp < njp - 1) {
+            int itx = it - skp + slp; double ur = x[itx], ui = x[itx + dim], sv = sq[ap * (bp + 1)];
+            yre += Jij * sv * (-co * ui + si * ur);
+            yim += Jij * sv * (co * ur + si * ui);
+          }
+          if (ap < nip - 1 && bp > 0) {
+            int itx = it + skp - slp; double ur = x[itx], ui = x[itx + dim], sv = sq[bp * (ap + 1)];
+            yre += Jij * sv * (-co * ui - si * ur);
+            yim += Jij * sv * (co * ur - si * ui);
+          }
+        } else {
+          if (a < ni - 1 && b > 0) {
+            int itx = it + sk - sl; double ur = x[itx], ui = x[itx + dim], sv = sq[b * (a + 1)];
+            yre += Jij * sv * (-co * ui + si * ur);
+            yim += Jij * sv * (co * ur + si * ui);
+          }
+          if (a > 0 && b < nj - 1) {
+            int itx = it - sk + sl; double ur = x[itx], ui = x[itx + dim], sv = sq[a * (b + 1)];
+            yre += Jij * sv * (-co * ui - si * ur);
+            yim += Jij * sv * (co * ur - si * ui);
+          }
+          if (ap < nip - 1 && bp > 0) {
+            int itx = it + skp - slp; double ur = x[itx], ui = x[itx + dim], sv = sq[bp * (ap + 1)];
+            yre += Jij * sv * (co * ui + si * ur);
+            yim += Jij * sv * (-co * ur + si * ui);
+          }
+          if (ap > 0 && bp < njp - 1) {
+            int itx = it - skp + slp; double ur = x[itx], ui = x[itx + dim], sv = sq[ap * (bp + 1)];
+            yre += Jij * sv * (co * ui - si * ur);
+            yim += Jij * sv * (-co * ur - si * ui);
+          }
+        }
+      }
+    /* T1 off-diagonal: mastereq.hpp:758-797 */
+    if (s->lindblad) {
+      for (int k = 0; k < Q; k++) {
+        const double g1 = s->g1[k];
+        if (!(fabs(g1) > 1e-12)) continue;
+        if (!transpose) {
+          if (i[k] < s->n[k] - 1 && ip[k] < s->n[k] - 1) {
+            double l1 = g1 * sq[(i[k] + 1) * (ip[k] + 1)];
+            int itx = it + s->post[k] + stp[k];
+            yre += l1 * x[itx];
+            yim += l1 * x[itx + dim];
+          }
+        } else {
+          if (i[k] > 0 && ip[k] > 0) {
+            double l1 = g1 * sq[i[k] * ip[k]];
+            int itx = it - s->post[k] - stp[k];
+            yre += l1 * x[itx];
+            yim += l1 * x[itx + dim];
+          }
+        }
+      }
+    }
+    /* control: mastereq.hpp:818-912 */
+    for (int k = 0; k < Q; k++) {
+      const double pt = c->p[k], qt = c->q[k];
+      const int n = s->n[k], npk = np[k], a = i[k], ap = ip[k], st = s->post[k], stq = stp[k];
+      if (!transpose) {
+        if (a < n - 1) {
+          int itx = it + st; double ur = x[itx], ui = x[itx + dim], sv = sq[a + 1];
+          yre += sv * (pt * ui + qt * ur);
+          yim += sv * (-pt * ur + qt * ui);
+        }
+        if (ap < npk - 1) {
+          int itx = it + stq; double ur = x[itx], ui = x[itx + dim], sv = sq[ap + 1];
+          yre += sv * (-pt * ui + qt * ur);
+          yim += sv * (pt * ur + qt * ui);
+        }
+        if (a > 0) {
+          int itx = it - st; double ur = x[itx], ui = x[itx + dim], sv = sq[a];
+          yre += sv * (pt * ui - qt * ur);
+          yim += sv * (-pt * ur - qt * ui);
+        }
+        if (ap > 0) {
+          int itx = it - stq; double ur = x[itx], ui = x[itx + dim], sv = sq[ap];
+          yre += sv * (-pt * ui - qt * ur);
+          yim += sv * (pt * ur - qt * ui);
+        }
+      } else {
+        if (a > 0) {
+          int itx = it - st; double ur = x[itx], ui = x[itx + dim], sv = sq[a];
+          yre += sv * (-pt * ui + qt * ur);
+          yim += sv * (pt * ur + qt * ui);
+        }
+        if (ap > 0) {
+          int itx = it - stq; double ur = x[itx], ui = x[itx + dim], sv = sq[ap];
+          yre += sv * (pt * ui + qt * ur);
+          yim += sv * (-pt * ur + qt * ui);
+        }
+        if (a < n - 1) {
+          int itx = it + st; double ur = x[itx], ui = x[itx + dim], sv = sq[a + 1];
+          yre += sv * (-pt * ui - qt * ur);
+          yim += sv * (pt * ur - qt * ui);
+        }
+        if (ap < npk - 1) {
+          int itx = it + stq; double ur = x[itx], ui = x[itx + dim], sv = sq[ap + 1];
+          yre += sv * (pt * ui - qt * ur);
+          yim += sv * (-pt * ur - qt * ui);
+        }
+      }
+    }
+    y[it] = yre;
+    y[it + dim] = yim;
+    /* advance the odometer: storage order (i0',..,iQ-1' ; i0,..,iQ-1), last fastest */
+    int k = Q - 1;
+    while (k >= 0) {
+      if (++i[k] < s->n[k]) break;
+      i[k] = 0;
+      k--;
+    }
+    if (k < 0) {
+      k = Q - 1;
+      while (k >= 0) {
+        if (++ip[k] < np[k]) break;
+        ip[k] = 0;
+        k--;
+      }
+    }
+  }
+}
+
+/* compute_dRHS_dParams_matfree, src/mastereq.cpp:970-1276 + dRHSdp_getcoeffs (mastereq.hpp:553-604).
+ * grad += evalControl_diff(t, alpha*coeff_p, alpha*coeff_q) for every oscillator. */
+static void drhs_dparams(qo_ctx* c, double t, const double* x, const double* xbar, double alpha, double* grad) {
+  const osys* s = &c->s;
+  const int Q = s->Q, N = s->N, dim = s->dim;
+  const double* sq = s->sq;
+  double cp[QO_MAXQ], cq[QO_MAXQ];
+  int i[QO_MAXQ], ip[QO_MAXQ], np[QO_MAXQ];
+  for (int k = 0; k < Q; k++) {
+    cp[k] = cq[k] = 0.0;
+    i[k] = ip[k] = 0;
+    np[k] = s->lindblad ? s->n[k] : 1;
+  }
+  for (int it = 0; it < dim; it++) {
+    const double br = xbar[it], bi = xbar[it + dim];
+    for (int k = 0; k < Q; k++) {
+      double ppr = 0, ppi = 0, qqr = 0, qqi = 0;
+      const int st = s->post[k], stq = N * s->post[k];
+      if (i[k] < s->n[k] - 1) {
+        int itx = it + st; double ur = x[itx], ui = x[itx + dim], sv = sq[i[k] + 1];
+        ppr += sv * ui; ppi += -sv * ur; qqr += sv * ur; qqi += sv * ui;
+      }
+      if (ip[k] < np[k] - 1) {
+        int itx = it + stq; double ur = x[itx], ui = x[itx + dim], sv = sq[ip[k] + 1];
+        ppr += -sv * ui; ppi += sv * ur; qqr += sv * ur; qqi += sv * ui;
+      }
+      if (i[k] > 0) {
+        int itx = it - st; double ur = x[itx], ui = x[itx + dim], sv = sq[i[k]];
+        ppr += sv * ui; ppi += -sv * ur; qqr += -sv * ur; qqi += -sv * ui;
+      }
+      if (ip[k] > 0) {
+        int itx = it - stq; double ur = x[itx], ui = x[itx + dim], sv = sq[ip[k]];
+        ppr += -sv * ui; ppi += sv * ur; qqr += -sv * ur; qqi += -sv * ui;
+      }
+      cp[k] += ppr * br + ppi * bi;
+      cq[k] += qqr * br + qqi * bi;
+    }
+    int k = Q - 1;
+    while (k >= 0) {
+      if (++i[k] < s->n[k]) break;
+      i[k] = 0;
+      k--;
+    }
+    if (k < 0) {
+      k = Q - 1;
+      while (k >= 0) {
+        if (++ip[k] < np[k]) break;
+        ip[k] = 0;
+        k--;
+      }
+    }
+  }
+  for (int k = 0; k < Q; k++) eval_control_diff(c, k, t, grad + c->osc[k].offset, alpha * cp[k], alpha * cq[k]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* small BLAS-1                                                               */
+/* ------------------------------------------------------------------------- */
+static double vdot(int n, const double* a, const double* b) {
+  double s = 0.0;
+  for (int i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+static double vnorm(int n, const double* a) { return sqrt(vdot(n, a, a)); }
+static void vaxpy(int n, double al, const double* x, double* y) {
+  for (int i = 0; i < n; i++) y[i] += al * x[i];
+}
+
+/* ------------------------------------------------------------------------- */
+/* linear solvers for (I - alpha M^{(T)}) y = b                               */
+/* ------------------------------------------------------------------------- */
+/* ImplMidpoint::NeumannSolve, src/timestepper.cpp:697-727 */
+static int neumann_solve(qo_ctx* c, const double* b, double* y, double alpha, int transpose) {
+  const int n2 = 2 * c->s.dim;
+  double errnorm = 0.0, errnorm0 = 1.0;
+  memcpy(y, b, sizeof(double) * n2);
+  int iter;
+  for (iter = 0; iter < c->sol.maxiter; iter++) {
+    memcpy(c->err, y, sizeof(double) * n2);
+    apply_rhs(c, transpose, y, c->tmp);
+    for (int i = 0; i < n2; i++) y[i] = b[i] + alpha * c->tmp[i];
+    for (int i = 0; i < n2; i++) c->err[i] -= y[i];
+    errnorm = vnorm(n2, c->err);
+    if (iter == 0) errnorm0 = errnorm;
+    if (errnorm < c->sol.abstol) break;
+    if (errnorm / errnorm0 < c->sol.reltol) break;
+  }
+  return iter;
+}
+
+/* GMRES (see file header): stands in for KSPSolve / KSPSolveTranspose at
+ * src/timestepper.cpp:602, :652, :674 with the operator scaled/shifted as at :600-601 */
+static int gmres_solve(qo_ctx* c, const double* b, double* y, double alpha, int transpose) {
+  const int n2 = 2 * c->s.dim;
+  const int m = c->sol.maxiter;
+  double* V = c->gm_V;
+  double* H = c->gm_H; /* (m+1) x m, column-major with ld m+1 */
+  double *cs = c->gm_cs, *sn = c->gm_sn, *g = c->gm_g;
+  const int ldh = m + 1;
+  memset(y, 0, sizeof(double) * n2);
+  double beta = vnorm(n2, b);
+  double ttol = c->sol.reltol * beta;
+  if (ttol < c->sol.abstol) ttol = c->sol.abstol;
+  if (beta <= ttol || m <= 0) return 0;
+  for (int i = 0; i < n2; i++) V[i] = b[i] / beta;
+  memset(g, 0, sizeof(double) * (m + 1));
+  g[0] = beta;
+  int j;
+  for (j = 0; j < m; j++) {
+    double* w = V + (size_t)(j + 1) * n2;
+    const double* vj = V + (size_t)j * n2;
+    apply_rhs(c, transpose, vj, c->tmp);
+    for (int i = 0; i < n2; i++) w[i] = vj[i] - alpha * c->tmp[i];
+    for (int k = 0; k <= j; k++) {
+      const double* vk = V + (size_t)k * n2;
+      double h = vdot(n2, w, vk);
+      H[k + j * ldh] = h;
+      vaxpy(n2, -h, vk, w);
+    }
+    double hn = vnorm(n2, w);
+    H[j + 1 + j * ldh] = hn;
+    if (hn > 0.0)
+      for (int i = 0; i < n2; i++) w[i] /= hn;
+    for (int k = 0; k < j; k++) {
+      double t1 = cs[k] * H[k + j * ldh] + sn[k] * H[k + 1 + j * ldh];
+      H[k + 1 + j * ldh] = -sn[k] * H[k + j * ldh] + cs[k] * H[k + 1 + j * ldh];
+      H[k + j * ldh] = t1;
+    }
+    double a = H[j + j * ldh], bb = H[j + 1 + j * ldh];
+    double r = hypot(a, bb);
+    if (r == 0.0) { cs[j] = 1.0; sn[j] = 0.0; } else { cs[j] = a / r; sn[j] = bb / r; }
+    H[j + j * ldh] = r;
+    H[j + 1 + j * ldh] = 0.0;
+    g[j + 1] = -sn[j] * g[j];
+    g[j] = cs[j] * g[j];
+    if (fabs(g[j + 1]) <= ttol || hn == 0.0) { j++; break; }
+  }
+  const int k = j; /* number of columns */
+  double* yv = c->gm_y;
+  for (int r = k - 1; r >= 0; r--) {
+    double sum = g[r];
+    for (int cc = r + 1; cc < k; cc++) sum -= H[r + cc * ldh] * yv[cc];
+    yv[r] = sum / H[r + r * ldh];
+  }
+  for (int cc = 0; cc < k; cc++) vaxpy(n2, yv[cc], V + (size_t)cc * n2, y);
+  return k;
+}
+
+static int lin_solve(qo_ctx* c, const double* b, double* y, double alpha, int transpose) {
+  if (c->sol.linsolve == QD_LINSOLVE_NEUMANN) return neumann_solve(c, b, y, alpha, transpose);
+  return gmres_solve(c, b, y, alpha, transpose);
+}
+
+/* ------------------------------------------------------------------------- */
+/* one-step integrators                                                       */
+/* ------------------------------------------------------------------------- */
+/* ImplMidpoint::evolveFWD, src/timestepper.cpp:584-629 */
+static int imr_fwd(qo_ctx* c, double tstart, double tstop, double* x) {
+  const int n2 = 2 * c->s.dim;
+  const double dt = tstop - tstart;
+  if (assemble_rhs(c, (tstart + tstop) / 2.0)) return -1;
+  apply_rhs(c, 0, x, c->rhs);
+  lin_solve(c, c->rhs, c->stage, dt / 2.0, 0);
+  vaxpy(n2, dt, c->stage, x);
+  return 0;
+}
+
+/* ImplMidpoint::evolveBWD, src/timestepper.cpp:631-694 */
+static int imr_bwd(qo_ctx* c, double tstop, double tstart, const double* x, double* xadj, double* grad, int compute_gradient) {
+  const int n2 = 2 * c->s.dim;
+  const double dt = tstop - tstart;
+  const double thalf = (tstart + tstop) / 2.0;
+  if (assemble_rhs(c, thalf)) return -1;
+  if (compute_gradient) apply_rhs(c, 0, x, c->rhs);
+  lin_solve(c, xadj, c->stage_adj, dt / 2.0, 1);
+  for (int i = 0; i < n2; i++) c->stage_adj[i] *= dt;
+  if (compute_gradient) {
+    lin_solve(c, c->rhs, c->stage, dt / 2.0, 0);
+    for (int i = 0; i < n2; i++) c->stage[i] = x[i] + dt / 2.0 * c->stage[i];
+    drhs_dparams(c, thalf, c->stage, c->stage_adj, 1.0, grad);
+  }
+  apply_rhs(c, 1, c->stage_adj, c->tmp);
+  vaxpy(n2, 1.0, c->tmp, xadj);
+  return 0;
+}
+
+/* CompositionalImplMidpoint coefficients, src/timestepper.cpp:735-757 */
+static int comp_gamma(int stepper, double* gam) {
+  if (stepper == QD_STEPPER_IMR8) {
+    static const double g8[15] = {0.74167036435061295344822780,  -0.40910082580003159399730010, 0.19075471029623837995387626,
+                                  -0.57386247111608226665638773, 0.29906418130365592384446354,  0.33462491824529818378495798,
+                                  0.31529309239676659663205666,  -0.79688793935291635401978884, 0.31529309239676659663205666,
+                                  0.33462491824529818378495798,  0.29906418130365592384446354,  -0.57386247111608226665638773,
+                                  0.19075471029623837995387626,  -0.40910082580003159399730010, 0.74167036435061295344822780};
+    memcpy(gam, g8, sizeof g8);
+    return 15;
+  }
+  if (stepper == QD_STEPPER_IMR4) {
+    gam[0] = 1. / (2. - pow(2., 1. / 3.));
+    gam[1] = -pow(2., 1. / 3.) * gam[0];
+    gam[2] = 1. / (2. - pow(2., 1. / 3.));
+    return 3;
+  }
+  gam[0] = 1.0;
+  return 1;
+}
+
+/* evolveFWD dispatch: ImplMidpoint (:584), CompositionalImplMidpoint (:784-802), ExplEuler (:493-504) */
+static int evolve_fwd(qo_ctx* c, double tstart, double tstop, double* x) {
+  c->n_steps++;
+  if (c->sol.stepper == QD_STEPPER_EE) {
+    const int n2 = 2 * c->s.dim;
+    if (assemble_rhs(c, tstart)) return -1;
+    apply_rhs(c, 0, x, c->stage);
+    vaxpy(n2, tstop - tstart, c->stage, x);
+    return 0;
+  }
+  if (c->sol.stepper == QD_STEPPER_IMR) return imr_fwd(c, tstart, tstop, x);
+  double gam[15];
+  int ns = comp_gamma(c->sol.stepper, gam);
+  double dt = tstop - tstart, tcurr = tstart;
+  for (int s = 0; s < ns; s++) {
+    double dts = gam[s] * dt;
+    if (imr_fwd(c, tcurr, tcurr + dts, x)) return -1;
+    tcurr += dts;
+  }
+  return 0;
+}
+
+/* evolveBWD dispatch: ImplMidpoint (:631), Compositional (:804-826), ExplEuler (:506-520) */
+static int evolve_bwd(qo_ctx* c, double tstop, double tstart, const double* x, double* xadj, double* grad, double* xstage_buf) {
+  const int n2 = 2 * c->s.dim;
+  if (c->sol.stepper == QD_STEPPER_EE) {
+    double dt = tstop - tstart;
+    /* compute_dRHS_dParams evaluates its own controls at tstop (mastereq.cpp:1262-1272) but the state
+       coefficients do not depend on the assembled RHS */
+    drhs_dparams(c, tstop, x, xadj, dt, grad);
+    if (assemble_rhs(c, tstop)) return -1;
+    apply_rhs(c, 1, xadj, c->stage);
+    vaxpy(n2, dt, c->stage, xadj);
+    return 0;
+  }
+  if (c->sol.stepper == QD_STEPPER_IMR) return imr_bwd(c, tstop, tstart, x, xadj, grad, 1);
+  double gam[15];
+  int ns = comp_gamma(c->sol.stepper, gam);
+  double dt = tstop - tstart, tcurr = tstart;
+  memcpy(c->aux, x, sizeof(double) * n2);
+  for (int s = 0; s < ns; s++) {
+    memcpy(xstage_buf + (size_t)s * n2, c->aux, sizeof(double) * n2);
+    double dts = gam[s] * dt;
+    if (imr_fwd(c, tcurr, tcurr + dts, c->aux)) return -1;
+    tcurr += dts;
+  }
+  for (int s = ns - 1; s >= 0; s--) {
+    double dts = gam[s] * dt;
+    if (imr_bwd(c, tcurr, tcurr - dts, xstage_buf + (size_t)s * n2, xadj, grad, 1)) return -1;
+    tcurr -= gam[s] * dt;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* index helpers: src/util.cpp:150-278                                        */
+/* ------------------------------------------------------------------------- */
+static int map_ess_to_full(const osys* s, int i) { /* util.cpp:155-175 */
+  int id = 0, index = i;
+  for (int k = 0; k < s->Q - 1; k++) {
+    int postdim = 1, postdim_ess = 1;
+    for (int j = k + 1; j < s->Q; j++) {
+      postdim *= s->n[j];
+      postdim_ess *= s->ness[j];
+    }
+    int iblock = index / postdim_ess;
+    index = index % postdim_ess;
+    id += iblock * postdim;
+  }
+  return id + index;
+}
+static int map_full_to_ess(const osys* s, int i) { /* util.cpp:177-196 */
+  int id = 0, index = i;
+  for (int k = 0; k < s->Q; k++) {
+    int postdim = 1, postdim_ess = 1;
+    for (int j = k + 1; j < s->Q; j++) {
+      postdim *= s->n[j];
+      postdim_ess *= s->ness[j];
+    }
+    int iblock = index / postdim;
+    index = index % postdim;
+    if (iblock >= s->ness[k]) return -1;
+    id += iblock * postdim_ess;
+  }
+  return id;
+}
+static int is_guard_level(const osys* s, int i) { /* util.cpp:259-278 */
+  int index = i;
+  for (int k = 0; k < s->Q; k++) {
+    int postdim = s->post[k];
+    int itest = index / postdim;
+    if (itest == s->n[k] - 1 && itest >= s->ness[k]) return 1;
+    index = index % postdim;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* optimisation target: src/optimtarget.cpp                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int initcond_type, target_type, objective_type;
+  int n_ids, ids[QO_MAXQ];
+  int purestate_id;
+  int ninit;
+  double purity;
+  double* rho0_fixed;   /* PURE / FROMFILE / ENSEMBLE: prepared once */
+  double* targetstate;  /* GATE / FROMFILE */
+  double *Vre, *Vim;    /* rotated, lifted gate V_f (N x N, row-major) */
+  double* aux;
+} otarget;
+
+/* Gate::assembleGate rotation (src/gate.cpp:98-132) + lifting to full dimension (:148-249).
+ * The lifted gate is V_f = P V_e P^T + identity on non-essential levels; the Lindblad
+ * superoperator conj(V_f) (x) V_f is applied as V_f rho V_f^dagger. */
+static void build_gate(const osys* s, const qd_objective* ob, double Tfinal, otarget* tg) {
+  const int de = s->dim_ess, N = s->N;
+  double* vr = (double*)calloc((size_t)de * de, sizeof(double));
+  double* vi = (double*)calloc((size_t)de * de, sizeof(double));
+  for (int row = 0; row < de; row++) {
+    int r = row;
+    double freq = 0.0;
+    for (int k = 0; k < s->Q; k++) {
+      int dim_post = 1;
+      for (int j = k + 1; j < s->Q; j++) dim_post *= s->ness[j];
+      int rk = r / dim_post;
+      freq += rk * 2.0 * M_PI * ob->gate_rot_freq[k];
+      r = r % dim_post;
+    }
+    double ra = cos(freq * Tfinal), rb = sin(freq * Tfinal);
+    for (int cidx = 0; cidx < de; cidx++) {
+      double a = ob->gate_re[row * de + cidx], b = ob->gate_im ? ob->gate_im[row * de + cidx] : 0.0;
+      vr[row * de + cidx] = ra * a - rb * b;
+      vi[row * de + cidx] = ra * b + rb * a;
+    }
+  }
+  tg->Vre = (double*)calloc((size_t)N * N, sizeof(double));
+  tg->Vim = (double*)calloc((size_t)N * N, sizeof(double));
+  for (int rf = 0; rf < N; rf++) {
+    int re = map_full_to_ess(s, rf);
+    if (re < 0) {
+      tg->Vre[rf * N + rf] = 1.0;
+      continue;
+    }
+    for (int ce = 0; ce < de; ce++) {
+      int cf = map_ess_to_full(s, ce);
+      tg->Vre[rf * N + cf] = vr[re * de + ce];
+      tg->Vim[rf * N + cf] = vi[re * de + ce];
+    }
+  }
+  free(vr);
+  free(vi);
+}
+
+/* Gate::applyGate, src/gate.cpp:260-283 */
+static void apply_gate(const osys* s, const otarget* tg, const double* x, double* out) {
+  const int N = s->N, dim = s->dim;
+  if (!s->lindblad) {
+    for (int r = 0; r < N; r++) {
+      double ar = 0, ai = 0;
+      for (int c = 0; c < N; c++) {
+        double vr = tg->Vre[r * N + c], vi = tg->Vim[r * N + c];
+        ar += vr * x[c] - vi * x[c + dim];
+        ai += vr * x[c + dim] + vi * x[c];
+      }
+      out[r] = ar;
+      out[r + dim] = ai;
+    }
+    return;
+  }
+  /* T = V rho ; out = T V^dagger ; rho(r,c) at r + c*N */
+  double* Tr = (double*)calloc((size_t)N * N, sizeof(double));
+  double* Ti = (double*)calloc((size_t)N * N, sizeof(double));
+  for (int r = 0; r < N; r++)
+    for (int k = 0; k < N; k++) {
+      double vr = tg->Vre[r * N + k], vi = tg->Vim[r * N + k];
+      if (vr == 0.0 && vi == 0.0) continue;
+      for (int c = 0; c < N; c++) {
+        double xr = x[k + c * N], xi = x[k + c * N + dim];
+        Tr[r + c * N] += vr * xr - vi * xi;
+        Ti[r + c * N] += vr * xi + vi * xr;
+      }
+    }
+  for (int i = 0; i < 2 * dim; i++) out[i] = 0.0;
+  for (int c = 0; c < N; c++)
+    for (int k = 0; k < N; k++) {
+      double vr = tg->Vre[c * N + k], vi = -tg->Vim[c * N + k]; /* conj(V[c][k]) */
+      if (vr == 0.0 && vi == 0.0) continue;
+      for (int r = 0; r < N; r++) {
+        double tr = Tr[r + k * N], ti = Ti[r + k * N];
+        out[r + c * N] += tr * vr - ti * vi;
+        out[r + c * N + dim] += tr * vi + ti * vr;
+      }
+    }
+  free(Tr);
+  free(Ti);
+}
+
+static int vec_id(int row, int col, int N) { return row + col * N; } /* util.cpp:150-152 */
+
+/* number of initial conditions, src/main.cpp:89-128 */
+static int count_ninit(const osys* s, const qd_objective* ob) {
+  switch (ob->initcond_type) {
+    case QD_INIT_FROMFILE: case QD_INIT_PURE: case QD_INIT_PERFORMANCE: case QD_INIT_ENSEMBLE: return 1;
+    case QD_INIT_THREESTATES: return 3;
+    case QD_INIT_NPLUSONE: return s->N + 1;
+    case QD_INIT_DIAGONAL: case QD_INIT_BASIS: {
+      int ninit = 1;
+      for (int i = 0; i < ob->n_init_ids; i++)
+        if (ob->init_ids[i] < s->Q) ninit *= s->ness[ob->init_ids[i]];
+      if (ob->initcond_type == QD_INIT_BASIS && s->lindblad) ninit = ninit * ninit;
+      return ninit;
+    }
+  }
+  return -1;
+}
+
+/* OptimTarget ctor, src/optimtarget.cpp:22-316 */
+static int target_init(const qo_ctx* c, const qd_objective* ob, otarget* tg) {
+  const osys* s = &c->s;
+  const int dim = s->dim, N = s->N, de = s->dim_ess;
+  memset(tg, 0, sizeof *tg);
+  tg->initcond_type = ob->initcond_type;
+  if (!s->lindblad) {
+    if (ob->initcond_type == QD_INIT_ENSEMBLE || ob->initcond_type == QD_INIT_THREESTATES || ob->initcond_type == QD_INIT_NPLUSONE)
+      return fail("initial condition type requires the Lindblad solver");
+    if (ob->initcond_type == QD_INIT_BASIS) tg->initcond_type = QD_INIT_DIAGONAL; /* :61-64 */
+  }
+  tg->n_ids = ob->n_init_ids;
+  for (int i = 0; i < ob->n_init_ids; i++) tg->ids[i] = ob->init_ids[i];
+  tg->ninit = count_ninit(s, ob);
+  tg->target_type = ob->target_type;
+  tg->objective_type = ob->objective_type;
+  tg->purity = 1.0;
+  tg->purestate_id = -1;
+  tg->aux = (double*)calloc((size_t)2 * dim, sizeof(double));
+  tg->rho0_fixed = (double*)calloc((size_t)2 * dim, sizeof(double));
+  double* r0 = tg->rho0_fixed;
+  if (tg->initcond_type == QD_INIT_PURE) { /* :74-102 */
+    if (tg->n_ids != s->Q) return fail("pure initial condition needs one level per oscillator");
+    int diag = 0;
+    for (int k = 0; k < s->Q; k++) {
+      if (tg->ids[k] > s->n[k] - 1) return fail("pure initial state exceeds nlevels");
+      diag += tg->ids[k] * s->post[k];
+    }
+    r0[s->lindblad ? vec_id(diag, diag, N) : diag] = 1.0;
+  } else if (tg->initcond_type == QD_INIT_FROMFILE) { /* :103-143 */
+    if (!ob->init_data) return fail("initial condition from file needs data");
+    if (s->lindblad) {
+      for (int i = 0; i < de * de; i++) {
+        int k = i % de, j = i / de;
+        if (de * de < dim) {
+          k = map_ess_to_full(s, k);
+          j = map_ess_to_full(s, j);
+        }
+        int el = vec_id(k, j, N);
+        r0[el] = ob->init_data[i];
+        r0[el + dim] = ob->init_data[i + de * de];
+      }
+    } else {
+      for (int i = 0; i < de; i++) {
+        int k = de < dim ? map_ess_to_full(s, i) : i;
+        r0[k] = ob->init_data[i];
+        r0[k + dim] = ob->init_data[i + de];
+      }
+    }
+  } else if (tg->initcond_type == QD_INIT_ENSEMBLE) { /* :144-196 */
+    int dimpost = 1, dimsub = 1;
+    for (int i = 0; i < s->Q; i++) {
+      if (tg->ids[0] <= i && i <= tg->ids[tg->n_ids - 1]) dimsub *= s->ness[i];
+      else dimpost *= s->ness[i];
+    }
+    for (int i = 0; i < dimsub; i++)
+      for (int j = i; j < dimsub; j++) {
+        int ifull = i * dimpost, jfull = j * dimpost;
+        if (de < N) {
+          ifull = map_ess_to_full(s, ifull);
+          jfull = map_ess_to_full(s, jfull);
+        }
+        if (i == j) r0[vec_id(ifull, jfull, N)] = 1. / dimsub;
+        else {
+          int el = vec_id(ifull, jfull, N);
+          r0[el] = 0.5 / (dimsub * dimsub);
+          r0[el + dim] = 0.5 / (dimsub * dimsub);
+          el = vec_id(jfull, ifull, N);
+          r0[el] = 0.5 / (dimsub * dimsub);
+          r0[el + dim] = -0.5 / (dimsub * dimsub);
+        }
+      }
+  }
+  if (ob->target_type == QD_TARGET_GATE) {
+    if (!ob->gate_re) return fail("gate target needs the gate matrix");
+    build_gate(s, ob, c->Tfinal, tg);
+    tg->targetstate = (double*)calloc((size_t)2 * dim, sizeof(double));
+  } else if (ob->target_type == QD_TARGET_PURE) { /* :218-237 */
+    tg->purestate_id = 0;
+    for (int k = 0; k < s->Q; k++) {
+      if (ob->target_pure_levels[k] >= s->n[k]) return fail("pure target exceeds nlevels");
+      tg->purestate_id += ob->target_pure_levels[k] * s->post[k];
+    }
+  } else { /* FROMFILE :267-306 */
+    if (!ob->target_data) return fail("target from file needs data");
+    tg->targetstate = (double*)calloc((size_t)2 * dim, sizeof(double));
+    if (s->lindblad) {
+      for (int i = 0; i < de * de; i++) {
+        int k = i % de, j = i / de;
+        if (de * de < dim) {
+          k = map_ess_to_full(s, k);
+          j = map_ess_to_full(s, j);
+        }
+        int el = vec_id(k, j, N);
+        tg->targetstate[el] = ob->target_data[i];
+        tg->targetstate[el + dim] = ob->target_data[i + de * de];
+      }
+    } else {
+      for (int i = 0; i < de; i++) {
+        int k = de < dim ? map_ess_to_full(s, i) : i;
+        tg->targetstate[k] = ob->target_data[i];
+        tg->targetstate[k + dim] = ob->target_data[i + de];
+      }
+    }
+  }
+  return 0;
+}
+
+static void target_free(otarget* tg) {
+  free(tg->rho0_fixed);
+  free(tg->targetstate);
+  free(tg->Vre);
+  free(tg->Vim);
+  free(tg->aux);
+}
+
+/* OptimTarget::prepareInitialState, src/optimtarget.cpp:450-698; returns the initial-condition id */
+static int prepare_initial_state(const osys* s, const otarget* tg, int iinit, double* rho0) {
+  const int dim = s->dim, N = s->N, de = s->dim_ess, ninit = tg->ninit;
+  int init_id = 0;
+  switch (tg->initcond_type) {
+    case QD_INIT_PURE: case QD_INIT_FROMFILE: case QD_INIT_ENSEMBLE:
+      memcpy(rho0, tg->rho0_fixed, sizeof(double) * 2 * dim);
+      break;
+    case QD_INIT_PERFORMANCE: /* :460-481, incl. the index quirk of the Lindblad branch */
+      memset(rho0, 0, sizeof(double) * 2 * dim);
+      for (int i = 0; i < N; i++) {
+        if (!s->lindblad) {
+          double val = 1. / sqrt(2. * N);
+          rho0[i] = val;
+          rho0[i + dim] = val;
+        } else {
+          rho0[i] = 1. / N;
+        }
+      }
+      break;
+    case QD_INIT_THREESTATES: /* :495-540 */
+      memset(rho0, 0, sizeof(double) * 2 * dim);
+      if (iinit == 0) {
+        init_id = 1;
+        for (int i = 0; i < N; i++) rho0[vec_id(i, i, N)] = 2. * (N - i) / ((double)N * (N + 1));
+      } else if (iinit == 1) {
+        init_id = 2;
+        for (int i = 0; i < N; i++)
+          for (int j = 0; j < N; j++) rho0[vec_id(i, j, N)] = 1. / N;
+      } else {
+        init_id = 3;
+        for (int i = 0; i < N; i++) rho0[vec_id(i, i, N)] = 1. / N;
+      }
+      break;
+    case QD_INIT_NPLUSONE: /* :542-572 (note: the iinit==N branch does not zero rho0 first; the
+                              previous state is E_{N-1,N-1}, fully overwritten on the diagonal) */
+      if (iinit < N) {
+        memset(rho0, 0, sizeof(double) * 2 * dim);
+        rho0[vec_id(iinit, iinit, N)] = 1.0;
+      } else {
+        memset(rho0, 0, sizeof(double) * 2 * dim);
+        for (int i = 0; i < N; i++)
+          for (int j = 0; j < N; j++) rho0[vec_id(i, j, N)] = 1.0 / N;
+      }
+      init_id = iinit;
+      break;
+    case QD_INIT_DIAGONAL: { /* :574-603 */
+      memset(rho0, 0, sizeof(double) * 2 * dim);
+      int dim_post = 1;
+      for (int k = tg->ids[tg->n_ids - 1] + 1; k < s->Q; k++) dim_post *= s->ness[k];
+      int diagelem = iinit * dim_post;
+      if (de < N) diagelem = map_ess_to_full(s, diagelem);
+      rho0[s->lindblad ? vec_id(diagelem, diagelem, N) : diagelem] = 1.0;
+      init_id = s->lindblad ? iinit * ninit + iinit : iinit;
+      break;
+    }
+    case QD_INIT_BASIS: { /* :605-690 */
+      memset(rho0, 0, sizeof(double) * 2 * dim);
+      int dim_post = 1;
+      for (int k = tg->ids[tg->n_ids - 1] + 1; k < s->Q; k++) dim_post *= s->ness[k];
+      int sqn = (int)sqrt((double)ninit);
+      int k = iinit % sqn, j = iinit / sqn;
+      init_id = j * sqn + k;
+      k *= dim_post;
+      j *= dim_post;
+      if (de < N) {
+        k = map_ess_to_full(s, k);
+        j = map_ess_to_full(s, j);
+      }
+      if (k == j) rho0[vec_id(k, k, N)] = 1.0;
+      else if (k < j) {
+        rho0[vec_id(k, k, N)] = 0.5;
+        rho0[vec_id(j, j, N)] = 0.5;
+        rho0[vec_id(k, j, N)] = 0.5;
+        rho0[vec_id(j, k, N)] = 0.5;
+      } else {
+        rho0[vec_id(k, k, N)] = 0.5;
+        rho0[vec_id(j, j, N)] = 0.5;
+        rho0[vec_id(k, j, N) + dim] = -0.5;
+        rho0[vec_id(j, k, N) + dim] = 0.5;
+      }
+      break;
+    }
+  }
+  return init_id;
+}
+
+/* OptimTarget::prepareTargetState, src/optimtarget.cpp:701-708 */
+static void prepare_target_state(const osys* s, otarget* tg, const double* rho0) {
+  if (tg->target_type == QD_TARGET_GATE) apply_gate(s, tg, rho0, tg->targetstate);
+  double nn = vnorm(2 * s->dim, rho0);
+  tg->purity = nn * nn;
+}
+
+/* HilbertSchmidtOverlap, src/optimtarget.cpp:343-408 */
+static void hs_overlap(const osys* s, const otarget* tg, const double* x, int scale, double* re, double* im) {
+  const int dim = s->dim;
+  double hr = 0.0, hi = 0.0;
+  if (tg->target_type == QD_TARGET_PURE) {
+    int idm = s->lindblad ? vec_id(tg->purestate_id, tg->purestate_id, s->N) : tg->purestate_id;
+    hr = x[idm];
+    hi = x[idm + dim];
+  } else if (s->lindblad) {
+    hr = vdot(2 * dim, tg->targetstate, x);
+  } else {
+    const double* t = tg->targetstate;
+    for (int i = 0; i < dim; i++) {
+      hr += t[i] * x[i] + t[i + dim] * x[i + dim];
+      hi += -t[i + dim] * x[i] + t[i] * x[i + dim];
+    }
+  }
+  if (scale) hr = hr / tg->purity;
+  *re = hr;
+  *im = hi;
+}
+
+/* HilbertSchmidtOverlap_diff, src/optimtarget.cpp:410-447 */
+static void hs_overlap_diff(const osys* s, const otarget* tg, double* xbar, int scaleflag, double rbar, double ibar) {
+  const int dim = s->dim;
+  double scale = scaleflag ? 1. / tg->purity : 1.0;
+  if (tg->target_type == QD_TARGET_PURE) {
+    int idm = s->lindblad ? vec_id(tg->purestate_id, tg->purestate_id, s->N) : tg->purestate_id;
+    xbar[idm] += rbar * scale;
+    xbar[idm + dim] += ibar;
+  } else if (s->lindblad) {
+    vaxpy(2 * dim, rbar * scale, tg->targetstate, xbar);
+  } else {
+    const double* t = tg->targetstate;
+    for (int i = 0; i < dim; i++) {
+      xbar[i] += t[i] * rbar * scale - t[i + dim] * ibar;
+      xbar[i + dim] += t[i + dim] * rbar * scale + t[i] * ibar;
+    }
+  }
+}
+
+/* OptimTarget::evalJ, src/optimtarget.cpp:712-799 */
+static void eval_J(const osys* s, const otarget* tg, const double* x, double* Jre, double* Jim) {
+  const int dim = s->dim, N = s->N;
+  double jr = 0.0, ji = 0.0;
+  switch (tg->objective_type) {
+    case QD_OBJ_JFROBENIUS:
+      if (tg->target_type != QD_TARGET_PURE) {
+        double nn = 0.0;
+        for (int i = 0; i < 2 * dim; i++) {
+          double d = tg->targetstate[i] - x[i];
+          nn += d * d;
+        }
+        jr = nn / 2.0;
+      } else {
+        int did = s->lindblad ? vec_id(tg->purestate_id, tg->purestate_id, N) : tg->purestate_id;
+        double nn = 0.0;
+        for (int i = 0; i < 2 * dim; i++) {
+          double d = x[i] - (i == did ? 1.0 : 0.0);
+          nn += d * d;
+        }
+        jr = nn / 2.0;
+      }
+      break;
+    case QD_OBJ_JTRACE:
+      hs_overlap(s, tg, x, 1, &jr, &ji);
+      break;
+    case QD_OBJ_JMEASURE: {
+      double sum = 0.0;
+      for (int i = 0; i < N; i++) {
+        double rii;
+        if (s->lindblad) rii = x[vec_id(i, i, N)];
+        else rii = x[i] * x[i] + x[i + dim] * x[i + dim];
+        sum += fabs((double)(i - tg->purestate_id)) * rii;
+      }
+      jr = sum;
+      break;
+    }
+  }
+  *Jre = jr;
+  *Jim = ji;
+}
+
+/* OptimTarget::evalJ_diff, src/optimtarget.cpp:802-862 */
+static void eval_J_diff(const osys* s, const otarget* tg, const double* x, double* xbar, double rbar, double ibar) {
+  const int dim = s->dim, N = s->N;
+  switch (tg->objective_type) {
+    case QD_OBJ_JFROBENIUS:
+      if (tg->target_type != QD_TARGET_PURE) {
+        double jb = rbar / 2.0;
+        vaxpy(2 * dim, 2.0 * jb, x, xbar);
+        vaxpy(2 * dim, -2.0 * jb, tg->targetstate, xbar);
+      } else {
+        vaxpy(2 * dim, rbar, x, xbar);
+        int did = s->lindblad ? vec_id(tg->purestate_id, tg->purestate_id, N) : tg->purestate_id;
+        xbar[did] += -1.0 * rbar;
+      }
+      break;
+    case QD_OBJ_JTRACE:
+      hs_overlap_diff(s, tg, xbar, 1, rbar, ibar);
+      break;
+    case QD_OBJ_JMEASURE:
+      for (int i = 0; i < N; i++) {
+        double lam = fabs((double)(i - tg->purestate_id));
+        if (s->lindblad) xbar[vec_id(i, i, N)] += lam * rbar;
+        else {
+          xbar[i] += 2. * rbar * lam * x[i];
+          xbar[i + dim] += 2. * rbar * lam * x[i + dim];
+        }
+      }
+      break;
+  }
+}
+
+/* finalizeJ / finalizeJ_diff, src/optimtarget.cpp:864-897 */
+static double finalize_J(const osys* s, const otarget* tg, double re, double im) {
+  if (tg->objective_type == QD_OBJ_JTRACE) {
+    if (!s->lindblad) return 1.0 - (re * re + im * im);
+    return 1.0 - re;
+  }
+  return re;
+}
+static void finalize_J_diff(const osys* s, const otarget* tg, double re, double im, double* rbar, double* ibar) {
+  if (tg->objective_type == QD_OBJ_JTRACE) {
+    if (!s->lindblad) {
+      *rbar = -2. * re;
+      *ibar = -2. * im;
+    } else {
+      *rbar = -1.0;
+      *ibar = 0.0;
+    }
+  } else {
+    *rbar = 1.0;
+    *ibar = 0.0;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* time loops: src/timestepper.cpp:96-480                                     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  const qd_penalty* pen;
+  otarget* tg;
+  int add_leakage;
+  double penalty_integral, penalty_dpdm, energy_penalty;
+  double* store;     /* (ntime+1) x 2dim when storeFWD */
+  double* dpdm[5];
+  /* optional trajectory sampling for output files */
+  int out_freq;
+  double* out_states; /* [nout][2dim] or NULL */
+} osweep;
+
+/* penaltyIntegral, src/timestepper.cpp:256-298 */
+static double penalty_integral(qo_ctx* c, osweep* w, double time, const double* x) {
+  const osys* s = &c->s;
+  double penalty = 0.0;
+  if (w->pen->penalty_param > 1e-13) {
+    double a = (time - c->Tfinal) / w->pen->penalty_param;
+    double weight = 1. / w->pen->penalty_param * exp(-(a * a));
+    double re, im;
+    eval_J(s, w->tg, x, &re, &im);
+    penalty = weight * finalize_J(s, w->tg, re, im) * c->dt;
+  }
+  if (w->add_leakage) {
+    double leakage = 0.0;
+    for (int i = 0; i < s->N; i++)
+      if (is_guard_level(s, i)) {
+        int id = s->lindblad ? vec_id(i, i, s->N) : i;
+        double xr = x[id], xi = x[id + s->dim];
+        leakage += (xr * xr + xi * xi) / (c->dt * c->ntime);
+      }
+    penalty += c->dt * leakage;
+  }
+  return penalty;
+}
+
+/* penaltyIntegral_diff, src/timestepper.cpp:300-339 */
+static void penalty_integral_diff(qo_ctx* c, osweep* w, double time, const double* x, double* xbar, double penaltybar) {
+  const osys* s = &c->s;
+  if (w->pen->penalty_param > 1e-13) {
+    double a = (time - c->Tfinal) / w->pen->penalty_param;
+    double weight = 1. / w->pen->penalty_param * exp(-(a * a));
+    double re, im, rb, ib;
+    eval_J(s, w->tg, x, &re, &im);
+    finalize_J_diff(s, w->tg, re, im, &rb, &ib);
+    eval_J_diff(s, w->tg, x, xbar, weight * rb * penaltybar * c->dt, weight * ib * penaltybar * c->dt);
+  }
+  if (w->add_leakage) {
+    for (int i = 0; i < s->N; i++)
+      if (is_guard_level(s, i)) {
+        int id = s->lindblad ? vec_id(i, i, s->N) : i;
+        xbar[id] += 2. * x[id] * penaltybar / c->ntime;
+        xbar[id + s->dim] += 2. * x[id + s->dim] * penaltybar / c->ntime;
+      }
+  }
+}
+
+/* penaltyDpDm, src/timestepper.cpp:342-369 */
+static double penalty_dpdm(qo_ctx* c, const double* x, const double* xm1, const double* xm2) {
+  const int dim = c->s.dim;
+  double dtinv = 1.0 / (c->dt * c->dt * c->dt * c->dt);
+  double v = 0.0;
+  for (int i = 0; i < dim; i++) {
+    double t1 = x[i] * x[i] - 2.0 * xm1[i] * xm1[i] + xm2[i] * xm2[i];
+    double t2 = x[i + dim] * x[i + dim] - 2.0 * xm1[i + dim] * xm1[i + dim] + xm2[i + dim] * xm2[i + dim];
+    v += dtinv * (t1 + t2) * (t1 + t2);
+  }
+  return v;
+}
+
+/* penaltyDpDm_diff, src/timestepper.cpp:372-442 */
+static void penalty_dpdm_diff(qo_ctx* c, osweep* w, int n, double* xbar, double Jbar) {
+  const int dim = c->s.dim, ntime = c->ntime;
+  int k = ntime - n;
+  int idx = 4 - (k + 4) % 5;
+  const double *xm2 = NULL, *xm1 = NULL, *x, *xp1 = NULL, *xp2 = NULL;
+  if (n > 1) xm2 = w->dpdm[idx];
+  if (n > 0) xm1 = w->dpdm[(idx + 1) % 5];
+  x = w->dpdm[(idx + 2) % 5];
+  if (n < ntime) xp1 = w->dpdm[(idx + 3) % 5];
+  if (n < ntime - 1) xp2 = w->dpdm[(idx + 4) % 5];
+  double dtinv = 1.0 / (c->dt * c->dt * c->dt * c->dt);
+  for (int i = 0; i < dim; i++) {
+    int ir = i, ii = i + dim;
+    if (n > 1) {
+      double t1 = xm2[ir] * xm2[ir] - 2.0 * xm1[ir] * xm1[ir] + x[ir] * x[ir];
+      double t2 = xm2[ii] * xm2[ii] - 2.0 * xm1[ii] * xm1[ii] + x[ii] * x[ii];
+      double pop = t1 + t2;
+      xbar[ir] += 2.0 * pop * 2.0 * x[ir] * dtinv * Jbar;
+      xbar[ii] += 2.0 * pop * 2.0 * x[ii] * dtinv * Jbar;
+    }
+    if (n > 0 && n < ntime) {
+      double t1 = xm1[ir] * xm1[ir] - 2.0 * x[ir] * x[ir] + xp1[ir] * xp1[ir];
+      double t2 = xm1[ii] * xm1[ii] - 2.0 * x[ii] * x[ii] + xp1[ii] * xp1[ii];
+      double pop = t1 + t2;
+      xbar[ir] += -4.0 * pop * 2.0 * x[ir] * dtinv * Jbar;
+      xbar[ii] += -4.0 * pop * 2.0 * x[ii] * dtinv * Jbar;
+    }
+    if (n < ntime - 1) {
+      double t1 = x[ir] * x[ir] - 2.0 * xp1[ir] * xp1[ir] + xp2[ir] * xp2[ir];
+      double t2 = x[ii] * x[ii] - 2.0 * xp1[ii] * xp1[ii] + xp2[ii] * xp2[ii];
+      double pop = t1 + t2;
+      xbar[ir] += 2.0 * pop * 2.0 * x[ir] * dtinv * Jbar;
+      xbar[ii] += 2.0 * pop * 2.0 * x[ii] * dtinv * Jbar;
+    }
+  }
+}
+
+/* energyPenaltyIntegral(_diff), src/timestepper.cpp:444-480 */
+static double energy_penalty(qo_ctx* c, double time) {
+  double pen = 0.0;
+  for (int k = 0; k < c->s.Q; k++) {
+    double p, q;
+    eval_control(c, k, time, &p, &q);
+    pen += (p * p + q * q) / c->ntime;
+  }
+  return pen;
+}
+static void energy_penalty_diff(qo_ctx* c, double time, double penaltybar, double* redgrad) {
+  for (int k = 0; k < c->s.Q; k++) {
+    double p, q;
+    eval_control(c, k, time, &p, &q);
+    double pbar = penaltybar / c->ntime * 2.0 * p;
+    double qbar = penaltybar / c->ntime * 2.0 * q;
+    eval_control_diff(c, k, time, redgrad + c->osc[k].offset, pbar, qbar);
+  }
+}
+
+/* TimeStepper::solveODE, src/timestepper.cpp:96-181.  x holds rho_t0 on entry, the final state on exit. */
+static int solve_ode(qo_ctx* c, osweep* w, double* x) {
+  const int n2 = 2 * c->s.dim;
+  const qd_penalty* pen = w->pen;
+  const int dpdm_on = pen->gamma_penalty_dpdm > 1e-13;
+  double* dp[2] = {NULL, NULL};
+  if (dpdm_on) {
+    dp[0] = (double*)malloc(sizeof(double) * n2);
+    dp[1] = (double*)malloc(sizeof(double) * n2);
+    memcpy(dp[0], x, sizeof(double) * n2);
+  }
+  w->penalty_integral = 0.0;
+  w->penalty_dpdm = 0.0;
+  w->energy_penalty = 0.0;
+  int nout = 0;
+  for (int n = 0; n < c->ntime; n++) {
+    double tstart = n * c->dt, tstop = (n + 1) * c->dt;
+    if (w->store) memcpy(w->store + (size_t)n * n2, x, sizeof(double) * n2);
+    if (w->out_states && n % w->out_freq == 0) memcpy(w->out_states + (size_t)(nout++) * n2, x, sizeof(double) * n2);
+    if (evolve_fwd(c, tstart, tstop, x)) return -1;
+    if (pen->gamma_penalty > 1e-13) w->penalty_integral += penalty_integral(c, w, tstop, x);
+    if (dpdm_on) {
+      if (n > 0) w->penalty_dpdm += penalty_dpdm(c, x, dp[n % 2], dp[(n + 1) % 2]);
+      memcpy(dp[(n + 1) % 2], x, sizeof(double) * n2);
+    }
+    if (pen->gamma_penalty_energy > 1e-13) w->energy_penalty += energy_penalty(c, tstop);
+  }
+  w->penalty_dpdm = w->penalty_dpdm / c->ntime;
+  if (w->store) memcpy(w->store + (size_t)c->ntime * n2, x, sizeof(double) * n2);
+  if (w->out_states && c->ntime % w->out_freq == 0) memcpy(w->out_states + (size_t)(nout++) * n2, x, sizeof(double) * n2);
+  free(dp[0]);
+  free(dp[1]);
+  return 0;
+}
+
+/* TimeStepper::solveAdjointODE, src/timestepper.cpp:184-253.  redgrad is zeroed first. */
+static int solve_adjoint_ode(qo_ctx* c, osweep* w, const double* rho_t0_bar, const double* finalstate, double Jbar_penalty,
+                             double Jbar_dpdm, double Jbar_energy, double* redgrad) {
+  const int n2 = 2 * c->s.dim, ntime = c->ntime;
+  const double dt = c->dt;
+  const qd_penalty* pen = w->pen;
+  const int dpdm_on = pen->gamma_penalty_dpdm > 1e-13;
+  double* xadj = (double*)malloc(sizeof(double) * n2);
+  double* xprimal = (double*)malloc(sizeof(double) * n2);
+  double* xstage = (double*)malloc(sizeof(double) * n2 * 15);
+  memset(redgrad, 0, sizeof(double) * c->ndesign);
+  memcpy(xadj, rho_t0_bar, sizeof(double) * n2);
+  memcpy(xprimal, finalstate, sizeof(double) * n2);
+  int rc = 0;
+  if (dpdm_on) {
+    for (int i = 0; i < 5; i++) w->dpdm[i] = (double*)calloc(n2, sizeof(double));
+    memcpy(w->dpdm[2], xprimal, sizeof(double) * n2);
+    memcpy(w->dpdm[1], w->dpdm[2], sizeof(double) * n2);
+    rc |= evolve_fwd(c, ntime * dt, (ntime - 1) * dt, w->dpdm[1]);
+    memcpy(w->dpdm[0], w->dpdm[1], sizeof(double) * n2);
+    rc |= evolve_fwd(c, (ntime - 1) * dt, (ntime - 2) * dt, w->dpdm[0]);
+  }
+  for (int n = ntime; n > 0 && !rc; n--) {
+    double tstop = n * dt, tstart = (n - 1) * dt;
+    if (pen->gamma_penalty_energy > 1e-13) energy_penalty_diff(c, tstop, Jbar_energy, redgrad);
+    if (dpdm_on) penalty_dpdm_diff(c, w, n, xadj, Jbar_dpdm / ntime);
+    if (pen->gamma_penalty > 1e-13) penalty_integral_diff(c, w, tstop, xprimal, xadj, Jbar_penalty);
+    if (w->store) memcpy(xprimal, w->store + (size_t)(n - 1) * n2, sizeof(double) * n2);
+    else rc |= evolve_fwd(c, tstop, tstart, xprimal);
+    rc |= evolve_bwd(c, tstop, tstart, xprimal, xadj, redgrad, xstage);
+    if (dpdm_on) {
+      int k = ntime - n;
+      int idx = 4 - ((k + 4) % 5);
+      int idx1 = 4 - (k % 5);
+      memcpy(w->dpdm[idx1], w->dpdm[idx], sizeof(double) * n2);
+      if (n > 2) rc |= evolve_fwd(c, (n - 2) * dt, (n - 3) * dt, w->dpdm[idx1]);
+    }
+  }
+  if (dpdm_on)
+    for (int i = 0; i < 5; i++) {
+      free(w->dpdm[i]);
+      w->dpdm[i] = NULL;
+    }
+  free(xadj);
+  free(xprimal);
+  free(xstage);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* public oracle API                                                          */
+/* ------------------------------------------------------------------------- */
+void qo_destroy(qo_ctx* c) {
+  if (!c) return;
+  for (int k = 0; k < QO_MAXQ; k++) {
+    oosc* o = &c->osc[k];
+    if (o->seg) {
+      for (int b = 0; b < o->nseg; b++) free(o->seg[b].tcenter);
+      free(o->seg);
+    }
+    free(o->car);
+    free(o->pt0);
+    free(o->pt1);
+    free(o->pamp);
+  }
+  free(c->s.sq);
+  free(c->params);
+  free(c->rhs); free(c->stage); free(c->stage_adj); free(c->tmp); free(c->err); free(c->aux);
+  free(c->gm_V); free(c->gm_H); free(c->gm_cs); free(c->gm_sn); free(c->gm_g); free(c->gm_y);
+  free(c);
+}
+
+int qo_create(const qd_system* sys, const qd_controls* ctl, const qd_time* tg, const qd_solver* sol, qo_ctx** out) {
+  qo_ctx* c = (qo_ctx*)calloc(1, sizeof *c);
+  if (!c) return fail("out of memory");
+  if (osys_init(&c->s, sys)) { free(c); return -1; }
+  c->ntime = tg->ntime;
+  c->dt = tg->dt;
+  c->Tfinal = tg->ntime * tg->dt;
+  c->sol = *sol;
+  c->enforce_bc = ctl->enforce_bc;
+  /* segments: Oscillator ctor parsing, src/oscillator.cpp:45-132; BSpline ctors controlbasis.cpp:20-32, :219-225 */
+  int carpos = 0, off = 0;
+  for (int k = 0; k < c->s.Q; k++) {
+    oosc* o = &c->osc[k];
+    o->ncar = ctl->ncarrier[k];
+    o->car = (double*)malloc(sizeof(double) * (o->ncar > 0 ? o->ncar : 1));
+    for (int f = 0; f < o->ncar; f++) o->car[f] = 2.0 * M_PI * ctl->carrier_freq[carpos + f];
+    carpos += o->ncar;
+    int ns = 0;
+    for (int g = 0; g < ctl->nseg_total; g++)
+      if (ctl->seg_osc[g] == k) ns++;
+    o->nseg = ns;
+    o->seg = (oseg*)calloc(ns > 0 ? ns : 1, sizeof(oseg));
+    int b = 0, skip = 0;
+    for (int g = 0; g < ctl->nseg_total; g++) {
+      if (ctl->seg_osc[g] != k) continue;
+      oseg* sg = &o->seg[b++];
+      sg->type = ctl->seg_type[g];
+      sg->nsplines = ctl->seg_nsplines[g];
+      sg->tstart = ctl->seg_tstart[g];
+      sg->tstop = ctl->seg_tstop[g];
+      sg->skip = skip;
+      if (sg->type == QD_CTRL_BSPLINE) {
+        sg->dtknot = (sg->tstop - sg->tstart) / (double)(sg->nsplines - 2);
+        sg->width = 3.0 * sg->dtknot;
+        sg->tcenter = (double*)malloc(sizeof(double) * sg->nsplines);
+        for (int i = 0; i < sg->nsplines; i++) sg->tcenter[i] = sg->tstart + sg->dtknot * ((i + 1) - 1.5);
+      } else if (sg->type == QD_CTRL_BSPLINE0) {
+        sg->dtknot = (sg->tstop - sg->tstart) / (sg->nsplines - 1.0);
+        sg->width = sg->dtknot;
+      } else {
+        qo_destroy(c);
+        return fail("unsupported control segment type");
+      }
+      skip += 2 * sg->nsplines * o->ncar;
+    }
+    o->nparams = skip;
+    o->offset = off;
+    off += skip;
+    int np = 0;
+    for (int i = 0; i < ctl->npipulse; i++)
+      if (ctl->pipulse_osc[i] == k) np++;
+    o->npulse = np;
+    o->pt0 = (double*)malloc(sizeof(double) * (np > 0 ? np : 1));
+    o->pt1 = (double*)malloc(sizeof(double) * (np > 0 ? np : 1));
+    o->pamp = (double*)malloc(sizeof(double) * (np > 0 ? np : 1));
+    np = 0;
+    for (int i = 0; i < ctl->npipulse; i++)
+      if (ctl->pipulse_osc[i] == k) {
+        o->pt0[np] = ctl->pipulse_tstart[i];
+        o->pt1[np] = ctl->pipulse_tstop[i];
+        o->pamp[np] = ctl->pipulse_amp[i];
+        np++;
+      }
+  }
+  c->ndesign = off;
+  c->params = (double*)calloc(off > 0 ? off : 1, sizeof(double));
+  size_t n2 = (size_t)2 * c->s.dim;
+  c->rhs = (double*)calloc(n2, sizeof(double));
+  c->stage = (double*)calloc(n2, sizeof(double));
+  c->stage_adj = (double*)calloc(n2, sizeof(double));
+  c->tmp = (double*)calloc(n2, sizeof(double));
+  c->err = (double*)calloc(n2, sizeof(double));
+  c->aux = (double*)calloc(n2, sizeof(double));
+  int m = sol->maxiter > 0 ? sol->maxiter : 1;
+  c->gm_V = (double*)calloc(n2 * (size_t)(m + 1), sizeof(double));
+  c->gm_H = (double*)calloc((size_t)(m + 1) * m, sizeof(double));
+  c->gm_cs = (double*)calloc(m + 1, sizeof(double));
+  c->gm_sn = (double*)calloc(m + 1, sizeof(double));
+  c->gm_g = (double*)calloc(m + 2, sizeof(double));
+  c->gm_y = (double*)calloc(m + 1, sizeof(double));
+  *out = c;
+  return 0;
+}
+
+int qo_dim(const qo_ctx* c) { return c->s.dim; }
+int qo_dim_rho(const qo_ctx* c) { return c->s.N; }
+int qo_dim_ess(const qo_ctx* c) { return c->s.dim_ess; }
+int qo_ndesign(const qo_ctx* c) { return c->ndesign; }
+
+/* MasterEq::setControlAmplitudes, src/mastereq.cpp:693-707 */
+int qo_set_params(qo_ctx* c, const double* alpha, int ndesign) {
+  if (ndesign != c->ndesign) return fail("ndesign mismatch");
+  memcpy(c->params, alpha, sizeof(double) * ndesign);
+  return 0;
+}
+
+int qo_eval_controls(qo_ctx* c, const double* times, int nt, double* pq) {
+  for (int i = 0; i < nt; i++)
+    for (int k = 0; k < c->s.Q; k++)
+      if (eval_control(c, k, times[i], &pq[(i * c->s.Q + k) * 2], &pq[(i * c->s.Q + k) * 2 + 1])) return -1;
+  return 0;
+}
+
+int qo_apply_rhs(qo_ctx* c, double t, int transpose, const double* x, double* y, int nb) {
+  if (assemble_rhs(c, t)) return -1;
+  for (int b = 0; b < nb; b++) apply_rhs(c, transpose, x + (size_t)b * 2 * c->s.dim, y + (size_t)b * 2 * c->s.dim);
+  return 0;
+}
+
+/* x^T (dM/dp_k) z and x^T (dM/dq_k) z for one pair of states: coeff is [nosc][2] */
+int qo_drhs_coeffs(qo_ctx* c, const double* z, const double* xbar, double* coeff) {
+  /* reuse drhs_dparams through a unit "gradient": evaluate the coefficients directly */
+  const osys* s = &c->s;
+  const int Q = s->Q, N = s->N, dim = s->dim;
+  const double* sq = s->sq;
+  int i[QO_MAXQ], ip[QO_MAXQ], np[QO_MAXQ];
+  for (int k = 0; k < Q; k++) {
+    coeff[2 * k] = coeff[2 * k + 1] = 0.0;
+    i[k] = ip[k] = 0;
+    np[k] = s->lindblad ? s->n[k] : 1;
+  }
+  for (int it = 0; it < dim; it++) {
+    const double br = xbar[it], bi = xbar[it + dim];
+    for (int k = 0; k < Q; k++) {
+      double ppr = 0, ppi = 0, qqr = 0, qqi = 0;
+      const int st = s->post[k], stq = N * s->post[k];
+      if (i[k] < s->n[k] - 1) { int itx = it + st; double ur = z[itx], ui = z[itx + dim], sv = sq[i[k] + 1]; ppr += sv * ui; ppi += -sv * ur; qqr += sv * ur; qqi += sv * ui; }
+      if (ip[k] < np[k] - 1) { int itx = it + stq; double ur = z[itx], ui = z[itx + dim], sv = sq[ip[k] + 1]; ppr += -sv * ui; ppi += sv * ur; qqr += sv * ur; qqi += sv * ui; }
+      if (i[k] > 0) { int itx = it - st; double ur = z[itx], ui = z[itx + dim], sv = sq[i[k]]; ppr += sv * ui; ppi += -sv * ur; qqr += -sv * ur; qqi += -sv * ui; }
+      if (ip[k] > 0) { int itx = it - stq; double ur = z[itx], ui = z[itx + dim], sv = sq[ip[k]]; ppr += -sv * ui; ppi += sv * ur; qqr += -sv * ur; qqi += -sv * ui; }
+      coeff[2 * k] += ppr * br + ppi * bi;
+      coeff[2 * k + 1] += qqr * br + qqi * bi;
+    }
+    int k = Q - 1;
+    while (k >= 0) { if (++i[k] < s->n[k]) break; i[k] = 0; k--; }
+    if (k < 0) { k = Q - 1; while (k >= 0) { if (++ip[k] < np[k]) break; ip[k] = 0; k--; } }
+  }
+  return 0;
+}
+
+/* one evolveFWD / evolveBWD step on explicit states (for stepper-level parity tests) */
+int qo_step_fwd(qo_ctx* c, double tstart, double tstop, double* x) { return evolve_fwd(c, tstart, tstop, x); }
+int qo_step_bwd(qo_ctx* c, double tstop, double tstart, const double* x, double* xadj, double* grad) {
+  double* xstage = (double*)malloc(sizeof(double) * 2 * c->s.dim * 15);
+  int rc = evolve_bwd(c, tstop, tstart, x, xadj, grad, xstage);
+  free(xstage);
+  return rc;
+}
+
+double qo_mean_applies(const qo_ctx* c) { return c->n_steps ? (double)c->n_apply / (double)c->n_steps : 0.0; }
+void qo_reset_stats(qo_ctx* c) { c->n_apply = 0; c->n_steps = 0; }
+
+/* ---- objective level -------------------------------------------------- */
+typedef struct qo_optim {
+  qo_ctx* c;
+  qd_objective ob; /* shallow copy; pointers must stay valid */
+  otarget tg;
+  double* weights; /* normalised, [ninit] */
+  double* alpha0;
+  int ninit;
+} qo_optim;
+
+void qo_optim_destroy(qo_optim* o) {
+  if (!o) return;
+  target_free(&o->tg);
+  free(o->weights);
+  free(o->alpha0);
+  free(o);
+}
+
+int qo_optim_create(qo_ctx* c, const qd_objective* ob, qo_optim** out) {
+  qo_optim* o = (qo_optim*)calloc(1, sizeof *o);
+  o->c = c;
+  o->ob = *ob;
+  if (target_init(c, ob, &o->tg)) { qo_optim_destroy(o); return -1; }
+  o->ninit = o->tg.ninit;
+  /* weights: src/optimproblem.cpp:72-91 */
+  o->weights = (double*)calloc(o->ninit, sizeof(double));
+  double sum = 0.0;
+  for (int i = 0; i < o->ninit; i++) {
+    double w = (ob->nweights > 0) ? ob->weights[i < ob->nweights ? i : ob->nweights - 1] : 1.0;
+    o->weights[i] = w;
+    sum += w;
+  }
+  for (int i = 0; i < o->ninit; i++) o->weights[i] /= sum;
+  /* dpdm disabled for Lindblad: src/optimproblem.cpp:119-124 */
+  if (o->ob.penalty.gamma_penalty_dpdm > 1e-13 && c->s.lindblad) o->ob.penalty.gamma_penalty_dpdm = 0.0;
+  if (ob->tik0 && ob->alpha0) {
+    o->alpha0 = (double*)malloc(sizeof(double) * c->ndesign);
+    memcpy(o->alpha0, ob->alpha0, sizeof(double) * c->ndesign);
+  }
+  *out = o;
+  return 0;
+}
+
+int qo_optim_ninit(const qo_optim* o) { return o->ninit; }
+
+int qo_optim_initial_state(qo_optim* o, int iinit, double* x0, int* initid) {
+  int id = prepare_initial_state(&o->c->s, &o->tg, iinit, x0);
+  if (initid) *initid = id;
+  return 0;
+}
+int qo_optim_target_state(qo_optim* o, int iinit, double* xt) {
+  double* x0 = (double*)malloc(sizeof(double) * 2 * o->c->s.dim);
+  prepare_initial_state(&o->c->s, &o->tg, iinit, x0);
+  prepare_target_state(&o->c->s, &o->tg, x0);
+  if (o->tg.targetstate) memcpy(xt, o->tg.targetstate, sizeof(double) * 2 * o->c->s.dim);
+  else {
+    memset(xt, 0, sizeof(double) * 2 * o->c->s.dim);
+    int id = o->c->s.lindblad ? vec_id(o->tg.purestate_id, o->tg.purestate_id, o->c->s.N) : o->tg.purestate_id;
+    xt[id] = 1.0;
+  }
+  free(x0);
+  return 0;
+}
+
+static void sweep_init(qo_optim* o, osweep* w) {
+  memset(w, 0, sizeof *w);
+  w->pen = &o->ob.penalty;
+  w->tg = &o->tg;
+  w->add_leakage = 0;
+  for (int k = 0; k < o->c->s.Q; k++)
+    if (o->c->s.ness[k] < o->c->s.n[k]) w->add_leakage = 1; /* timestepper.cpp:28-32 */
+}
+
+static void finish_objective(qo_optim* o, const double* alpha, const double* sums, qd_objective_value* val) {
+  qo_ctx* c = o->c;
+  /* src/optimproblem.cpp:300-329 */
+  val->fidelity = c->s.lindblad ? sums[QD_SUM_FID_RE] : sums[QD_SUM_FID_RE] * sums[QD_SUM_FID_RE] + sums[QD_SUM_FID_IM] * sums[QD_SUM_FID_IM];
+  val->cost = finalize_J(&c->s, &o->tg, sums[QD_SUM_COST_RE], sums[QD_SUM_COST_IM]);
+  double xnorm2 = 0.0;
+  for (int i = 0; i < c->ndesign; i++) {
+    double d = alpha[i] - (o->alpha0 ? o->alpha0[i] : 0.0);
+    xnorm2 += d * d;
+  }
+  double xnorm = sqrt(xnorm2);
+  val->regul = o->ob.gamma_tik / 2. * xnorm * xnorm;
+  val->penalty = sums[QD_SUM_PENALTY];
+  val->penalty_dpdm = sums[QD_SUM_DPDM];
+  val->penalty_energy = sums[QD_SUM_ENERGY];
+  val->penalty_variation = 0.5 * o->ob.gamma_penalty_variation * control_variation(c);
+  val->objective = val->cost + val->regul + val->penalty + val->penalty_dpdm + val->penalty_energy + val->penalty_variation;
+}
+
+/* OptimProblem::evalF, src/optimproblem.cpp:224-338.
+ * traj (optional): [ninit][nout][2*dim] states every out_freq steps (the fullstate output),
+ * final_states (optional): [ninit][2*dim]. */
+int qo_optim_evalF(qo_optim* o, const double* alpha, qd_objective_value* val, int out_freq, double* traj, double* final_states) {
+  qo_ctx* c = o->c;
+  const int n2 = 2 * c->s.dim;
+  if (qo_set_params(c, alpha, c->ndesign)) return -1;
+  osweep w;
+  sweep_init(o, &w);
+  double sums[QD_NSUMS] = {0};
+  double* x = (double*)malloc(sizeof(double) * n2);
+  int nout = (out_freq > 0) ? c->ntime / out_freq + 1 : 0;
+  int rc = 0;
+  for (int ii = 0; ii < o->ninit && !rc; ii++) {
+    prepare_initial_state(&c->s, &o->tg, ii, x);
+    prepare_target_state(&c->s, &o->tg, x);
+    w.out_freq = out_freq;
+    w.out_states = traj ? traj + (size_t)ii * nout * n2 : NULL;
+    rc = solve_ode(c, &w, x);
+    if (final_states) memcpy(final_states + (size_t)ii * n2, x, sizeof(double) * n2);
+    sums[QD_SUM_PENALTY] += o->weights[ii] * o->ob.penalty.gamma_penalty * w.penalty_integral;
+    sums[QD_SUM_DPDM] += o->weights[ii] * o->ob.penalty.gamma_penalty_dpdm * w.penalty_dpdm;
+    sums[QD_SUM_ENERGY] += o->weights[ii] * o->ob.penalty.gamma_penalty_energy * w.energy_penalty;
+    double jr, ji, fr, fi;
+    eval_J(&c->s, &o->tg, x, &jr, &ji);
+    sums[QD_SUM_COST_RE] += o->weights[ii] * jr;
+    sums[QD_SUM_COST_IM] += o->weights[ii] * ji;
+    hs_overlap(&c->s, &o->tg, x, 0, &fr, &fi);
+    sums[QD_SUM_FID_RE] += 1. / o->ninit * fr;
+    sums[QD_SUM_FID_IM] += 1. / o->ninit * fi;
+  }
+  free(x);
+  if (rc) return rc;
+  finish_objective(o, alpha, sums, val);
+  return 0;
+}
+
+/* OptimProblem::evalGradF, src/optimproblem.cpp:342-538 */
+int qo_optim_evalGradF(qo_optim* o, const double* alpha, qd_objective_value* val, double* G) {
+  qo_ctx* c = o->c;
+  const int n2 = 2 * c->s.dim, nd = c->ndesign;
+  if (qo_set_params(c, alpha, nd)) return -1;
+  osweep w;
+  sweep_init(o, &w);
+  const qd_penalty* pen = &o->ob.penalty;
+  for (int i = 0; i < nd; i++) G[i] = o->ob.gamma_tik * (alpha[i] - (o->alpha0 ? o->alpha0[i] : 0.0));
+  control_variation_diff(c, G, 0.5 * o->ob.gamma_penalty_variation);
+  double sums[QD_NSUMS] = {0};
+  double* x = (double*)malloc(sizeof(double) * n2);
+  double* xbar = (double*)malloc(sizeof(double) * n2);
+  double* redgrad = (double*)malloc(sizeof(double) * (nd > 0 ? nd : 1));
+  double* finals = NULL;
+  if (c->s.lindblad) w.store = (double*)malloc(sizeof(double) * n2 * (size_t)(c->ntime + 1)); /* storeFWD, main.cpp:353-355 */
+  else finals = (double*)malloc(sizeof(double) * n2 * (size_t)o->ninit);
+  int rc = 0;
+  for (int ii = 0; ii < o->ninit && !rc; ii++) {
+    prepare_initial_state(&c->s, &o->tg, ii, x);
+    prepare_target_state(&c->s, &o->tg, x);
+    rc = solve_ode(c, &w, x);
+    if (finals) memcpy(finals + (size_t)ii * n2, x, sizeof(double) * n2);
+    sums[QD_SUM_PENALTY] += o->weights[ii] * pen->gamma_penalty * w.penalty_integral;
+    sums[QD_SUM_DPDM] += o->weights[ii] * pen->gamma_penalty_dpdm * w.penalty_dpdm;
+    sums[QD_SUM_ENERGY] += o->weights[ii] * pen->gamma_penalty_energy * w.energy_penalty;
+    double jr, ji, fr, fi;
+    eval_J(&c->s, &o->tg, x, &jr, &ji);
+    sums[QD_SUM_COST_RE] += o->weights[ii] * jr;
+    sums[QD_SUM_COST_IM] += o->weights[ii] * ji;
+    hs_overlap(&c->s, &o->tg, x, 0, &fr, &fi);
+    sums[QD_SUM_FID_RE] += 1. / o->ninit * fr;
+    sums[QD_SUM_FID_IM] += 1. / o->ninit * fi;
+    if (c->s.lindblad && !rc) { /* :427-443 */
+      memset(xbar, 0, sizeof(double) * n2);
+      double rb, ib;
+      finalize_J_diff(&c->s, &o->tg, sums[QD_SUM_COST_RE], sums[QD_SUM_COST_IM], &rb, &ib);
+      eval_J_diff(&c->s, &o->tg, x, xbar, o->weights[ii] * rb, o->weights[ii] * ib);
+      rc = solve_adjoint_ode(c, &w, xbar, x, o->weights[ii] * pen->gamma_penalty, o->weights[ii] * pen->gamma_penalty_dpdm,
+                             o->weights[ii] * pen->gamma_penalty_energy, redgrad);
+      for (int i = 0; i < nd; i++) G[i] += redgrad[i];
+    }
+  }
+  if (!rc) finish_objective(o, alpha, sums, val);
+  if (!c->s.lindblad && !rc) { /* :495-519 */
+    for (int ii = 0; ii < o->ninit && !rc; ii++) {
+      prepare_initial_state(&c->s, &o->tg, ii, x);
+      prepare_target_state(&c->s, &o->tg, x);
+      memset(xbar, 0, sizeof(double) * n2);
+      double rb, ib;
+      finalize_J_diff(&c->s, &o->tg, sums[QD_SUM_COST_RE], sums[QD_SUM_COST_IM], &rb, &ib);
+      double* fs = finals + (size_t)ii * n2;
+      eval_J_diff(&c->s, &o->tg, fs, xbar, o->weights[ii] * rb, o->weights[ii] * ib);
+      rc = solve_adjoint_ode(c, &w, xbar, fs, o->weights[ii] * pen->gamma_penalty, o->weights[ii] * pen->gamma_penalty_dpdm,
+                             o->weights[ii] * pen->gamma_penalty_energy, redgrad);
+      for (int i = 0; i < nd; i++) G[i] += redgrad[i];
+    }
+  }
+  free(x);
+  free(xbar);
+  free(redgrad);
+  free(finals);
+  free(w.store);
+  return rc;
+}
+
+/* Observables for the trajectory output files (next-row scope, used by the file-level goldens):
+ * Oscillator::expectedEnergy (src/oscillator.cpp:430-470) and Oscillator::population (:518-566). */
+double qo_expected_energy(const qo_ctx* c, int k, const double* x) {
+  const osys* s = &c->s;
+  double e = 0.0;
+  for (int i = 0; i < s->N; i++) {
+    int num = (i % (s->n[k] * s->post[k])) / s->post[k];
+    if (s->lindblad) e += num * x[vec_id(i, i, s->N)];
+    else e += num * (x[i] * x[i] + x[i + s->dim] * x[i + s->dim]);
+  }
+  return e;
+}
+void qo_population(const qo_ctx* c, int k, const double* x, double* pop) {
+  const osys* s = &c->s;
+  for (int l = 0; l < s->n[k]; l++) pop[l] = 0.0;
+  for (int i = 0; i < s->N; i++) {
+    int num = (i % (s->n[k] * s->post[k])) / s->post[k];
+    if (s->lindblad) pop[num] += x[vec_id(i, i, s->N)];
+    else pop[num] += x[i] * x[i] + x[i + s->dim] * x[i + s->dim];
+  }
+}

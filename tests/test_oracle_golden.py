@@ -1,0 +1,109 @@
+"""Pins the CPU oracle (oracle/qd_oracle.c) against the reference's own golden regression files.
+
+The golden numbers were produced by the reference (PETSc build) and are compared by its harness
+at rtol=1e-7 / atol=1e-15 (tests/regression/regression_test.py:14-15).  We hold the oracle to the
+same tolerance on every hot-path case, and report that it actually agrees far tighter.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, REF_ATOL, REF_RTOL, golden_grad, golden_history, golden_rows, load_case
+from oracle.oracle import Oracle
+
+OBJ_KEYS = ["objective", "fidelity", "cost", "regul", "penalty", "penalty_dpdm", "penalty_energy", "penalty_variation"]
+
+
+def _check_history(val, h, rtol=REF_RTOL):
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(h[k], rel=rtol, abs=REF_ATOL), k
+
+
+def _check_rho(case, orc, traj, atol=2e-11):
+    ids = [orc.initial_state(i)[1] for i in range(orc.ninit)]
+    files = sorted(glob.glob(os.path.join(GOLDEN, case, "base", "rho_*.dat")))
+    assert files
+    for f in files:
+        name = os.path.basename(f)
+        ii = ids.index(int(name.split("iinit")[1][:4]))
+        rows, _, d = golden_rows(case, name)
+        part = 0 if "rho_Re" in name else 1
+        mine = traj[ii][rows][:, part * orc.dim:(part + 1) * orc.dim]
+        # the files carry 11 significant digits (%1.10e, src/output.cpp:257-258)
+        np.testing.assert_allclose(mine, d, rtol=REF_RTOL, atol=atol)
+
+
+@pytest.mark.parametrize("case", ["AxC", "AxC_initDiag0", "AxC_initEnsemble", "AxC_initFile", "pipulse"])
+def test_forward_cases(case):
+    sp = load_case(case)
+    assert sp.runtype == "simulation"
+    orc = Oracle(sp)
+    val, traj, _ = orc.evalF(sp.params0, out_freq=sp.output_frequency)
+    _check_history(val, golden_history(case))
+    _check_rho(case, orc, traj)
+    orc.close()
+
+
+def test_axc_observables():
+    """expected<k>.dat / population<k>.dat of AxC (Oscillator::expectedEnergy / population)."""
+    case = "AxC"
+    sp = load_case(case)
+    orc = Oracle(sp)
+    _, traj, _ = orc.evalF(sp.params0, out_freq=sp.output_frequency)
+    for k in range(2):
+        rows, _, d = golden_rows(case, f"expected{k}.iinit0000.dat")
+        mine = np.array([orc.expected_energy(k, traj[0][r]) for r in rows])
+        np.testing.assert_allclose(mine, d[:, 0], rtol=REF_RTOL, atol=1e-12)
+        rows, _, d = golden_rows(case, f"population{k}.iinit0000.dat")
+        mine = np.array([orc.population(k, traj[0][r]) for r in rows])
+        np.testing.assert_allclose(mine, d, rtol=REF_RTOL, atol=1e-12)
+    orc.close()
+
+
+@pytest.mark.parametrize("case,grad_rtol", [
+    ("AxC_grad_initBasis0", 1e-8),     # Lindblad adjoint, matfree <3,20>, 9 initial conditions
+    ("AxC_grad_schroedinger", 1e-8),   # Schroedinger adjoint, Jkl != 0, eta != 0, dpdm/energy/weighted-J penalties
+    ("xgate_sparsemat", 1e-7),         # sparse-matrix path of the reference: same math, other rounding
+])
+def test_gradient_cases(case, grad_rtol):
+    sp = load_case(case)
+    assert sp.runtype == "gradient"
+    orc = Oracle(sp)
+    val, g = orc.evalGradF(sp.params0)
+    h = golden_history(case)
+    _check_history(val, h)
+    gg = golden_grad(case)
+    assert np.linalg.norm(g) == pytest.approx(h["gnorm"], rel=REF_RTOL)
+    # north_star: gradient matching the reference to 1e-8 relative (of the gradient norm)
+    assert np.linalg.norm(g - gg) / np.linalg.norm(gg) < grad_rtol
+    np.testing.assert_allclose(g, gg, rtol=REF_RTOL, atol=REF_RTOL * np.abs(gg).max() * 1e-2)
+    orc.close()
+
+
+@pytest.mark.parametrize("case", ["cnot", "xgate", "state-to-state_spline0"])
+def test_optimization_iteration0(case):
+    """Row 0 of optim_history.dat of the optimisation cases is pure path output: the objective at
+    the initial guess projected onto the control bounds (TAO BQNLS projects first).  Later rows and
+    the projected-gradient norm column depend on PETSc TAO and are not pinned."""
+    sp = load_case(case)
+    assert sp.runtype == "optimization"
+    orc = Oracle(sp)
+    x0 = np.clip(sp.params0, -sp.bounds, sp.bounds)
+    val, _, _ = orc.evalF(x0)
+    _check_history(val, golden_history(case, 0))
+    val2, g = orc.evalGradF(x0)
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15)
+    assert np.all(np.isfinite(g))
+    orc.close()
+
+
+def test_axc_schroedinger_trajectory():
+    case = "AxC_grad_schroedinger"
+    sp = load_case(case)
+    orc = Oracle(sp)
+    _, traj, _ = orc.evalF(sp.params0, out_freq=sp.output_frequency)
+    _check_rho(case, orc, traj)
+    orc.close()
