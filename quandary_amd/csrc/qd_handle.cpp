@@ -1,0 +1,581 @@
+// Operator / stepper level of the C ABI (include/quandary_amd.h): qd_create ... qd_adjoint.
+// Host code only orchestrates: every state-sized operation runs in the HIP kernels of
+// qd_kernels.hip.  There is no CPU fallback: without a HIP device qd_create fails.
+#include "qd_handle.h"
+
+#include <cmath>
+#include <cstdio>
+
+namespace qd {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace qd
+
+using namespace qd;
+
+static int fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+
+extern "C" const char* qd_last_error(void) { return qd::g_err.c_str(); }
+extern "C" const char* qd_version(void) { return "quandary_amd 0.1.0 (gfx950)"; }
+
+extern "C" int qd_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(QD_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+// CompositionalImplMidpoint coefficients (src/timestepper.cpp:735-757)
+static int stage_gammas(int stepper, double* gam) {
+  if (stepper == QD_STEPPER_IMR8) {
+    static const double g8[15] = {0.74167036435061295344822780,  -0.40910082580003159399730010, 0.19075471029623837995387626,
+                                  -0.57386247111608226665638773, 0.29906418130365592384446354,  0.33462491824529818378495798,
+                                  0.31529309239676659663205666,  -0.79688793935291635401978884, 0.31529309239676659663205666,
+                                  0.33462491824529818378495798,  0.29906418130365592384446354,  -0.57386247111608226665638773,
+                                  0.19075471029623837995387626,  -0.40910082580003159399730010, 0.74167036435061295344822780};
+    for (int i = 0; i < 15; i++) gam[i] = g8[i];
+    return 15;
+  }
+  if (stepper == QD_STEPPER_IMR4) {
+    gam[0] = 1. / (2. - pow(2., 1. / 3.));
+    gam[1] = -pow(2., 1. / 3.) * gam[0];
+    gam[2] = 1. / (2. - pow(2., 1. / 3.));
+    return 3;
+  }
+  gam[0] = 1.0;
+  return 1;
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& v) {
+  *dst = nullptr;
+  size_t n = v.size() > 0 ? v.size() : 1;
+  QD_HIP(hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * n));
+  if (!v.empty()) QD_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  return QD_OK;
+}
+
+extern "C" void qd_destroy(qd_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
+                  &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_pen, &h->d_dpdm, &h->d_out4,
+                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y})
+    b->release();
+  if (h->d_segs) (void)hipFree(h->d_segs);
+  if (h->d_oscs) (void)hipFree(h->d_oscs);
+  if (h->d_carriers) (void)hipFree(h->d_carriers);
+  if (h->d_pulses) (void)hipFree(h->d_pulses);
+  if (h->d_napply) (void)hipFree(h->d_napply);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_time* tg, const qd_solver* sol, int device_ordinal,
+                         qd_handle** out) {
+  if (!sys || !ctl || !tg || !sol || !out) return fail(QD_ERR_INVALID, "qd_create: null argument");
+  *out = nullptr;
+  if (sys->nosc < 1 || sys->nosc > QD_MAX_OSC) return fail(QD_ERR_INVALID, "qd_create: nosc out of range");
+  if (tg->ntime < 1 || !(tg->dt > 0.0)) return fail(QD_ERR_INVALID, "qd_create: ntime and dt must be positive");
+  if (sol->stepper < QD_STEPPER_IMR || sol->stepper > QD_STEPPER_EE) return fail(QD_ERR_INVALID, "qd_create: unknown timestepper");
+  if (sol->linsolve != QD_LINSOLVE_GMRES && sol->linsolve != QD_LINSOLVE_NEUMANN)
+    return fail(QD_ERR_INVALID, "qd_create: unknown linear solver");
+  int ndev = qd_device_count();
+  if (ndev <= 0) return fail(QD_ERR_DEVICE, "qd_create: no HIP device visible (this library has no CPU path)");
+  if (device_ordinal < 0 || device_ordinal >= ndev) return fail(QD_ERR_INVALID, "qd_create: device ordinal out of range");
+
+  qd_handle* h = new qd_handle();
+  h->device = device_ordinal;
+  h->tg = *tg;
+  h->sol = *sol;
+  // ---- system constants: src/mastereq.cpp:14-60, src/oscillator.cpp:15-23, src/main.cpp:299-307
+  DevSys& S = h->S;
+  std::memset(&S, 0, sizeof S);
+  S.Q = sys->nosc;
+  S.lindblad = sys->lindblad_type != QD_LINDBLAD_NONE;
+  const bool addT1 = sys->lindblad_type == QD_LINDBLAD_DECAY || sys->lindblad_type == QD_LINDBLAD_BOTH;
+  const bool addT2 = sys->lindblad_type == QD_LINDBLAD_DEPHASE || sys->lindblad_type == QD_LINDBLAD_BOTH;
+  long long N = 1;
+  h->dim_ess = 1;
+  for (int k = 0; k < S.Q; k++) {
+    S.n[k] = sys->nlevels[k];
+    S.ness[k] = sys->nessential[k];
+    if (S.n[k] < 1 || S.n[k] > 255) {
+      delete h;
+      return fail(QD_ERR_INVALID, "qd_create: nlevels must be in 1..255");
+    }
+    if (S.ness[k] < 1 || S.ness[k] > S.n[k]) S.ness[k] = S.n[k];
+    N *= S.n[k];
+    h->dim_ess *= S.ness[k];
+    if (S.n[k] > S.maxn) S.maxn = S.n[k];
+  }
+  long long dim = S.lindblad ? N * N : N;
+  if (dim > 4096) {
+    delete h;
+    return fail(QD_ERR_UNSUPPORTED, "qd_create: state dimension > 4096 needs the tiled large-system kernels (not built yet)");
+  }
+  if (S.Q > 5) {
+    delete h;
+    return fail(QD_ERR_UNSUPPORTED, "qd_create: the stencil kernels are instantiated for 1..5 oscillators (as the reference's matrix-free path)");
+  }
+  S.N = (int)N;
+  S.dim = (int)dim;
+  for (int k = 0; k < S.Q; k++) {
+    S.post[k] = 1;
+    for (int j = k + 1; j < S.Q; j++) S.post[k] *= S.n[j];
+    S.detune[k] = 2.0 * M_PI * (sys->transfreq[k] - sys->rotfreq[k]);
+    S.xi[k] = 2.0 * M_PI * sys->selfkerr[k];
+    S.g1[k] = (sys->decay_time[k] > 1e-14 && addT1) ? 1.0 / sys->decay_time[k] : 0.0;
+    S.g2[k] = (sys->dephase_time[k] > 1e-14 && addT2) ? 1.0 / sys->dephase_time[k] : 0.0;
+  }
+  S.npairs = S.Q * (S.Q - 1) / 2;
+  DevCtlDesc& D = h->dctl;
+  std::memset(&D, 0, sizeof D);
+  int idx = 0;
+  for (int k = 0; k < S.Q; k++)
+    for (int l = k + 1; l < S.Q; l++) {
+      S.xikl[idx] = 2.0 * M_PI * sys->crosskerr[idx];
+      S.J[idx] = 2.0 * M_PI * sys->Jkl[idx];
+      D.eta[idx] = 2.0 * M_PI * (sys->rotfreq[k] - sys->rotfreq[l]);
+      idx++;
+    }
+  // ---- controls: src/oscillator.cpp:45-132, src/controlbasis.cpp:20-32,219-225
+  int carpos = 0, off = 0;
+  for (int k = 0; k < S.Q; k++) {
+    DevOsc o{};
+    o.seg_begin = (int)h->segs.size();
+    o.car_begin = (int)h->carriers.size();
+    o.ncar = ctl->ncarrier ? ctl->ncarrier[k] : 0;
+    for (int f = 0; f < o.ncar; f++) h->carriers.push_back(2.0 * M_PI * ctl->carrier_freq[carpos + f]);
+    carpos += o.ncar;
+    int skip = 0;
+    for (int g = 0; g < ctl->nseg_total; g++) {
+      if (ctl->seg_osc[g] != k) continue;
+      DevSeg sg{};
+      sg.type = ctl->seg_type[g];
+      sg.nsplines = ctl->seg_nsplines[g];
+      sg.tstart = ctl->seg_tstart[g];
+      sg.tstop = ctl->seg_tstop[g];
+      sg.skip = skip;
+      if (sg.type == QD_CTRL_BSPLINE) {
+        if (sg.nsplines < 3) { delete h; return fail(QD_ERR_INVALID, "qd_create: spline segment needs >= 3 splines"); }
+        sg.dtknot = (sg.tstop - sg.tstart) / (double)(sg.nsplines - 2);
+        sg.width = 3.0 * sg.dtknot;
+      } else if (sg.type == QD_CTRL_BSPLINE0) {
+        if (sg.nsplines < 2) { delete h; return fail(QD_ERR_INVALID, "qd_create: spline0 segment needs >= 2 splines"); }
+        sg.dtknot = (sg.tstop - sg.tstart) / (sg.nsplines - 1.0);
+        sg.width = sg.dtknot;
+      } else {
+        delete h;
+        return fail(QD_ERR_UNSUPPORTED, "qd_create: control segment type without a gradient in the reference (step / spline_amplitude)");
+      }
+      skip += 2 * sg.nsplines * o.ncar;
+      h->segs.push_back(sg);
+      o.nseg++;
+    }
+    o.nparams = skip;
+    o.offset = off;
+    off += skip;
+    o.pulse_begin = (int)h->pulses.size() / 3;
+    for (int i = 0; i < ctl->npipulse; i++)
+      if (ctl->pipulse_osc[i] == k) {
+        h->pulses.push_back(ctl->pipulse_tstart[i]);
+        h->pulses.push_back(ctl->pipulse_tstop[i]);
+        h->pulses.push_back(ctl->pipulse_amp[i]);
+        o.npulse++;
+        h->has_pipulse = true;
+      }
+    h->oscs.push_back(o);
+  }
+  h->ndesign = off;
+  h->params.assign(off, 0.0);
+
+  // ---- device resources
+  int rc = QD_OK;
+  auto dev_setup = [&]() -> int {
+    QD_HIP(hipSetDevice(h->device));
+    QD_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    QD_HIP(hipEventCreate(&h->ev0));
+    QD_HIP(hipEventCreate(&h->ev1));
+    int r;
+    if ((r = upload(&h->d_segs, h->segs))) return r;
+    if ((r = upload(&h->d_oscs, h->oscs))) return r;
+    if ((r = upload(&h->d_carriers, h->carriers))) return r;
+    if ((r = upload(&h->d_pulses, h->pulses))) return r;
+    QD_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_napply), sizeof(unsigned long long)));
+    return QD_OK;
+  };
+  rc = dev_setup();
+  if (rc) {
+    qd_destroy(h);
+    return rc;
+  }
+  D.Q = S.Q;
+  D.enforce_bc = ctl->enforce_bc;
+  D.npairs = S.npairs;
+  D.segs = h->d_segs;
+  D.oscs = h->d_oscs;
+  D.carriers = h->d_carriers;
+  D.pulses = h->d_pulses;
+  D.Tfinal = tg->ntime * tg->dt;
+
+  // ---- step schedule (times exactly as the reference forms them: timestepper.cpp:128-129, :587-590, :786-798)
+  double gam[15];
+  h->nstages = (sol->stepper == QD_STEPPER_EE) ? 1 : stage_gammas(sol->stepper, gam);
+  h->nsub = tg->ntime * h->nstages;
+  h->cs = ctl_stride(S.Q, S.npairs);
+  for (int n = 0; n < tg->ntime; n++) {
+    const double tstart = n * tg->dt, tstop = (n + 1) * tg->dt;
+    if (sol->stepper == QD_STEPPER_EE) {
+      h->sched_t.push_back(tstart);
+      h->sched_h.push_back(tstop - tstart);
+    } else if (sol->stepper == QD_STEPPER_IMR) {
+      h->sched_t.push_back((tstart + tstop) / 2.0);
+      h->sched_h.push_back(tstop - tstart);
+    } else {
+      const double dt = tstop - tstart;
+      double tcurr = tstart;
+      for (int s = 0; s < h->nstages; s++) {
+        const double dts = gam[s] * dt;
+        const double t1 = tcurr + dts;
+        h->sched_t.push_back((tcurr + t1) / 2.0);
+        h->sched_h.push_back(t1 - tcurr);
+        tcurr = tcurr + dts;
+      }
+    }
+    h->etimes.push_back(tstop);
+  }
+  if (sol->stepper == QD_STEPPER_EE) {  // extra row M(T) for the adjoint of the last step
+    h->sched_t.push_back(tg->ntime * tg->dt);
+    h->sched_h.push_back(0.0);
+  }
+  auto sched_setup = [&]() -> int {
+    int r;
+    const size_t nrows = h->sched_t.size();
+    if ((r = h->d_sched_t.ensure(nrows))) return r;
+    if ((r = h->d_sched_h.ensure(nrows))) return r;
+    if ((r = h->d_etimes.ensure(h->etimes.size()))) return r;
+    if ((r = h->d_ezero.ensure(h->etimes.size()))) return r;
+    if ((r = h->d_table.ensure(nrows * h->cs))) return r;
+    if ((r = h->d_etable.ensure(h->etimes.size() * h->cs))) return r;
+    if ((r = h->d_onerow.ensure(h->cs))) return r;
+    if ((r = h->d_onetime.ensure(2))) return r;
+    if ((r = h->d_params.ensure(h->ndesign))) return r;
+    QD_HIP(hipMemcpy(h->d_sched_t.p, h->sched_t.data(), sizeof(double) * nrows, hipMemcpyHostToDevice));
+    QD_HIP(hipMemcpy(h->d_sched_h.p, h->sched_h.data(), sizeof(double) * nrows, hipMemcpyHostToDevice));
+    QD_HIP(hipMemcpy(h->d_etimes.p, h->etimes.data(), sizeof(double) * h->etimes.size(), hipMemcpyHostToDevice));
+    QD_HIP(hipMemset(h->d_ezero.p, 0, sizeof(double) * h->etimes.size()));
+    QD_HIP(hipMemset(h->d_params.p, 0, sizeof(double) * (h->ndesign > 0 ? h->ndesign : 1)));
+    return QD_OK;
+  };
+  rc = sched_setup();
+  if (rc) {
+    qd_destroy(h);
+    return rc;
+  }
+  h->etable_host.assign(h->etimes.size() * h->cs, 0.0);
+  *out = h;
+  return QD_OK;
+}
+
+extern "C" int qd_dim(const qd_handle* h) { return h ? h->S.dim : QD_ERR_INVALID; }
+extern "C" int qd_dim_rho(const qd_handle* h) { return h ? h->S.N : QD_ERR_INVALID; }
+extern "C" int qd_dim_ess(const qd_handle* h) { return h ? h->dim_ess : QD_ERR_INVALID; }
+extern "C" int qd_ndesign(const qd_handle* h) { return h ? h->ndesign : QD_ERR_INVALID; }
+
+extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
+  if (!h || (!alpha && ndesign > 0)) return fail(QD_ERR_INVALID, "qd_set_params: null argument");
+  if (ndesign != h->ndesign) return fail(QD_ERR_INVALID, "qd_set_params: ndesign mismatch");
+  QD_HIP(hipSetDevice(h->device));
+  if (ndesign > 0) {
+    std::memcpy(h->params.data(), alpha, sizeof(double) * ndesign);
+    QD_HIP(hipMemcpyAsync(h->d_params.p, h->params.data(), sizeof(double) * ndesign, hipMemcpyHostToDevice, h->stream));
+  }
+  h->params_dirty = true;
+  h->traj_valid = false;
+  return QD_OK;
+}
+
+// Evaluate the control tables for the current parameters (one tiny kernel per parameter update
+// instead of Q*ncarrier*nsplines basis evaluations per step and initial condition).
+int qd_handle::refresh_tables() {
+  if (!params_dirty) return QD_OK;
+  QD_HIP(launch_controls(dctl, d_params.p, d_sched_t.p, d_sched_h.p, (int)sched_t.size(), d_table.p, cs, stream));
+  QD_HIP(launch_controls(dctl, d_params.p, d_etimes.p, d_ezero.p, (int)etimes.size(), d_etable.p, cs, stream));
+  QD_HIP(hipMemcpyAsync(etable_host.data(), d_etable.p, sizeof(double) * etable_host.size(), hipMemcpyDeviceToHost, stream));
+  QD_HIP(hipStreamSynchronize(stream));
+  params_dirty = false;
+  return QD_OK;
+}
+
+// energyPenaltyIntegral summed over the time loop (src/timestepper.cpp:154, :444-455)
+double qd_handle::energy_penalty_host() const {
+  double e = 0.0;
+  for (size_t n = 0; n < etimes.size(); n++) {
+    double pen = 0.0;
+    const double* row = etable_host.data() + n * cs;
+    for (int k = 0; k < S.Q; k++) pen += (row[2 + k] * row[2 + k] + row[2 + S.Q + k] * row[2 + S.Q + k]) / tg.ntime;
+    e += pen;
+  }
+  return e;
+}
+
+extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, double* pq) {
+  if (!h || !times || !pq || nt < 0) return fail(QD_ERR_INVALID, "qd_eval_controls: bad argument");
+  QD_HIP(hipSetDevice(h->device));
+  for (int i = 0; i < nt; i++)
+    if (times[i] > h->dctl.Tfinal) return fail(QD_ERR_INVALID, "qd_eval_controls: t > Tfinal (src/oscillator.cpp:284-287)");
+  DBuf dt, dz, dtab;
+  int r;
+  if ((r = dt.ensure(nt)) || (r = dz.ensure(nt)) || (r = dtab.ensure((size_t)nt * h->cs))) return r;
+  QD_HIP(hipMemcpyAsync(dt.p, times, sizeof(double) * nt, hipMemcpyHostToDevice, h->stream));
+  QD_HIP(hipMemsetAsync(dz.p, 0, sizeof(double) * nt, h->stream));
+  QD_HIP(launch_controls(h->dctl, h->d_params.p, dt.p, dz.p, nt, dtab.p, h->cs, h->stream));
+  std::vector<double> tab((size_t)nt * h->cs);
+  QD_HIP(hipMemcpyAsync(tab.data(), dtab.p, sizeof(double) * tab.size(), hipMemcpyDeviceToHost, h->stream));
+  QD_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < nt; i++)
+    for (int k = 0; k < h->S.Q; k++) {
+      pq[(i * h->S.Q + k) * 2] = tab[(size_t)i * h->cs + 2 + k];
+      pq[(i * h->S.Q + k) * 2 + 1] = tab[(size_t)i * h->cs + 2 + h->S.Q + k];
+    }
+  dt.release();
+  dz.release();
+  dtab.release();
+  return QD_OK;
+}
+
+static int check_cfg(const LaunchCfg& cfg) {
+  const int lim = cfg.ept <= 4 ? 1024 : 512;
+  if (cfg.block > lim) return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
+  if (cfg.lds > 160 * 1024) return fail(QD_ERR_UNSUPPORTED, "state does not fit the 160 KiB LDS of one CU");
+  return QD_OK;
+}
+
+extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double* x, double* y, int nb) {
+  if (!h || !x || !y || nb < 1) return fail(QD_ERR_INVALID, "qd_apply_rhs: bad argument");
+  if (t > h->dctl.Tfinal) return fail(QD_ERR_INVALID, "qd_apply_rhs: t > Tfinal (src/oscillator.cpp:284-287)");
+  QD_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)nb * 2 * h->S.dim;
+  int r;
+  if ((r = h->d_x0.ensure(n)) || (r = h->d_y.ensure(n))) return r;
+  const double tt[2] = {t, 0.0};
+  QD_HIP(hipMemcpyAsync(h->d_onetime.p, tt, sizeof tt, hipMemcpyHostToDevice, h->stream));
+  QD_HIP(launch_controls(h->dctl, h->d_params.p, h->d_onetime.p, h->d_onetime.p + 1, 1, h->d_onerow.p, h->cs, h->stream));
+  QD_HIP(hipMemcpyAsync(h->d_x0.p, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  LaunchCfg cfg = pick_config(h->S, nb);
+  if ((r = check_cfg(cfg))) return r;
+  QD_HIP(launch_apply(h->S, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
+  QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  QD_HIP(hipStreamSynchronize(h->stream));
+  return QD_OK;
+}
+
+extern "C" int qd_set_target(qd_handle* h, const qd_target* tgt, int nb) {
+  if (!h || !tgt || nb < 1) return fail(QD_ERR_INVALID, "qd_set_target: bad argument");
+  if (tgt->target_type != QD_TARGET_PURE && !tgt->target_states) return fail(QD_ERR_INVALID, "qd_set_target: target states required");
+  if (tgt->objective_type == QD_OBJ_JMEASURE && tgt->target_type != QD_TARGET_PURE)
+    return fail(QD_ERR_INVALID, "qd_set_target: Jmeasure needs a pure target (src/optimtarget.cpp:758-761)");
+  QD_HIP(hipSetDevice(h->device));
+  int r;
+  h->dtg.target_type = tgt->target_type;
+  h->dtg.objective_type = tgt->objective_type;
+  h->dtg.purestate_id = tgt->purestate_id;
+  h->dtg.idm = h->S.lindblad ? tgt->purestate_id * (h->S.N + 1) : tgt->purestate_id;
+  h->dtg.tstates = nullptr;
+  if (tgt->target_type != QD_TARGET_PURE) {
+    const size_t n = (size_t)nb * 2 * h->S.dim;
+    if ((r = h->d_tstates.ensure(n))) return r;
+    QD_HIP(hipMemcpy(h->d_tstates.p, tgt->target_states, sizeof(double) * n, hipMemcpyHostToDevice));
+    h->dtg.tstates = h->d_tstates.p;
+  }
+  std::vector<double> pur(nb, 1.0);
+  if (tgt->purity)
+    for (int i = 0; i < nb; i++) pur[i] = tgt->purity[i];
+  if ((r = h->d_purity.ensure(nb))) return r;
+  QD_HIP(hipMemcpy(h->d_purity.p, pur.data(), sizeof(double) * nb, hipMemcpyHostToDevice));
+  h->dtg.purity = h->d_purity.p;
+  h->target_set = true;
+  h->target_nb = nb;
+  return QD_OK;
+}
+
+extern "C" int qd_set_penalty(qd_handle* h, const qd_penalty* pen) {
+  if (!h || !pen) return fail(QD_ERR_INVALID, "qd_set_penalty: null argument");
+  h->pen = *pen;
+  return QD_OK;
+}
+
+int qd_handle::traj_doubles(int nb, size_t* n) const {
+  *n = (size_t)(nsub + 1) * (size_t)nb * 2 * (size_t)S.dim;
+  return QD_OK;
+}
+
+static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget* tg) {
+  std::memset(&a, 0, sizeof a);
+  a.S = h->S;
+  if (tg) a.tg = *tg;
+  a.ctl = h->d_table.p;
+  a.cs = h->cs;
+  a.nsub = h->nsub;
+  a.nstages = h->nstages;
+  a.ntime = h->tg.ntime;
+  a.nb = nb;
+  a.dt = h->tg.dt;
+  a.Tfinal = h->dctl.Tfinal;
+  a.stepper_ee = h->sol.stepper == QD_STEPPER_EE;
+  a.linsolve = h->sol.linsolve;
+  a.maxiter = h->sol.maxiter;
+  a.abstol = h->sol.abstol;
+  a.reltol = h->sol.reltol;
+  // penalties that need target data are only active when a target has been set
+  a.gamma_penalty = h->pen.gamma_penalty;
+  a.penalty_param = tg ? h->pen.penalty_param : 0.0;
+  a.gamma_dpdm = h->pen.gamma_penalty_dpdm;
+  a.leak_on = 0;
+  for (int k = 0; k < h->S.Q; k++)
+    if (h->S.ness[k] < h->S.n[k]) a.leak_on = 1;  // addLeakagePrevent, src/timestepper.cpp:28-32
+}
+
+int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarget* tgp, double* energy) {
+  QD_HIP(hipSetDevice(device));
+  int r;
+  if ((r = refresh_tables())) return r;
+  if (pen.gamma_penalty > 1e-13 && pen.penalty_param > 1e-13 && !tgp)
+    return fail(QD_ERR_STATE, "qd_forward: the weighted-J penalty (optim_penalty_param > 0) needs qd_set_target first");
+  const size_t n = (size_t)nb * 2 * S.dim;
+  if ((r = d_xT.ensure(n)) || (r = d_pen.ensure(nb)) || (r = d_dpdm.ensure(nb)) || (r = d_out4.ensure((size_t)4 * nb))) return r;
+  traj_valid = false;
+  if (store) {
+    size_t nt;
+    traj_doubles(nb, &nt);
+    if ((r = d_traj.ensure(nt))) return r;
+  }
+  SweepArgs a;
+  fill_sweep(this, a, nb, tgp);
+  a.x0 = dx0;
+  a.xT = d_xT.p;
+  a.traj = store ? d_traj.p : nullptr;
+  a.pen_out = d_pen.p;
+  a.dpdm_out = d_dpdm.p;
+  a.napply = d_napply;
+  LaunchCfg cfg = pick_config(S, nb);
+  if ((r = check_cfg(cfg))) return r;
+  QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
+  QD_HIP(hipEventRecord(ev0, stream));
+  QD_HIP(launch_forward(a, cfg, stream));
+  QD_HIP(hipEventRecord(ev1, stream));
+  if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4.p, stream));
+  unsigned long long nap = 0;
+  QD_HIP(hipMemcpyAsync(&nap, d_napply, sizeof nap, hipMemcpyDeviceToHost, stream));
+  QD_HIP(hipStreamSynchronize(stream));
+  float ms = 0.f;
+  QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+  last_fwd_ms = ms;
+  last_mean_applies = (double)nap / ((double)nb * (double)nsub);
+  last_nb = nb;
+  traj_valid = store;
+  if (energy) *energy = energy_penalty_host();
+  return QD_OK;
+}
+
+extern "C" int qd_forward(qd_handle* h, const double* x0, int nb, int store_trajectory, qd_forward_out* out) {
+  if (!h || !x0 || nb < 1) return fail(QD_ERR_INVALID, "qd_forward: bad argument");
+  if (h->target_set && h->target_nb != nb) return fail(QD_ERR_INVALID, "qd_forward: batch size differs from qd_set_target");
+  QD_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)nb * 2 * h->S.dim;
+  int r;
+  if ((r = h->d_x0.ensure(n))) return r;
+  QD_HIP(hipMemcpyAsync(h->d_x0.p, x0, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  double energy = 0.0;
+  if ((r = h->forward_dev(h->d_x0.p, nb, store_trajectory != 0, h->target_set ? &h->dtg : nullptr, &energy))) return r;
+  if (out) {
+    if (out->final_states) QD_HIP(hipMemcpy(out->final_states, h->d_xT.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (out->penalty_integral) QD_HIP(hipMemcpy(out->penalty_integral, h->d_pen.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    if (out->penalty_dpdm) QD_HIP(hipMemcpy(out->penalty_dpdm, h->d_dpdm.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    if (out->energy_penalty) *out->energy_penalty = energy;
+    if (h->target_set && (out->J_re || out->J_im || out->fid_re || out->fid_im)) {
+      std::vector<double> o4((size_t)4 * nb);
+      QD_HIP(hipMemcpy(o4.data(), h->d_out4.p, sizeof(double) * o4.size(), hipMemcpyDeviceToHost));
+      for (int b = 0; b < nb; b++) {
+        if (out->J_re) out->J_re[b] = o4[4 * b];
+        if (out->J_im) out->J_im[b] = o4[4 * b + 1];
+        if (out->fid_re) out->fid_re[b] = o4[4 * b + 2];
+        if (out->fid_im) out->fid_im[b] = o4[4 * b + 3];
+      }
+    }
+  }
+  return QD_OK;
+}
+
+extern "C" int qd_get_state(qd_handle* h, int timestep, double* x) {
+  if (!h || !x) return fail(QD_ERR_INVALID, "qd_get_state: null argument");
+  if (!h->traj_valid) return fail(QD_ERR_STATE, "qd_get_state: no stored trajectory (call qd_forward with store_trajectory=1)");
+  if (timestep < 0 || timestep > h->tg.ntime) return fail(QD_ERR_INVALID, "qd_get_state: time step out of range");
+  QD_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)h->last_nb * 2 * h->S.dim;
+  QD_HIP(hipMemcpy(x, h->d_traj.p + (size_t)timestep * h->nstages * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return QD_OK;
+}
+
+int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, const DevTarget* tgp, bool accumulate) {
+  QD_HIP(hipSetDevice(device));
+  if (!traj_valid || last_nb != nb) return fail(QD_ERR_STATE, "qd_adjoint: needs a forward sweep of the same batch with store_trajectory=1");
+  if (has_pipulse) return fail(QD_ERR_UNSUPPORTED, "qd_adjoint: derivative of pi-pulses is not implemented in the reference (src/oscillator.cpp:373-378)");
+  int r;
+  const size_t ncol = (size_t)nsub * 2 * S.Q;
+  if ((r = d_coeff.ensure((size_t)nb * ncol)) || (r = d_coeffsum.ensure(ncol))) return r;
+  SweepArgs a;
+  fill_sweep(this, a, nb, tgp);
+  a.traj = d_traj.p;
+  a.xbarT = dxbarT;
+  a.jbar = djbar;
+  a.coeff = d_coeff.p;
+  LaunchCfg cfg = pick_config(S, nb);
+  if ((r = check_cfg(cfg))) return r;
+  QD_HIP(hipEventRecord(ev0, stream));
+  QD_HIP(launch_adjoint(a, cfg, stream));
+  QD_HIP(hipEventRecord(ev1, stream));
+  QD_HIP(launch_reduce_coeff(d_coeff.p, nb, (int)ncol, d_coeffsum.p, accumulate ? 1 : 0, stream));
+  QD_HIP(hipStreamSynchronize(stream));
+  float ms = 0.f;
+  QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+  last_adj_ms = accumulate ? last_adj_ms + ms : ms;
+  return QD_OK;
+}
+
+int qd_handle::gradient_from_coeffs(double ebar, double* grad) {
+  QD_HIP(hipSetDevice(device));
+  int r;
+  if (ndesign == 0) return QD_OK;
+  if ((r = d_grad.ensure(ndesign))) return r;
+  const int nsub_flag = sol.stepper == QD_STEPPER_EE ? -nsub : nsub;
+  QD_HIP(launch_grad(dctl, d_table.p, cs, nsub_flag, d_coeffsum.p, d_etable.p, tg.ntime, ebar, d_grad.p, ndesign, stream));
+  QD_HIP(hipMemcpyAsync(grad, d_grad.p, sizeof(double) * ndesign, hipMemcpyDeviceToHost, stream));
+  QD_HIP(hipStreamSynchronize(stream));
+  return QD_OK;
+}
+
+extern "C" int qd_adjoint(qd_handle* h, const double* xbarT, const double* jbar, int nb, double* grad) {
+  if (!h || !xbarT || !jbar || !grad || nb < 1) return fail(QD_ERR_INVALID, "qd_adjoint: bad argument");
+  QD_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)nb * 2 * h->S.dim;
+  int r;
+  if ((r = h->d_xbar.ensure(n)) || (r = h->d_jbar.ensure((size_t)3 * nb))) return r;
+  QD_HIP(hipMemcpyAsync(h->d_xbar.p, xbarT, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  QD_HIP(hipMemcpyAsync(h->d_jbar.p, jbar, sizeof(double) * 3 * nb, hipMemcpyHostToDevice, h->stream));
+  if ((r = h->adjoint_dev(h->d_xbar.p, h->d_jbar.p, nb, h->target_set ? &h->dtg : nullptr, false))) return r;
+  double ebar = 0.0;
+  if (h->pen.gamma_penalty_energy > 1e-13)
+    for (int b = 0; b < nb; b++) ebar += jbar[3 * b + 2];
+  return h->gradient_from_coeffs(ebar, grad);
+}
+
+extern "C" double qd_last_mean_applies(const qd_handle* h) { return h ? h->last_mean_applies : 0.0; }
+extern "C" double qd_last_forward_ms(const qd_handle* h) { return h ? h->last_fwd_ms : 0.0; }
+extern "C" double qd_last_adjoint_ms(const qd_handle* h) { return h ? h->last_adj_ms : 0.0; }

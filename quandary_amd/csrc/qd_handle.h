@@ -1,0 +1,92 @@
+// Host-side state behind the opaque qd_handle (one per GPU, single-threaded like the reference's
+// TimeStepper/MasterEq objects).  Internal; the public boundary is include/quandary_amd.h.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qd_internal.h"
+
+#define QD_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      qd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                                \
+      return (_e == hipErrorOutOfMemory) ? QD_ERR_NOMEM : QD_ERR_DEVICE;                               \
+    }                                                                                                  \
+  } while (0)
+
+namespace qd {
+
+// growable device buffer of doubles
+struct DBuf {
+  double* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return QD_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    QD_HIP(hipMalloc(reinterpret_cast<void**>(&p), sizeof(double) * (n > 0 ? n : 1)));
+    cap = n;
+    return QD_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace qd
+
+struct qd_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  qd::DevSys S{};
+  qd_time tg{};
+  qd_solver sol{};
+  qd_penalty pen{};
+  // controls (host description + device mirror)
+  std::vector<qd::DevSeg> segs;
+  std::vector<qd::DevOsc> oscs;
+  std::vector<double> carriers, pulses;
+  qd::DevCtlDesc dctl{};
+  qd::DevSeg* d_segs = nullptr;
+  qd::DevOsc* d_oscs = nullptr;
+  double *d_carriers = nullptr, *d_pulses = nullptr;
+  int ndesign = 0, dim_ess = 1;
+  bool has_pipulse = false;
+  std::vector<double> params;
+  qd::DBuf d_params;
+  bool params_dirty = true;
+  // step schedule
+  int nstages = 1, nsub = 0, cs = 0;
+  std::vector<double> sched_t, sched_h, etimes;  // host copies
+  qd::DBuf d_sched_t, d_sched_h, d_etimes, d_ezero, d_table, d_etable, d_onerow, d_onetime;
+  std::vector<double> etable_host;
+  // target for in-loop / final objective terms
+  bool target_set = false;
+  qd::DevTarget dtg{};
+  qd::DBuf d_tstates, d_purity;
+  int target_nb = 0;
+  // sweep buffers
+  qd::DBuf d_x0, d_xT, d_traj, d_pen, d_dpdm, d_out4, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y;
+  unsigned long long* d_napply = nullptr;
+  int last_nb = 0;
+  bool traj_valid = false;
+  double last_mean_applies = 0.0, last_fwd_ms = 0.0, last_adj_ms = 0.0;
+
+  // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
+  int refresh_tables();
+  int traj_doubles(int nb, size_t* n) const;
+  // forward sweep on device-resident states; results stay on the device (d_pen, d_dpdm, d_xT, d_out4)
+  int forward_dev(const double* dx0, int nb, bool store, const qd::DevTarget* tg, double* energy);
+  // adjoint sweep; dxbarT/djbar device pointers; coefficient sums accumulate into d_coeffsum
+  int adjoint_dev(const double* dxbarT, const double* djbar, int nb, const qd::DevTarget* tg, bool accumulate);
+  // gradient from d_coeffsum (+ energy term ebar); writes host grad[ndesign]
+  int gradient_from_coeffs(double ebar, double* grad);
+  double energy_penalty_host() const;
+};

@@ -1,0 +1,103 @@
+// Internal declarations shared by the kernel translation unit (qd_kernels.hip) and the
+// host side of the C ABI (qd_handle.cpp, qd_optim.cpp).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "quandary_amd.h"
+
+namespace qd {
+
+// ---------------------------------------------------------------------------------------------
+// Device-side description of the operator: the MatShellCtx parameter block of the reference
+// (include/mastereq.hpp:20-42) with every constant already in rad/ns.  Passed BY VALUE as a
+// kernel argument so that all per-oscillator constants are wave-uniform scalar loads.
+// ---------------------------------------------------------------------------------------------
+struct DevSys {
+  int Q, lindblad, N, dim, npairs, maxn;
+  int n[QD_MAX_OSC], ness[QD_MAX_OSC], post[QD_MAX_OSC];
+  double detune[QD_MAX_OSC], xi[QD_MAX_OSC], g1[QD_MAX_OSC], g2[QD_MAX_OSC];
+  double xikl[QD_MAX_PAIRS], J[QD_MAX_PAIRS];
+};
+
+// Control parameterisation on the device (src/oscillator.cpp:45-132, src/controlbasis.cpp:20-32,219-225)
+struct DevSeg {
+  int type, nsplines, skip, pad;
+  double tstart, tstop, dtknot, width;
+};
+struct DevOsc {
+  int seg_begin, nseg, car_begin, ncar, offset, nparams, pulse_begin, npulse;
+};
+struct DevCtlDesc {
+  int Q, enforce_bc, npairs, pad;
+  const DevSeg* segs;
+  const DevOsc* oscs;
+  const double* carriers;  // rad/ns
+  const double* pulses;    // [npulse_total][3] tstart, tstop, amp
+  double eta[QD_MAX_PAIRS];
+  double Tfinal;
+};
+
+// One row of the step-control table per sub-step: [h, t_eval, p_0..p_{Q-1}, q_0..q_{Q-1},
+// cos_0.., sin_0..].  t_eval is the midpoint (IMR family) or tstart (EE).
+inline int ctl_stride(int Q, int npairs) { return 2 + 2 * Q + 2 * npairs; }
+
+struct DevTarget {
+  int target_type, objective_type, purestate_id, idm;  // idm = vectorised index of the pure target
+  const double* tstates;                               // [nb][2*dim] or nullptr
+  const double* purity;                                // [nb]
+};
+
+struct SweepArgs {
+  DevSys S;
+  DevTarget tg;
+  const double* ctl;  // step-control table [nsub][cs]
+  int cs, nsub, nstages, ntime, nb;
+  double dt, Tfinal;
+  int stepper_ee, linsolve, maxiter, mr;  // mr: GMRES restart length held in registers
+  double abstol, reltol;
+  // penalties (src/timestepper.cpp:256-480)
+  double gamma_penalty, penalty_param, gamma_dpdm;
+  int leak_on;
+  // forward
+  const double* x0;  // [nb][2*dim]
+  double* xT;        // [nb][2*dim]
+  double* traj;      // [(nsub+1)][nb][2*dim] or nullptr
+  double* pen_out;   // [nb]
+  double* dpdm_out;  // [nb]
+  unsigned long long* napply;
+  // adjoint
+  const double* xbarT;  // [nb][2*dim]
+  const double* jbar;   // [nb][3]
+  double* coeff;        // [nb][nsub][2Q]  (x^T dM/dp_k z, x^T dM/dq_k z)
+  double* xbar0;        // [nb][2*dim] adjoint at t=0 (diagnostic) or nullptr
+};
+
+struct LaunchCfg {
+  int ept;    // elements per thread (template instantiation)
+  int block;  // threads per block (one block per initial condition)
+  size_t lds;
+};
+
+// kernel launch wrappers implemented in qd_kernels.hip; all return hipError_t
+hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
+                           double* table, int cs, hipStream_t st);
+hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
+                        const LaunchCfg& cfg, hipStream_t st);
+hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
+hipError_t launch_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
+hipError_t launch_objective(const DevSys& S, const DevTarget& tg, const double* x, int nb, double* out4, hipStream_t st);
+hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, const double* rbar_ibar, int nb, double* xbar,
+                       hipStream_t st);
+hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st);
+hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
+                       const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
+bool config_supported(int Q, int ept);
+LaunchCfg pick_config(const DevSys& S, int nb);
+
+void set_error(const std::string& msg);
+
+}  // namespace qd

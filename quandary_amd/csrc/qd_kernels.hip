@@ -1,0 +1,304 @@
+// qd_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4) for the Quandary hot path.
+//
+// Design: the batch of initial conditions is the data-parallel axis.  One
+// workgroup owns one initial condition for the WHOLE time loop (persistent over time): the state
+// lives in registers (each thread owns EPT elements) and in LDS as interleaved complex numbers
+// (one ds_read_b128 per stencil neighbour), the linear-solver iterations run inside the kernel,
+// and HBM sees only the stored trajectory (Lindblad adjoint) and the final state.  Controls are
+// streamed from a precomputed per-sub-step table through scalar loads.
+//
+// Reference semantics restated here (paths relative to the reference repository):
+//   stencil            include/mastereq.hpp:316-912, src/mastereq.cpp:1464-1709 (generic in Q, runtime levels)
+//   gradient coeffs    include/mastereq.hpp:553-604, src/mastereq.cpp:970-1276
+//   IMR fwd / bwd      src/timestepper.cpp:584-694, Neumann :697-727
+//   time loops         src/timestepper.cpp:96-253, penalties :256-480
+//   controls           src/oscillator.cpp:281-381, src/controlbasis.cpp:48-96,230-254
+//   objective / seeds  src/optimtarget.cpp:343-447, :712-897
+#include <hip/hip_runtime.h>
+
+#include "qd_device.h"
+
+namespace qd {
+
+// ---------------------------------------------------------------------------------------------
+// controls: Oscillator::evalControl for every table row (src/oscillator.cpp:281-337)
+// ---------------------------------------------------------------------------------------------
+__device__ inline double bspline2(const DevSeg& g, int id, double t) {  // controlbasis.cpp:81-96
+  const double tc = g.tstart + g.dtknot * ((id + 1) - 1.5);
+  const double tau = (t - tc) / g.width;
+  if (tau < -1. / 2. || tau >= 1. / 2.) return 0.0;
+  if (tau < -1. / 6.) return 9. / 8. + 9. / 2. * tau + 9. / 2. * tau * tau;
+  if (tau < 1. / 6.) return 3. / 4. - 9. * tau * tau;
+  return 9. / 8. - 9. / 2. * tau + 9. / 2. * tau * tau;
+}
+
+__device__ inline void eval_control_dev(const DevCtlDesc& d, const double* __restrict__ params, int k, double t, double& p, double& q) {
+  const DevOsc o = d.oscs[k];
+  p = 0.0;
+  q = 0.0;
+  if (o.nparams > 0) {
+    const double* coeff = params + o.offset;
+    for (int bs = 0; bs < o.nseg; bs++) {
+      const DevSeg g = d.segs[o.seg_begin + bs];
+      if (g.tstart <= t && g.tstop >= t) {
+        double sp = 0.0, sq = 0.0;
+        for (int f = 0; f < o.ncar; f++) {
+          double b1 = 0.0, b2 = 0.0;
+          const double* cf = coeff + g.skip + f * g.nsplines * 2;
+          if (g.type == QD_CTRL_BSPLINE) {
+            for (int l = 0; l < g.nsplines; l++) {
+              if (d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) continue;
+              const double B = bspline2(g, l, t);
+              b1 += cf[l] * B;
+              b2 += cf[l + g.nsplines] * B;
+            }
+          } else {
+            const int id = (int)ceil((t - g.tstart) / g.dtknot - 0.5);
+            if (id >= 0 && id < g.nsplines) {
+              b1 = cf[id];
+              b2 = cf[id + g.nsplines];
+            }
+          }
+          const double om = d.carriers[o.car_begin + f];
+          const double co = cos(om * t), si = sin(om * t);
+          sp += co * b1 - si * b2;
+          sq += si * b1 + co * b2;
+        }
+        p = sp;
+        q = sq;
+        break;
+      }
+    }
+  }
+  for (int i = 0; i < o.npulse; i++) {
+    const double* pu = d.pulses + (size_t)(o.pulse_begin + i) * 3;
+    if (pu[0] <= t && t <= pu[1]) {
+      p = pu[2] / sqrt(2.0);
+      q = p;
+    }
+  }
+}
+
+__global__ void k_controls(const DevCtlDesc d, const double* __restrict__ params, const double* __restrict__ times,
+                           const double* __restrict__ hs, int nrows, double* __restrict__ table, int cs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = idx / d.Q, k = idx % d.Q;
+  if (row >= nrows) return;
+  const double t = times[row];
+  double p, q;
+  eval_control_dev(d, params, k, t, p, q);
+  double* r = table + (size_t)row * cs;
+  r[2 + k] = p;
+  r[2 + d.Q + k] = q;
+  if (k == 0) {
+    r[0] = hs[row];
+    r[1] = t;
+    for (int i = 0; i < d.npairs; i++) {  // MasterEq::assemble_RHS, mastereq.cpp:671-675
+      r[2 + 2 * d.Q + i] = cos(d.eta[i] * t);
+      r[2 + 2 * d.Q + d.npairs + i] = sin(d.eta[i] * t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// final-time objective and adjoint seed (one block per initial condition, runtime Q)
+// ---------------------------------------------------------------------------------------------
+template <bool LIND>
+__global__ void k_objective(const DevSys S, const DevTarget tg, const double* __restrict__ x, double* __restrict__ out4) {
+  __shared__ double red[4 * 16];
+  const int b = blockIdx.x, dim = S.dim;
+  const double* xs = x + (size_t)b * 2 * dim;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int it = threadIdx.x; it < dim; it += blockDim.x) {
+    const double2 xv = make_double2(xs[it], xs[dim + it]);
+    evalJ_part<LIND>(S, tg, b, it, xv, v[0], v[1]);
+    fidelity_part<LIND>(S, tg, b, it, xv, v[2], v[3]);
+  }
+  block_sum<4>(v, red);
+  if (threadIdx.x < 4) out4[b * 4 + threadIdx.x] = v[threadIdx.x];
+}
+
+template <bool LIND>
+__global__ void k_seed(const DevSys S, const DevTarget tg, const double* __restrict__ x, const double* __restrict__ rbib,
+                       double* __restrict__ xbar) {
+  const int b = blockIdx.x, dim = S.dim;
+  const double* xs = x + (size_t)b * 2 * dim;
+  double* xo = xbar + (size_t)b * 2 * dim;
+  const double rbar = rbib[2 * b], ibar = rbib[2 * b + 1];
+  for (int it = threadIdx.x; it < dim; it += blockDim.x) {
+    double2 xb = make_double2(0.0, 0.0);
+    evalJ_diff_elem<LIND>(S, tg, b, it, make_double2(xs[it], xs[dim + it]), xb, rbar, ibar);
+    xo[it] = xb.x;
+    xo[dim + it] = xb.y;
+  }
+}
+
+// coeff[nb][ncol] -> sum over the batch in a fixed order (deterministic gradient)
+__global__ void k_reduce_coeff(const double* __restrict__ coeff, int nb, int ncol, double* __restrict__ sum, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncol) return;
+  double s = accumulate ? sum[i] : 0.0;
+  for (int b = 0; b < nb; b++) s += coeff[(size_t)b * ncol + i];
+  sum[i] = s;
+}
+
+// grad[d] = sum_s B_d(t_s) * {Blt1bar | Blt2bar}(s) + energy-penalty terms
+// (Oscillator::evalControl_diff oscillator.cpp:339-381, BSpline2nd::derivative controlbasis.cpp:68-79,
+//  BSpline0::derivative :245-254, energyPenaltyIntegral_diff timestepper.cpp:458-480)
+__global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int cs, int nsub, int ee, const double* __restrict__ coeffsum,
+                       const double* __restrict__ etable, int nstep, double ebar, double* __restrict__ grad, int ndesign) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ndesign) return;
+  // locate (oscillator, segment, carrier, spline, part)
+  int k = 0;
+  while (k < d.Q - 1 && idx >= d.oscs[k].offset + d.oscs[k].nparams) k++;
+  const DevOsc o = d.oscs[k];
+  const int loc = idx - o.offset;
+  int gs = 0;
+  for (int bs = 0; bs < o.nseg; bs++) {
+    const DevSeg g = d.segs[o.seg_begin + bs];
+    if (loc >= g.skip && loc < g.skip + 2 * g.nsplines * o.ncar) gs = bs;
+  }
+  const DevSeg g = d.segs[o.seg_begin + gs];
+  const int r = loc - g.skip;
+  const int f = r / (2 * g.nsplines), l = (r % (2 * g.nsplines)) % g.nsplines, part = (r % (2 * g.nsplines)) / g.nsplines;
+  if (g.type == QD_CTRL_BSPLINE && d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) {
+    grad[idx] = 0.0;
+    return;
+  }
+  const double om = d.carriers[o.car_begin + f];
+  auto active = [&](double t) {  // this segment is the FIRST one containing t (oscillator.cpp:344-346 + break)
+    if (!(g.tstart <= t && g.tstop >= t)) return false;
+    for (int bs = 0; bs < gs; bs++) {
+      const DevSeg g2 = d.segs[o.seg_begin + bs];
+      if (g2.tstart <= t && g2.tstop >= t) return false;
+    }
+    return true;
+  };
+  auto basis = [&](double t) {
+    if (g.type == QD_CTRL_BSPLINE) return bspline2(g, l, t);
+    const int id = (int)ceil((t - g.tstart) / g.dtknot - 0.5);
+    return id == l ? 1.0 : 0.0;
+  };
+  double acc = 0.0;
+  for (int s = 0; s < nsub; s++) {
+    const double* row = table + (size_t)s * cs;
+    const double t = ee ? row[1] + row[0] : row[1];
+    if (!active(t)) continue;
+    const double B = basis(t);
+    if (B == 0.0) continue;
+    const double pbar = coeffsum[(size_t)s * 2 * d.Q + 2 * k], qbar = coeffsum[(size_t)s * 2 * d.Q + 2 * k + 1];
+    const double co = cos(om * t), si = sin(om * t);
+    acc += B * (part == 0 ? si * qbar + co * pbar : co * qbar - si * pbar);
+  }
+  if (ebar != 0.0) {
+    for (int n = 0; n < nstep; n++) {
+      const double* row = etable + (size_t)n * cs;
+      const double t = row[1];
+      if (!active(t)) continue;
+      const double B = basis(t);
+      if (B == 0.0) continue;
+      const double pbar = ebar / nstep * 2.0 * row[2 + k], qbar = ebar / nstep * 2.0 * row[2 + d.Q + k];
+      const double co = cos(om * t), si = sin(om * t);
+      acc += B * (part == 0 ? si * qbar + co * pbar : co * qbar - si * pbar);
+    }
+  }
+  grad[idx] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+bool config_supported(int Q, int ept) { return Q >= 1 && Q <= 5 && (ept == 1 || ept == 2 || ept == 4 || ept == 8); }
+
+LaunchCfg pick_config(const DevSys& S, int nb) {
+  // One workgroup per initial condition.  Few initial conditions (latency regime): spread one state
+  // over as many lanes as it has elements.  Many initial conditions (throughput regime): more
+  // elements per thread so that several workgroups share a CU.
+  LaunchCfg c;
+  const int dim = S.dim;
+  int ept = 1;
+  while ((dim + ept - 1) / ept > 1024 && ept < 8) ept *= 2;
+  if (nb >= 1024 && dim >= 1024 && ept < 4) ept = 4;
+  if (const char* ev = getenv("QD_EPT")) {  // tuning override
+    const int v = atoi(ev);
+    if ((v == 1 || v == 2 || v == 4 || v == 8) && (dim + v - 1) / v <= (v == 8 ? 512 : 1024)) ept = v;
+  }
+  int block = ((dim + ept - 1) / ept + 63) / 64 * 64;
+  c.ept = ept;
+  c.block = block;
+  c.lds = lds_bytes(dim, S.maxn, block, NRED);
+  return c;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// dispatch to the per-(Q, Lindblad) translation units (qd_inst.hip)
+// ---------------------------------------------------------------------------------------------
+#define QD_DECL(q, l)                                                                                                   \
+  hipError_t inst_forward_##q##_##l(const SweepArgs&, const LaunchCfg&, hipStream_t);                                    \
+  hipError_t inst_adjoint_##q##_##l(const SweepArgs&, const LaunchCfg&, hipStream_t);                                    \
+  hipError_t inst_apply_##q##_##l(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
+QD_DECL(1, 0) QD_DECL(2, 0) QD_DECL(3, 0) QD_DECL(4, 0) QD_DECL(5, 0)
+QD_DECL(1, 1) QD_DECL(2, 1) QD_DECL(3, 1) QD_DECL(4, 1) QD_DECL(5, 1)
+
+typedef hipError_t (*sweep_fn)(const SweepArgs&, const LaunchCfg&, hipStream_t);
+typedef hipError_t (*apply_fn)(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
+static const sweep_fn fwd_tab[2][5] = {{inst_forward_1_0, inst_forward_2_0, inst_forward_3_0, inst_forward_4_0, inst_forward_5_0},
+                                       {inst_forward_1_1, inst_forward_2_1, inst_forward_3_1, inst_forward_4_1, inst_forward_5_1}};
+static const sweep_fn adj_tab[2][5] = {{inst_adjoint_1_0, inst_adjoint_2_0, inst_adjoint_3_0, inst_adjoint_4_0, inst_adjoint_5_0},
+                                       {inst_adjoint_1_1, inst_adjoint_2_1, inst_adjoint_3_1, inst_adjoint_4_1, inst_adjoint_5_1}};
+static const apply_fn app_tab[2][5] = {{inst_apply_1_0, inst_apply_2_0, inst_apply_3_0, inst_apply_4_0, inst_apply_5_0},
+                                       {inst_apply_1_1, inst_apply_2_1, inst_apply_3_1, inst_apply_4_1, inst_apply_5_1}};
+
+hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  if (a.S.Q < 1 || a.S.Q > 5) return hipErrorInvalidValue;
+  return fwd_tab[a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
+}
+hipError_t launch_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  if (a.S.Q < 1 || a.S.Q > 5) return hipErrorInvalidValue;
+  return adj_tab[a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
+}
+hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
+                        const LaunchCfg& cfg, hipStream_t st) {
+  if (S.Q < 1 || S.Q > 5) return hipErrorInvalidValue;
+  return app_tab[S.lindblad ? 1 : 0][S.Q - 1](S, ctlrow, transpose, x, y, nb, cfg, st);
+}
+
+hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
+                           double* table, int cs, hipStream_t st) {
+  const int total = nrows * d.Q;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_controls, dim3((total + 127) / 128), dim3(128), 0, st, d, params, times, hs, nrows, table, cs);
+  return hipGetLastError();
+}
+
+hipError_t launch_objective(const DevSys& S, const DevTarget& tg, const double* x, int nb, double* out4, hipStream_t st) {
+  if (S.lindblad) hipLaunchKernelGGL(k_objective<true>, dim3(nb), dim3(256), 0, st, S, tg, x, out4);
+  else hipLaunchKernelGGL(k_objective<false>, dim3(nb), dim3(256), 0, st, S, tg, x, out4);
+  return hipGetLastError();
+}
+
+hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, const double* rbar_ibar, int nb, double* xbar,
+                       hipStream_t st) {
+  if (S.lindblad) hipLaunchKernelGGL(k_seed<true>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
+  else hipLaunchKernelGGL(k_seed<false>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_coeff, dim3((ncol + 255) / 256), dim3(256), 0, st, coeff, nb, ncol, sum, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum, const double* etable,
+                       int nstep, double ebar, double* grad, int ndesign, hipStream_t st) {
+  if (ndesign == 0) return hipSuccess;
+  const int ee = nsub < 0;  // negative nsub flags the explicit-Euler gradient time (t_stop)
+  const int ns = ee ? -nsub : nsub;
+  hipLaunchKernelGGL(k_grad, dim3((ndesign + 63) / 64), dim3(64), 0, st, d, table, cs, ns, ee, coeffsum, etable, nstep, ebar, grad,
+                     ndesign);
+  return hipGetLastError();
+}
+
+}  // namespace qd

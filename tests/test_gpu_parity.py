@@ -1,0 +1,206 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's golden files.
+
+Tolerances: the operator applications are compared at 1e-13 relative (pure fp64 stencils, only the
+summation order and sqrt(a*b) vs sqrt(a)*sqrt(b) differ).  Whole sweeps are compared at the level the
+linear solves are converged to (abstol 1e-10 per step, the reference's own setting): states 1e-8
+absolute, objective parts and gradients 1e-7 relative (the reference harness tolerance), and the
+north-star figure of 1e-8 relative on the gradient norm where noted.
+"""
+import numpy as np
+import pytest
+
+from helpers import REF_ATOL, REF_RTOL, golden_grad, golden_history, golden_rows, load_case, synthetic_spec
+from oracle.oracle import Oracle
+from quandary_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+OBJ_KEYS = ["objective", "fidelity", "cost", "regul", "penalty", "penalty_dpdm", "penalty_energy", "penalty_variation"]
+
+SHAPES = [
+    pytest.param(dict(nlevels=[2, 2], lindblad=False), id="C1-2x2-schroedinger"),
+    pytest.param(dict(nlevels=[2, 2, 2], lindblad=True), id="C2-2x2x2-lindblad"),
+    pytest.param(dict(nlevels=[2, 2, 2, 2], lindblad=False), id="C3-2^4-schroedinger"),
+    pytest.param(dict(nlevels=[3, 20], lindblad=True, target="pure", objective="Jmeasure"), id="C4-3x20-lindblad"),
+    pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True), id="C5-2^5-lindblad"),
+    pytest.param(dict(nlevels=[3, 4], lindblad=True, jkl=0.01, detuned=True, target="pure", objective="Jfrobenius"), id="3x4-lindblad-Jkl"),
+    pytest.param(dict(nlevels=[2, 3, 2], lindblad=False, jkl=0.01, detuned=True, target="pure", objective="Jmeasure"), id="2x3x2-schroedinger-Jkl"),
+    pytest.param(dict(nlevels=[4], lindblad=True, nessential=[3], target="pure", objective="Jtrace"), id="4-lindblad-guard"),
+    pytest.param(dict(nlevels=[3, 3], lindblad=False, nessential=[2, 2], jkl=0.005, detuned=True), id="3x3-schroedinger-guard-gate"),
+]
+
+
+def _pair(kw, **extra):
+    sp = synthetic_spec(**{**kw, **extra})
+    return sp, capi.Handle(sp), Oracle(sp)
+
+
+@pytest.mark.parametrize("kw", SHAPES)
+def test_apply_rhs_and_transpose(kw):
+    sp, h, orc = _pair(kw)
+    rng = np.random.default_rng(1234)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    x = rng.standard_normal((3, 2 * h.dim))
+    t = 0.37 * sp.time.ntime * sp.time.dt
+    for tr in (False, True):
+        y = h.apply_rhs(t, x, transpose=tr)
+        yo = orc.apply_rhs(t, x, transpose=tr)
+        np.testing.assert_allclose(y, yo, rtol=1e-13, atol=1e-13 * np.abs(yo).max())
+    # <Mx, y> = <x, M^T y>
+    y = rng.standard_normal((3, 2 * h.dim))
+    lhs = np.sum(h.apply_rhs(t, x) * y)
+    rhs = np.sum(x * h.apply_rhs(t, y, transpose=True))
+    assert lhs == pytest.approx(rhs, rel=1e-12)
+    h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", SHAPES[:3])
+def test_eval_controls(kw):
+    sp, h, orc = _pair(kw)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    T = sp.time.ntime * sp.time.dt
+    times = np.linspace(0.0, T, 41)
+    np.testing.assert_allclose(h.eval_controls(times), orc.eval_controls(times), rtol=1e-13, atol=1e-16)
+    h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", SHAPES)
+@pytest.mark.parametrize("penalties", [False, True])
+def test_objective_and_gradient_vs_oracle(kw, penalties):
+    if kw["nlevels"] == [3, 20]:
+        kw = {**kw, "init": "basis, 0"}  # 9 initial conditions instead of 3600 (oracle time)
+    sp, h, orc = _pair(kw, ntime=40, penalties=penalties)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    val2 = opt.evalF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15), k
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("stepper", ["IMR4", "IMR8", "EE"])
+def test_other_steppers(stepper):
+    sp, h, orc = _pair(dict(nlevels=[3, 2], lindblad=True, jkl=0.01, detuned=True), ntime=12, stepper=stepper, penalties=True)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
+def test_forward_states_and_trajectory():
+    sp, h, orc = _pair(dict(nlevels=[2, 2, 2], lindblad=True), ntime=30)
+    opt = capi.Optim(h, sp)
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(opt.ninit_local)])
+    h.set_params(sp.params0)
+    res = h.forward(x0, store_trajectory=True)
+    _, traj, fin = orc.evalF(sp.params0, out_freq=10, want_final=True)
+    np.testing.assert_allclose(res["final_states"], fin, rtol=0, atol=1e-9)
+    for j, n in enumerate((0, 10, 20, 30)):
+        np.testing.assert_allclose(h.get_state(n, x0.shape[0]), traj[:, j, :], rtol=0, atol=1e-9)
+    opt.close(); h.close(); orc.close()
+
+
+# ---- the reference's own golden regression outputs, through the C ABI --------------------------------
+@pytest.mark.parametrize("case", ["AxC", "AxC_initDiag0", "AxC_initEnsemble", "AxC_initFile", "pipulse"])
+def test_golden_forward(case):
+    sp = load_case(case)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val = opt.evalF(sp.params0)
+    hist = golden_history(case)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(hist[k], rel=REF_RTOL, abs=REF_ATOL), k
+    opt.close(); h.close()
+
+
+def test_golden_axc_trajectory():
+    case = "AxC"
+    sp = load_case(case)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    x0, _ = opt.initial_state(0)
+    h.set_params(sp.params0)
+    h.forward(x0[None, :], store_trajectory=True)
+    for part, name in enumerate(("rho_Re.iinit0000.dat", "rho_Im.iinit0000.dat")):
+        rows, _, d = golden_rows(case, name)
+        for r, drow in zip(rows, d):
+            st = h.get_state(r * sp.output_frequency, 1)[0]
+            np.testing.assert_allclose(st[part * h.dim:(part + 1) * h.dim], drow, rtol=REF_RTOL, atol=2e-11)
+    opt.close(); h.close()
+
+
+@pytest.mark.parametrize("case,grad_rtol", [("AxC_grad_initBasis0", 1e-8), ("AxC_grad_schroedinger", 1e-8), ("xgate_sparsemat", 1e-7)])
+def test_golden_gradient(case, grad_rtol):
+    sp = load_case(case)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    hist = golden_history(case)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(hist[k], rel=REF_RTOL, abs=REF_ATOL), k
+    gg = golden_grad(case)
+    assert np.linalg.norm(g) == pytest.approx(hist["gnorm"], rel=REF_RTOL)
+    assert np.linalg.norm(g - gg) / np.linalg.norm(gg) < grad_rtol
+    opt.close(); h.close()
+
+
+@pytest.mark.parametrize("case", ["cnot", "xgate", "state-to-state_spline0"])
+def test_golden_optimization_iteration0(case):
+    sp = load_case(case)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    x0 = np.clip(sp.params0, -sp.bounds, sp.bounds)
+    val = opt.evalF(x0)
+    hist = golden_history(case, 0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(hist[k], rel=REF_RTOL, abs=REF_ATOL), k
+    opt.close(); h.close()
+
+
+def test_two_rank_sharding_matches_single_rank():
+    """Two shards on one GPU: partial sums and gradients add up to the single-rank result."""
+    sp = synthetic_spec([2, 2], lindblad=True, ntime=25, penalties=True)
+    h = capi.Handle(sp)
+    full = capi.Optim(h, sp)
+    val, g = full.evalGradF(sp.params0)
+    full.close()
+    parts, grads = [], []
+    shards = [capi.Optim(h, sp, rank=r, nranks=2) for r in range(2)]
+    # forward of both shards, then the global sums, then both adjoints (src/optimproblem.cpp:454-527)
+    hs = [capi.Handle(sp) for _ in range(2)]
+    shards = [capi.Optim(hs[r], sp, rank=r, nranks=2) for r in range(2)]
+    parts = [s.forward_local(sp.params0, store_trajectory=True) for s in shards]
+    sums = parts[0] + parts[1]
+    v2 = shards[0].finalize(sp.params0, sums)
+    grads = [s.adjoint_local(sp.params0, sums) for s in shards]
+    for k in OBJ_KEYS:
+        assert v2[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15), k
+    np.testing.assert_allclose(grads[0] + grads[1], g, rtol=1e-10, atol=1e-14)
+    for s in shards:
+        s.close()
+    for x in hs:
+        x.close()
+    h.close()
+
+
+def test_error_paths():
+    sp = synthetic_spec([2, 2], lindblad=False, ntime=5)
+    h = capi.Handle(sp)
+    with pytest.raises(capi.QuandaryAmdError):
+        h.set_params(np.zeros(h.ndesign + 1))
+    with pytest.raises(capi.QuandaryAmdError):
+        h.adjoint(np.zeros((1, 2 * h.dim)), np.zeros((1, 3)))  # no stored trajectory
+    with pytest.raises(capi.QuandaryAmdError):
+        h.apply_rhs(1e9, np.zeros((1, 2 * h.dim)))  # t > Tfinal
+    with pytest.raises(capi.QuandaryAmdError):
+        capi.Optim(h, sp, rank=0, nranks=3)  # 3 does not divide 4
+    h.close()
