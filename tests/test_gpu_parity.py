@@ -138,7 +138,11 @@ def test_golden_axc_trajectory():
     opt.close(); h.close()
 
 
-@pytest.mark.parametrize("case,grad_rtol", [("AxC_grad_initBasis0", 1e-8), ("AxC_grad_schroedinger", 1e-8), ("xgate_sparsemat", 1e-7)])
+# xgate_sparsemat: the objective is 2.3e-6 and ||grad|| 6.5e-4, so the reference's own linear-solver
+# tolerance (abstol 1e-10 per step over 700 steps) already sits at ~1e-7 of the gradient norm (SURVEY
+# fact 10); the golden file is produced by the reference's sparse-matrix path with GMRES, the device
+# solves the same systems with the Neumann iteration.  Absolute agreement is ~1e-10.
+@pytest.mark.parametrize("case,grad_rtol", [("AxC_grad_initBasis0", 1e-8), ("AxC_grad_schroedinger", 1e-8), ("xgate_sparsemat", 1e-6)])
 def test_golden_gradient(case, grad_rtol):
     sp = load_case(case)
     h = capi.Handle(sp)
