@@ -55,6 +55,9 @@ def load():
     lib.qo_optim_target_state.argtypes = [vp, C.c_int, capi.c_dp]
     lib.qo_optim_evalF.argtypes = [vp, capi.c_dp, C.POINTER(capi.qd_objective_value), C.c_int, capi.c_dp, capi.c_dp]
     lib.qo_optim_evalGradF.argtypes = [vp, capi.c_dp, C.POINTER(capi.qd_objective_value), capi.c_dp]
+    lib.qo_optim_forward_local.argtypes = [vp, capi.c_dp, C.c_int, C.c_int, capi.c_dp, capi.c_dp]
+    lib.qo_optim_finalize.argtypes = [vp, capi.c_dp, capi.c_dp, C.POINTER(capi.qd_objective_value)]
+    lib.qo_optim_adjoint_local.argtypes = [vp, capi.c_dp, C.c_int, C.c_int, capi.c_dp, capi.c_dp]
     lib.qo_expected_energy.argtypes = [vp, C.c_int, capi.c_dp]
     lib.qo_expected_energy.restype = C.c_double
     lib.qo_population.argtypes = [vp, C.c_int, capi.c_dp, capi.c_dp]
@@ -183,6 +186,30 @@ class Oracle:
         g = np.zeros(max(self.ndesign, 1))
         _check(self.lib, self.lib.qo_optim_evalGradF(self._optim(), dptr(alpha), C.byref(val), dptr(g)), "qo_optim_evalGradF")
         return val.as_dict(), g[: self.ndesign]
+
+    # sharded API (one comm_init rank of the reference); the caller does the all-reduces
+    def forward_local(self, alpha, rank, nranks, want_final=False):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        partial = np.zeros(capi.NSUMS)
+        fin = np.zeros((self.ninit // nranks, 2 * self.dim)) if want_final else None
+        _check(self.lib, self.lib.qo_optim_forward_local(self._optim(), dptr(alpha), int(rank), int(nranks), dptr(partial), dptr(fin)),
+               "qo_optim_forward_local")
+        return (partial, fin) if want_final else partial
+
+    def finalize(self, alpha, sums):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        val = capi.qd_objective_value()
+        _check(self.lib, self.lib.qo_optim_finalize(self._optim(), dptr(alpha), dptr(sums), C.byref(val)), "qo_optim_finalize")
+        return val.as_dict()
+
+    def adjoint_local(self, alpha, rank, nranks, sums):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        g = np.zeros(max(self.ndesign, 1))
+        _check(self.lib, self.lib.qo_optim_adjoint_local(self._optim(), dptr(alpha), int(rank), int(nranks), dptr(sums), dptr(g)),
+               "qo_optim_adjoint_local")
+        return g[: self.ndesign]
 
     def expected_energy(self, k, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

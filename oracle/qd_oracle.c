@@ -1859,6 +1859,90 @@ int qo_optim_evalGradF(qo_optim* o, const double* alpha, qd_objective_value* val
   return rc;
 }
 
+
+/* Sharded variants used by the multi-process tests and the parallel CPU baseline: the initial
+ * conditions [rank*nl, (rank+1)*nl) are processed exactly as one comm_init rank of the reference
+ * does (src/optimproblem.cpp:245-298, :386-527); the caller plays MPI_Allreduce. */
+int qo_optim_forward_local(qo_optim* o, const double* alpha, int rank, int nranks, double* partial, double* finals) {
+  qo_ctx* c = o->c;
+  const int n2 = 2 * c->s.dim;
+  if (o->ninit % nranks) return fail("nranks must divide ninit");
+  const int nl = o->ninit / nranks, first = rank * nl;
+  if (qo_set_params(c, alpha, c->ndesign)) return -1;
+  osweep w;
+  sweep_init(o, &w);
+  for (int i = 0; i < QD_NSUMS; i++) partial[i] = 0.0;
+  double* x = (double*)malloc(sizeof(double) * n2);
+  int rc = 0;
+  for (int il = 0; il < nl && !rc; il++) {
+    const int ii = first + il;
+    prepare_initial_state(&c->s, &o->tg, ii, x);
+    prepare_target_state(&c->s, &o->tg, x);
+    rc = solve_ode(c, &w, x);
+    if (finals) memcpy(finals + (size_t)il * n2, x, sizeof(double) * n2);
+    partial[QD_SUM_PENALTY] += o->weights[ii] * o->ob.penalty.gamma_penalty * w.penalty_integral;
+    partial[QD_SUM_DPDM] += o->weights[ii] * o->ob.penalty.gamma_penalty_dpdm * w.penalty_dpdm;
+    partial[QD_SUM_ENERGY] += o->weights[ii] * o->ob.penalty.gamma_penalty_energy * w.energy_penalty;
+    double jr, ji, fr, fi;
+    eval_J(&c->s, &o->tg, x, &jr, &ji);
+    partial[QD_SUM_COST_RE] += o->weights[ii] * jr;
+    partial[QD_SUM_COST_IM] += o->weights[ii] * ji;
+    hs_overlap(&c->s, &o->tg, x, 0, &fr, &fi);
+    partial[QD_SUM_FID_RE] += 1. / o->ninit * fr;
+    partial[QD_SUM_FID_IM] += 1. / o->ninit * fi;
+  }
+  free(x);
+  return rc;
+}
+
+int qo_optim_finalize(qo_optim* o, const double* alpha, const double* sums, qd_objective_value* val) {
+  if (qo_set_params(o->c, alpha, o->c->ndesign)) return -1;
+  finish_objective(o, alpha, sums, val);
+  return 0;
+}
+
+/* Adjoint of the local shard seeded from the GLOBAL sums; the primal is re-propagated first (this
+ * restatement keeps no state between the two calls). */
+int qo_optim_adjoint_local(qo_optim* o, const double* alpha, int rank, int nranks, const double* sums, double* G) {
+  qo_ctx* c = o->c;
+  const int n2 = 2 * c->s.dim, nd = c->ndesign;
+  if (o->ninit % nranks) return fail("nranks must divide ninit");
+  const int nl = o->ninit / nranks, first = rank * nl;
+  if (qo_set_params(c, alpha, nd)) return -1;
+  osweep w;
+  sweep_init(o, &w);
+  const qd_penalty* pen = &o->ob.penalty;
+  for (int i = 0; i < nd; i++) G[i] = 0.0;
+  if (rank == 0) {
+    for (int i = 0; i < nd; i++) G[i] = o->ob.gamma_tik * (alpha[i] - (o->alpha0 ? o->alpha0[i] : 0.0));
+    control_variation_diff(c, G, 0.5 * o->ob.gamma_penalty_variation);
+  }
+  double* x = (double*)malloc(sizeof(double) * n2);
+  double* xbar = (double*)malloc(sizeof(double) * n2);
+  double* redgrad = (double*)malloc(sizeof(double) * (nd > 0 ? nd : 1));
+  if (c->s.lindblad) w.store = (double*)malloc(sizeof(double) * n2 * (size_t)(c->ntime + 1));
+  int rc = 0;
+  for (int il = 0; il < nl && !rc; il++) {
+    const int ii = first + il;
+    prepare_initial_state(&c->s, &o->tg, ii, x);
+    prepare_target_state(&c->s, &o->tg, x);
+    rc = solve_ode(c, &w, x);
+    memset(xbar, 0, sizeof(double) * n2);
+    double rb, ib;
+    finalize_J_diff(&c->s, &o->tg, sums[QD_SUM_COST_RE], sums[QD_SUM_COST_IM], &rb, &ib);
+    eval_J_diff(&c->s, &o->tg, x, xbar, o->weights[ii] * rb, o->weights[ii] * ib);
+    if (!rc)
+      rc = solve_adjoint_ode(c, &w, xbar, x, o->weights[ii] * pen->gamma_penalty, o->weights[ii] * pen->gamma_penalty_dpdm,
+                             o->weights[ii] * pen->gamma_penalty_energy, redgrad);
+    for (int i = 0; i < nd; i++) G[i] += redgrad[i];
+  }
+  free(x);
+  free(xbar);
+  free(redgrad);
+  free(w.store);
+  return rc;
+}
+
 /* Observables for the trajectory output files (next-row scope, used by the file-level goldens):
  * Oscillator::expectedEnergy (src/oscillator.cpp:430-470) and Oscillator::population (:518-566). */
 double qo_expected_energy(const qo_ctx* c, int k, const double* x) {

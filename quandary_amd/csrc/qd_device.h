@@ -1,5 +1,24 @@
-// qd_device.h — device templates of the sweep kernels (included by qd_inst.hip and qd_kernels.hip).
-// See qd_kernels.hip for the design notes and the reference citations.
+// qd_device.h — device templates of the persistent sweep kernels (included by qd_inst.hip and
+// qd_kernels.hip).  gfx950 / CDNA4 only.
+//
+// One workgroup owns one initial condition for the WHOLE time loop.  Each thread owns EPT elements of
+// the vectorised state in registers; the vector that is being stencil-read lives in LDS as
+// interleaved complex numbers (one ds_read_b128 per neighbour).  Two stencil implementations share
+// the sweep skeleton:
+//   * general: runtime level counts, branch-free — validity of a neighbour is folded into
+//     per-oscillator coefficient tables in LDS (zero where the reference's `if` fails) and the
+//     neighbour index is clamped into the vector;
+//   * qubit (all n_k == 2): digits are bits of the storage index, neighbours are `it ^ bit`, every
+//     ladder coefficient is +-1, no tables at all.
+// Kernel variants (VAR) fix elements/thread, the maximal block size (= register budget through
+// __launch_bounds__), LDS double buffering and whether the block is a single wave (no barriers).
+//
+// Reference semantics restated here (paths relative to the reference repository):
+//   stencil            include/mastereq.hpp:316-912, src/mastereq.cpp:1464-1709
+//   gradient coeffs    include/mastereq.hpp:553-604, src/mastereq.cpp:970-1276
+//   IMR fwd / bwd      src/timestepper.cpp:584-694, Neumann :697-727
+//   time loops         src/timestepper.cpp:96-253, penalties :256-480
+//   objective / seeds  src/optimtarget.cpp:343-447, :712-897
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,26 +27,61 @@
 namespace qd {
 
 // ---------------------------------------------------------------------------------------------
-// small device helpers
+// kernel variants
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int digit(uint64_t d, int k) { return (int)((d >> (8 * k)) & 0xffull); }
+template <int VAR> struct Variant;
+template <> struct Variant<0> { static constexpr int EPT = 1, MAXB = 64;   static constexpr bool DBUF = false, ONEWAVE = true;  };
+template <> struct Variant<1> { static constexpr int EPT = 1, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false; };
+template <> struct Variant<2> { static constexpr int EPT = 4, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false; };
+template <> struct Variant<3> { static constexpr int EPT = 4, MAXB = 1024; static constexpr bool DBUF = false, ONEWAVE = false; };
+template <> struct Variant<4> { static constexpr int EPT = 8, MAXB = 512;  static constexpr bool DBUF = false, ONEWAVE = false; };
+template <> struct Variant<5> { static constexpr int EPT = 1, MAXB = 1024; static constexpr bool DBUF = true,  ONEWAVE = false; };
+constexpr int NVARIANTS = 6;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+constexpr int NRED = 16;  // max values reduced at once (2*QD_MAX_OSC)
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(h2, l2);
 }
 
-// Block-wide sum of NV values; every thread returns the same bits (fixed summation order), so
-// convergence decisions taken on the result are uniform.  Contains ONE __syncthreads(); the caller
-// guarantees another barrier before the next call re-writes `red`.
-template <int NV>
+// Sum over the 64 lanes of a wave; the result is wave-uniform (same bits in every lane).
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8  -> every lane holds a total of its row of 16
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+template <bool ONEWAVE>
+__device__ __forceinline__ void team_sync() {
+  if (!ONEWAVE) __syncthreads();
+}
+
+// Block-wide sum of NV values; every thread returns the same bits, so decisions taken on the result
+// are uniform.  Multi-wave blocks: contains ONE __syncthreads(); `red` has two slots used
+// alternately by the caller so that no second barrier is needed between consecutive reductions.
+template <int NV, bool ONEWAVE>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-  for (int i = 0; i < NV; i++) {
-    v[i] = wave_sum(v[i]);
-    if (lane == 0) red[i * nw + wave] = v[i];
+  for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
+  if (ONEWAVE) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) red[i * nw + wave] = v[i];
   }
   __syncthreads();
 #pragma unroll
@@ -38,54 +92,9 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red) {
   }
 }
 
-// Per-thread description of one owned element of the vectorised state.
-struct Elem {
-  int it;         // storage index, or -1 when the slot is beyond dim
-  uint64_t dig;   // bra digits i_k, 8 bits each (oscillator 0 slowest in the Hilbert index)
-  uint64_t digp;  // ket digits i_k' (Lindblad), 0 for Schroedinger
-  double dw;      // Delta = h(I) - h(I')    (mastereq.hpp:316-403)
-  double dd;      // d = L2 + L1diag          (mastereq.hpp:339-353, :416-433)
-};
-
-template <int Q, bool LIND>
-__device__ __forceinline__ void elem_init(const DevSys& S, int it, Elem& e) {
-  e.it = it;
-  e.dig = 0;
-  e.digp = 0;
-  e.dw = 0.0;
-  e.dd = 0.0;
-  if (it < 0) return;
-  const int I = LIND ? it % S.N : it;
-  const int Ip = LIND ? it / S.N : 0;
-  int ia[Q], ipa[Q];
-#pragma unroll
-  for (int k = 0; k < Q; k++) {
-    ia[k] = (I / S.post[k]) % S.n[k];
-    ipa[k] = LIND ? (Ip / S.post[k]) % S.n[k] : 0;
-    e.dig |= (uint64_t)ia[k] << (8 * k);
-    e.digp |= (uint64_t)ipa[k] << (8 * k);
-  }
-  double hd = 0.0, hdp = 0.0, dd = 0.0;
-  int pair = 0;
-#pragma unroll
-  for (int k = 0; k < Q; k++) {
-    hd += S.detune[k] * ia[k] - S.xi[k] / 2.0 * ia[k] * (ia[k] - 1);
-    if (LIND) {
-      hdp += S.detune[k] * ipa[k] - S.xi[k] / 2.0 * ipa[k] * (ipa[k] - 1);
-      dd += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
-    }
-#pragma unroll
-    for (int l = k + 1; l < Q; l++) {
-      hd -= S.xikl[pair] * ia[k] * ia[l];
-      if (LIND) hdp -= S.xikl[pair] * ipa[k] * ipa[l];
-      pair++;
-    }
-  }
-  e.dw = hd - hdp;
-  e.dd = dd;
-}
-
-// Controls of one sub-step, wave-uniform (scalar loads from the table row).
+// ---------------------------------------------------------------------------------------------
+// step controls (wave-uniform, streamed from the table by scalar loads, prefetched one step ahead)
+// ---------------------------------------------------------------------------------------------
 template <int Q>
 struct StepC {
   double h, p[Q], q[Q];
@@ -93,7 +102,7 @@ struct StepC {
 };
 
 template <int Q>
-__device__ __forceinline__ void load_step(const double* __restrict__ row, StepC<Q>& c) {
+__device__ __forceinline__ void load_step(const double* __restrict__ row, StepC<Q>& c, bool with_pairs) {
   constexpr int NP = Q * (Q - 1) / 2;
   c.h = row[0];
 #pragma unroll
@@ -101,204 +110,376 @@ __device__ __forceinline__ void load_step(const double* __restrict__ row, StepC<
     c.p[k] = row[2 + k];
     c.q[k] = row[2 + Q + k];
   }
+  if (with_pairs) {
 #pragma unroll
-  for (int k = 0; k < NP; k++) {
-    c.cs[k] = row[2 + 2 * Q + k];
-    c.sn[k] = row[2 + 2 * Q + NP + k];
-  }
-}
-
-// Ladder-operator neighbour sums of oscillator k at one element (control(), mastereq.hpp:818-912):
-//   U1 = sqrt(i+1) x(it+post), U2 = sqrt(i'+1) x(it+N post), D1 = sqrt(i) x(it-post), D2 = sqrt(i') x(it-N post)
-//   A = U1 + U2 - D1 - D2,  B = U1 - U2 + D1 - D2
-// so that the control part of y = M x is  y_re += q A_re + p B_im,  y_im += q A_im - p B_re, and
-// dRHSdp_getcoeffs (mastereq.hpp:553-604) is  res_p = (B_im, -B_re), res_q = (A_re, A_im).
-// Invalid neighbours read the element itself with a zero coefficient (no divergence).
-template <bool LIND>
-__device__ __forceinline__ void ladder_AB(const DevSys& S, int k, const Elem& e, const double2* __restrict__ sx,
-                                          const double* __restrict__ ssq, double2& A, double2& B) {
-  const int a = digit(e.dig, k), n = S.n[k], st = S.post[k], it = e.it;
-  const bool up = a < n - 1, dn = a > 0;
-  const double su = up ? ssq[a + 1] : 0.0, sd = dn ? ssq[a] : 0.0;
-  const double2 xu = sx[up ? it + st : it], xd = sx[dn ? it - st : it];
-  double er = su * xu.x, ei = su * xu.y;  // U1
-  double fr = -sd * xd.x, fi = -sd * xd.y;  // -D1
-  if (LIND) {
-    const int ap = digit(e.digp, k), stp = S.N * st;
-    const bool upp = ap < n - 1, dnp = ap > 0;
-    const double sup = upp ? ssq[ap + 1] : 0.0, sdp = dnp ? ssq[ap] : 0.0;
-    const double2 xup = sx[upp ? it + stp : it], xdp = sx[dnp ? it - stp : it];
-    er = fma(-sdp, xdp.x, er);  // U1 - D2
-    ei = fma(-sdp, xdp.y, ei);
-    fr = fma(sup, xup.x, fr);  // U2 - D1
-    fi = fma(sup, xup.y, fi);
-  }
-  A.x = er + fr;
-  A.y = ei + fi;
-  B.x = er - fr;
-  B.y = ei - fi;
-}
-
-// y = M x (TRANS=false) or M^T x (TRANS=true) at one element.  The Hamiltonian part of the real
-// 2dim x 2dim operator is antisymmetric (M_H^T = -M_H: compare control/control_T, Jkl_coupling/
-// Jkl_coupling_T and the drift signs at mastereq.cpp:1541-1542 vs :1665-1666), the dissipator
-// diagonal is symmetric, and the T1 off-diagonal term moves to the mirrored neighbour
-// (L1decay / L1decay_T, mastereq.hpp:758-797).
-template <int Q, bool LIND, bool TRANS>
-__device__ __forceinline__ double2 apply_elem(const DevSys& S, const Elem& e, const double2* __restrict__ sx,
-                                              const double* __restrict__ ssq, const StepC<Q>& c, const double2 xs) {
-  // Hamiltonian part, accumulated for the forward operator
-  double hr = e.dw * xs.y, hi = -e.dw * xs.x;
-#pragma unroll
-  for (int k = 0; k < Q; k++) {
-    double2 A, B;
-    ladder_AB<LIND>(S, k, e, sx, ssq, A, B);
-    hr = fma(c.q[k], A.x, fma(c.p[k], B.y, hr));
-    hi = fma(c.q[k], A.y, fma(-c.p[k], B.x, hi));
-  }
-  // dipole-dipole coupling (Jkl_coupling, mastereq.hpp:632-675):
-  //   T1 = sqrt(i_k (i_l+1)) x(it-post_k+post_l), T2 = sqrt(i_l (i_k+1)) x(it+post_k-post_l), T3/T4 the ket analogues
-  //   y += J [ sin (T1 - T2 + T3 - T4) - i cos (T1 + T2 - T3 - T4) ]
-  {
-    int pair = 0;
-#pragma unroll
-    for (int k = 0; k < Q; k++) {
-#pragma unroll
-      for (int l = k + 1; l < Q; l++, pair++) {
-        const double Jkl = S.J[pair];
-        if (!(fabs(Jkl) > 1e-10)) continue;
-        const int a = digit(e.dig, k), b = digit(e.dig, l), it = e.it;
-        const int sk = S.post[k], sl = S.post[l];
-        const bool v1 = a > 0 && b < S.n[l] - 1, v2 = a < S.n[k] - 1 && b > 0;
-        const double s1 = v1 ? ssq[a] * ssq[b + 1] : 0.0, s2 = v2 ? ssq[b] * ssq[a + 1] : 0.0;
-        const double2 x1 = sx[v1 ? it - sk + sl : it], x2 = sx[v2 ? it + sk - sl : it];
-        double ar = s1 * x1.x - s2 * x2.x, ai = s1 * x1.y - s2 * x2.y;  // T1 - T2
-        double br = s1 * x1.x + s2 * x2.x, bi = s1 * x1.y + s2 * x2.y;  // T1 + T2
-        if (LIND) {
-          const int ap = digit(e.digp, k), bp = digit(e.digp, l);
-          const int skp = S.N * sk, slp = S.N * sl;
-          const bool v3 = ap > 0 && bp < S.n[l] - 1, v4 = ap < S.n[k] - 1 && bp > 0;
-          const double s3 = v3 ? ssq[ap] * ssq[bp + 1] : 0.0, s4 = v4 ? ssq[bp] * ssq[ap + 1] : 0.0;
-          const double2 x3 = sx[v3 ? it - skp + slp : it], x4 = sx[v4 ? it + skp - slp : it];
-          ar += s3 * x3.x - s4 * x4.x;
-          ai += s3 * x3.y - s4 * x4.y;
-          br -= s3 * x3.x + s4 * x4.x;
-          bi -= s3 * x3.y + s4 * x4.y;
-        }
-        const double co = c.cs[pair], si = c.sn[pair];
-        hr += Jkl * (si * ar + co * bi);
-        hi += Jkl * (si * ai - co * br);
-      }
+    for (int k = 0; k < NP; k++) {
+      c.cs[k] = row[2 + 2 * Q + k];
+      c.sn[k] = row[2 + 2 * Q + NP + k];
     }
   }
-  double yr = TRANS ? -hr : hr, yi = TRANS ? -hi : hi;
-  if (LIND) {
-    yr = fma(e.dd, xs.x, yr);
-    yi = fma(e.dd, xs.y, yi);
-#pragma unroll
-    for (int k = 0; k < Q; k++) {
-      const double g1 = S.g1[k];
-      if (!(fabs(g1) > 1e-12)) continue;
-      const int a = digit(e.dig, k), ap = digit(e.digp, k), n = S.n[k], st = S.post[k] * (S.N + 1);
-      if (!TRANS) {
-        const bool v = a < n - 1 && ap < n - 1;
-        const double l1 = v ? g1 * ssq[a + 1] * ssq[ap + 1] : 0.0;
-        const double2 xn = sx[v ? e.it + st : e.it];
-        yr = fma(l1, xn.x, yr);
-        yi = fma(l1, xn.y, yi);
-      } else {
-        const bool v = a > 0 && ap > 0;
-        const double l1 = v ? g1 * ssq[a] * ssq[ap] : 0.0;
-        const double2 xn = sx[v ? e.it - st : e.it];
-        yr = fma(l1, xn.x, yr);
-        yi = fma(l1, xn.y, yi);
-      }
-    }
-  }
-  return make_double2(yr, yi);
 }
 
-// LDS carve-up shared by all sweep kernels
+// ---------------------------------------------------------------------------------------------
+// LDS layout
+// ---------------------------------------------------------------------------------------------
 struct Lds {
-  double2* sx;
-  double* ssq;
-  double* red;
+  double2* buf[2];  // state exchange vector(s); buf[1] == buf[0] without double buffering
+  double* tup;      // general stencil: tup[ofs_k + a] = (a < n_k-1) ? sqrt(a+1) : 0
+  double* tdn;      //                  tdn[ofs_k + a] = sqrt(a)
+  double* red;      // reduction scratch, two slots of NRED * nwaves
 };
-__device__ __forceinline__ Lds carve(unsigned char* smem, int dim, int maxn) {
+__host__ __device__ inline int table_len(const DevSys& S) {
+  int t = 0;
+  for (int k = 0; k < S.Q; k++) t += S.n[k];
+  return (t + 1) & ~1;
+}
+__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf) {
   Lds l;
-  l.sx = reinterpret_cast<double2*>(smem);
-  l.ssq = reinterpret_cast<double*>(l.sx + dim);
-  l.red = l.ssq + ((maxn + 2 + 1) & ~1);
+  l.buf[0] = reinterpret_cast<double2*>(smem);
+  l.buf[1] = dbuf ? l.buf[0] + S.dim : l.buf[0];
+  const int tl = table_len(S);
+  l.tup = reinterpret_cast<double*>(l.buf[0] + (dbuf ? 2 : 1) * (size_t)S.dim);
+  l.tdn = l.tup + tl;
+  l.red = l.tdn + tl;
   return l;
 }
-static size_t lds_bytes(int dim, int maxn, int block, int nred) {
-  return sizeof(double2) * (size_t)dim + sizeof(double) * (size_t)((maxn + 2 + 1) & ~1) + sizeof(double) * (size_t)nred * ((block + 63) / 64);
+static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf) {
+  return sizeof(double2) * (size_t)S.dim * (dbuf ? 2 : 1) + sizeof(double) * 2 * (size_t)table_len(S) +
+         sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64);
 }
 
-constexpr int NRED = 16;  // max values reduced at once (2*QD_MAX_OSC)
+// Keeps index arithmetic INSIDE the time loop: without it the compiler hoists every neighbour index,
+// digit and coefficient of every owned element out of the loop and spills hundreds of registers.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
-template <int EPT>
-constexpr int launch_bound() {
-  return EPT <= 4 ? 1024 : (EPT <= 8 ? 512 : 256);
+// ---------------------------------------------------------------------------------------------
+// general stencil (runtime level counts)
+// ---------------------------------------------------------------------------------------------
+template <int Q, bool LIND, int EPT>
+struct GenStencil {
+  static constexpr int DB = (Q <= 4) ? 8 : 6;  // bits per packed digit (levels <= 255, or <= 63 for Q = 5)
+  int it[EPT];         // storage index (clamped to dim-1 for slots beyond the vector)
+  bool valid[EPT];
+  unsigned dbra[EPT];  // bra digits i_k
+  unsigned dket[EPT];  // ket digits i_k' (Lindblad)
+  double dw[EPT];      // Delta = h(I) - h(I')   (mastereq.hpp:316-403)
+  double dd[EPT];      // d = L2 + L1diag         (mastereq.hpp:339-353, :416-433)
+  int ofs[Q];          // start of oscillator k in the coefficient tables
+
+  __device__ __forceinline__ static int dig(unsigned d, int k) { return (int)((d >> (DB * k)) & ((1u << DB) - 1u)); }
+
+  __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      ofs[k] = o;
+      o += S.n[k];
+    }
+    // coefficient tables: validity of a neighbour is a zero coefficient
+    for (int k = 0; k < Q; k++)
+      for (int a = threadIdx.x; a < S.n[k]; a += blockDim.x) {
+        L.tup[ofs[k] + a] = (a < S.n[k] - 1) ? sqrt((double)(a + 1)) : 0.0;
+        L.tdn[ofs[k] + a] = sqrt((double)a);
+      }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int raw = (int)threadIdx.x + j * (int)blockDim.x;
+      valid[j] = raw < S.dim;
+      it[j] = valid[j] ? raw : S.dim - 1;
+      const int I = LIND ? it[j] % S.N : it[j];
+      const int Ip = LIND ? it[j] / S.N : 0;
+      int ia[Q], ipa[Q];
+      dbra[j] = 0;
+      dket[j] = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        ia[k] = (I / S.post[k]) % S.n[k];
+        ipa[k] = LIND ? (Ip / S.post[k]) % S.n[k] : 0;
+        dbra[j] |= (unsigned)ia[k] << (DB * k);
+        dket[j] |= (unsigned)ipa[k] << (DB * k);
+      }
+      double hd = 0.0, hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        hd += S.detune[k] * ia[k] - S.xi[k] / 2.0 * ia[k] * (ia[k] - 1);
+        if (LIND) {
+          hdp += S.detune[k] * ipa[k] - S.xi[k] / 2.0 * ipa[k] * (ipa[k] - 1);
+          d += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
+        }
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          hd -= S.xikl[pair] * ia[k] * ia[l];
+          if (LIND) hdp -= S.xikl[pair] * ipa[k] * ipa[l];
+          pair++;
+        }
+      }
+      dw[j] = hd - hdp;
+      dd[j] = d;
+    }
+  }
+
+  // Ladder-operator neighbour sums of oscillator k (control(), mastereq.hpp:818-912):
+  //   U1 = sqrt(i+1) x(it+post), U2 = sqrt(i'+1) x(it+N post), D1 = sqrt(i) x(it-post), D2 = sqrt(i') x(it-N post)
+  //   A = U1 + U2 - D1 - D2,  B = U1 - U2 + D1 - D2
+  // so that the control part of y = M x is  y_re += q A_re + p B_im,  y_im += q A_im - p B_re, and
+  // dRHSdp_getcoeffs (mastereq.hpp:553-604) is  res_p = (B_im, -B_re), res_q = (A_re, A_im).
+  __device__ __forceinline__ void ladder(const DevSys& S, const Lds& L, const double2* __restrict__ sx, int k, int j, double2& A,
+                                         double2& B) const {
+    const int a = dig(opaque(dbra[j]), k), st = S.post[k], i0 = opaque(it[j]), top = S.dim - 1;
+    const double su = L.tup[ofs[k] + a], sd = L.tdn[ofs[k] + a];
+    const double2 xu = sx[min(i0 + st, top)], xd = sx[max(i0 - st, 0)];
+    double er = su * xu.x, ei = su * xu.y;    // U1
+    double fr = -sd * xd.x, fi = -sd * xd.y;  // -D1
+    if (LIND) {
+      const int ap = dig(opaque(dket[j]), k), stp = S.N * st;
+      const double sup = L.tup[ofs[k] + ap], sdp = L.tdn[ofs[k] + ap];
+      const double2 xup = sx[min(i0 + stp, top)], xdp = sx[max(i0 - stp, 0)];
+      er = fma(-sdp, xdp.x, er);  // U1 - D2
+      ei = fma(-sdp, xdp.y, ei);
+      fr = fma(sup, xup.x, fr);  // U2 - D1
+      fi = fma(sup, xup.y, fi);
+    }
+    A.x = er + fr;
+    A.y = ei + fi;
+    B.x = er - fr;
+    B.y = ei - fi;
+  }
+
+  // y = M x (TRANS = false) or M^T x at element j.  The Hamiltonian part of the real operator is
+  // antisymmetric (compare control/control_T, Jkl_coupling/Jkl_coupling_T and the drift signs at
+  // mastereq.cpp:1541-1542 vs :1665-1666), the dissipator diagonal is symmetric and the T1
+  // off-diagonal term moves to the mirrored neighbour (L1decay / L1decay_T, mastereq.hpp:758-797).
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                           const double2 xs) const {
+    const int i0 = opaque(it[j]), top = S.dim - 1;
+    const unsigned db = opaque(dbra[j]), dk = opaque(dket[j]);
+    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      double2 A, B;
+      ladder(S, L, sx, k, j, A, B);
+      hr = fma(c.q[k], A.x, fma(c.p[k], B.y, hr));
+      hi = fma(c.q[k], A.y, fma(-c.p[k], B.x, hi));
+    }
+    // dipole-dipole coupling (Jkl_coupling, mastereq.hpp:632-675):
+    //   T1 = sqrt(i_k (i_l+1)) x(it-post_k+post_l), T2 = sqrt(i_l (i_k+1)) x(it+post_k-post_l), T3/T4 ket analogues
+    //   y += J [ sin (T1 - T2 + T3 - T4) - i cos (T1 + T2 - T3 - T4) ]
+    {
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+#pragma unroll
+        for (int l = k + 1; l < Q; l++, pair++) {
+          const double Jkl = S.J[pair];
+          if (!(fabs(Jkl) > 1e-10)) continue;
+          const int a = dig(db, k), b = dig(db, l);
+          const int sk = S.post[k], sl = S.post[l];
+          const double s1 = L.tdn[ofs[k] + a] * L.tup[ofs[l] + b], s2 = L.tdn[ofs[l] + b] * L.tup[ofs[k] + a];
+          const double2 x1 = sx[min(max(i0 - sk + sl, 0), top)], x2 = sx[min(max(i0 + sk - sl, 0), top)];
+          double ar = s1 * x1.x - s2 * x2.x, ai = s1 * x1.y - s2 * x2.y;  // T1 - T2
+          double br = s1 * x1.x + s2 * x2.x, bi = s1 * x1.y + s2 * x2.y;  // T1 + T2
+          if (LIND) {
+            const int ap = dig(dk, k), bp = dig(dk, l);
+            const int skp = S.N * sk, slp = S.N * sl;
+            const double s3 = L.tdn[ofs[k] + ap] * L.tup[ofs[l] + bp], s4 = L.tdn[ofs[l] + bp] * L.tup[ofs[k] + ap];
+            const double2 x3 = sx[min(max(i0 - skp + slp, 0), top)], x4 = sx[min(max(i0 + skp - slp, 0), top)];
+            ar += s3 * x3.x - s4 * x4.x;
+            ai += s3 * x3.y - s4 * x4.y;
+            br -= s3 * x3.x + s4 * x4.x;
+            bi -= s3 * x3.y + s4 * x4.y;
+          }
+          const double co = c.cs[pair], si = c.sn[pair];
+          hr += Jkl * (si * ar + co * bi);
+          hi += Jkl * (si * ai - co * br);
+        }
+      }
+    }
+    double yr = TRANS ? -hr : hr, yi = TRANS ? -hi : hi;
+    if (LIND) {
+      yr = fma(dd[j], xs.x, yr);
+      yi = fma(dd[j], xs.y, yi);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const double g1 = S.g1[k];
+        if (!(fabs(g1) > 1e-12)) continue;
+        const int a = dig(db, k), ap = dig(dk, k), st = S.post[k] * (S.N + 1);
+        const double l1 = TRANS ? g1 * L.tdn[ofs[k] + a] * L.tdn[ofs[k] + ap] : g1 * L.tup[ofs[k] + a] * L.tup[ofs[k] + ap];
+        const double2 xn = sx[TRANS ? max(i0 - st, 0) : min(i0 + st, top)];
+        yr = fma(l1, xn.x, yr);
+        yi = fma(l1, xn.y, yi);
+      }
+    }
+    return make_double2(yr, yi);
+  }
+
+  // isGuardLevel (util.cpp:259-278) for a diagonal element
+  __device__ __forceinline__ bool is_guard(const DevSys& S, int j) const {
+    if (!valid[j]) return false;
+    if (LIND && dbra[j] != dket[j]) return false;
+    bool g = false;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const int a = dig(dbra[j], k);
+      g = g || (a == S.n[k] - 1 && a >= S.ness[k]);
+    }
+    return g;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// qubit stencil (all n_k == 2): the digits are bits of `it`
+//   bra digit of oscillator k = bit (Q-1-k), ket digit = bit (2Q-1-k); neighbours are it ^ bit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double flip_if(double v, unsigned cond) {  // cond ? -v : v  (one v_xor_b32)
+  return __hiloint2double(__double2hiint(v) ^ (int)(cond << 31), __double2loint(v));
 }
 
 template <int Q, bool LIND, int EPT>
-__device__ __forceinline__ void init_elems(const DevSys& S, Elem (&e)[EPT], double* ssq) {
-#pragma unroll
-  for (int j = 0; j < EPT; j++) {
-    const int it = (int)threadIdx.x + j * (int)blockDim.x;
-    elem_init<Q, LIND>(S, it < S.dim ? it : -1, e[j]);
-  }
-  for (int i = threadIdx.x; i < S.maxn + 2; i += blockDim.x) ssq[i] = sqrt((double)i);
-}
+struct QubitStencil {
+  int it[EPT];
+  bool valid[EPT];  // only the single-wave variant can have idle lanes (dim < 64)
+  double dw[EPT], dd[EPT];
 
-// Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727).
-// On entry sx may hold anything that all threads have finished reading; on exit y holds the solution
-// in registers AND sx holds y (after a barrier).  Returns the number of RHS applications.
-template <int Q, bool LIND, bool TRANS, int EPT>
-__device__ __forceinline__ int neumann(const SweepArgs& A, const Elem (&e)[EPT], const Lds& L, const StepC<Q>& c, double alpha,
-                                       const double2 (&b)[EPT], double2 (&y)[EPT]) {
-#pragma unroll
-  for (int j = 0; j < EPT; j++) {
-    y[j] = b[j];
-    if (e[j].it >= 0) L.sx[e[j].it] = y[j];
-  }
-  __syncthreads();
-  double err0 = 1.0;
-  int iter;
-  for (iter = 0; iter < A.maxiter; iter++) {
-    double2 yn[EPT];
-    double d[1] = {0.0};
+  __device__ __forceinline__ void init(const DevSys& S, const Lds&) {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      yn[j] = y[j];
-      if (e[j].it >= 0) {
-        const double2 t = apply_elem<Q, LIND, TRANS>(A.S, e[j], L.sx, L.ssq, c, y[j]);
-        yn[j].x = fma(alpha, t.x, b[j].x);
-        yn[j].y = fma(alpha, t.y, b[j].y);
-        const double dx = y[j].x - yn[j].x, dy = y[j].y - yn[j].y;
-        d[0] += dx * dx + dy * dy;
+      const int raw = (int)threadIdx.x + j * (int)blockDim.x;
+      valid[j] = raw < S.dim;
+      it[j] = raw & (S.dim - 1);  // dim is a power of two
+      double hd = 0.0, hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int a = (it[j] >> (Q - 1 - k)) & 1, ap = LIND ? (it[j] >> (2 * Q - 1 - k)) & 1 : 0;
+        hd += S.detune[k] * a;  // the self-Kerr term a(a-1) vanishes for two levels
+        if (LIND) {
+          hdp += S.detune[k] * ap;
+          d += S.g2[k] * (a * ap - 0.5 * (a + ap)) - S.g1[k] / 2.0 * (a + ap);
+        }
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          const int b = (it[j] >> (Q - 1 - l)) & 1, bp = LIND ? (it[j] >> (2 * Q - 1 - l)) & 1 : 0;
+          hd -= S.xikl[pair] * a * b;
+          if (LIND) hdp -= S.xikl[pair] * ap * bp;
+          pair++;
+        }
+      }
+      dw[j] = hd - hdp;
+      dd[j] = d;
+    }
+  }
+
+  // digit 0: only the "up" neighbour exists (U, coefficient sqrt(1) = 1); digit 1: only "down" (D).
+  //   A = (U1 - D1) + (U2 - D2) = s_b x_b + s_k x_k,  B = (U1 + D1) - (U2 + D2) = x_b - x_k
+  __device__ __forceinline__ void ladder(const DevSys&, const Lds&, const double2* __restrict__ sx, int k, int j, double2& A,
+                                         double2& B) const {
+    const int i0 = opaque(it[j]);
+    const unsigned a = (i0 >> (Q - 1 - k)) & 1;
+    const double2 xb = sx[i0 ^ (1 << (Q - 1 - k))];
+    A.x = flip_if(xb.x, a);
+    A.y = flip_if(xb.y, a);
+    B = xb;
+    if (LIND) {
+      const unsigned ap = (i0 >> (2 * Q - 1 - k)) & 1;
+      const double2 xk = sx[i0 ^ (1 << (2 * Q - 1 - k))];
+      A.x += flip_if(xk.x, ap);
+      A.y += flip_if(xk.y, ap);
+      B.x -= xk.x;
+      B.y -= xk.y;
+    }
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                           const double2 xs) const {
+    const int i0 = opaque(it[j]);
+    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      double2 A, B;
+      ladder(S, L, sx, k, j, A, B);
+      hr = fma(c.q[k], A.x, fma(c.p[k], B.y, hr));
+      hi = fma(c.q[k], A.y, fma(-c.p[k], B.x, hi));
+    }
+    {
+      // Jkl coupling for two-level systems: T1 exists iff (i_k, i_l) = (1, 0), T2 iff (0, 1), both read
+      // x(it ^ (bit_k | bit_l)) with coefficient 1; T3/T4 likewise on the ket bits.
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+#pragma unroll
+        for (int l = k + 1; l < Q; l++, pair++) {
+          const double Jkl = S.J[pair];
+          if (!(fabs(Jkl) > 1e-10)) continue;
+          const unsigned a = (i0 >> (Q - 1 - k)) & 1, b = (i0 >> (Q - 1 - l)) & 1;
+          const double2 xb = sx[i0 ^ ((1 << (Q - 1 - k)) | (1 << (Q - 1 - l)))];
+          const double mb = (a != b) ? 1.0 : 0.0;
+          // a=1,b=0: T1 (A +, B +); a=0,b=1: T2 (A -, B +)
+          double ar = mb * flip_if(xb.x, b), ai = mb * flip_if(xb.y, b);
+          double br = mb * xb.x, bi = mb * xb.y;
+          if (LIND) {
+            const unsigned ap = (i0 >> (2 * Q - 1 - k)) & 1, bp = (i0 >> (2 * Q - 1 - l)) & 1;
+            const double2 xk = sx[i0 ^ ((1 << (2 * Q - 1 - k)) | (1 << (2 * Q - 1 - l)))];
+            const double mk = (ap != bp) ? 1.0 : 0.0;
+            // ap=1,bp=0: T3 (A +, B -); ap=0,bp=1: T4 (A -, B -)
+            ar += mk * flip_if(xk.x, bp);
+            ai += mk * flip_if(xk.y, bp);
+            br -= mk * xk.x;
+            bi -= mk * xk.y;
+          }
+          const double co = c.cs[pair], si = c.sn[pair];
+          hr += Jkl * (si * ar + co * bi);
+          hi += Jkl * (si * ai - co * br);
+        }
       }
     }
-    block_sum<1>(d, L.red);  // barrier: every read of sx above has completed
+    double yr = TRANS ? -hr : hr, yi = TRANS ? -hi : hi;
+    if (LIND) {
+      yr = fma(dd[j], xs.x, yr);
+      yi = fma(dd[j], xs.y, yi);
 #pragma unroll
-    for (int j = 0; j < EPT; j++) {
-      y[j] = yn[j];
-      if (e[j].it >= 0) L.sx[e[j].it] = y[j];
+      for (int k = 0; k < Q; k++) {
+        const double g1 = S.g1[k];
+        if (!(fabs(g1) > 1e-12)) continue;
+        const int bits = (1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k));
+        // forward: both digits 0 -> neighbour with both set; transpose: both 1 -> neighbour with both cleared
+        const bool v = TRANS ? ((i0 & bits) == bits) : ((i0 & bits) == 0);
+        const double l1 = v ? g1 : 0.0;
+        const double2 xn = sx[i0 ^ bits];
+        yr = fma(l1, xn.x, yr);
+        yi = fma(l1, xn.y, yi);
+      }
     }
-    __syncthreads();
-    const double errnorm = sqrt(d[0]);
-    if (iter == 0) err0 = errnorm;
-    if (errnorm < A.abstol) { iter++; break; }
-    if (errnorm / err0 < A.reltol) { iter++; break; }
+    return make_double2(yr, yi);
   }
-  return iter;
-}
+
+  __device__ __forceinline__ bool is_guard(const DevSys&, int) const { return false; }  // nessential == nlevels == 2 ... see host check
+};
+
+template <int Q, bool LIND, int EPT, bool QUBIT>
+struct StencilSel { typedef GenStencil<Q, LIND, EPT> type; };
+template <int Q, bool LIND, int EPT>
+struct StencilSel<Q, LIND, EPT, true> { typedef QubitStencil<Q, LIND, EPT> type; };
+
+template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
+template <int Q, bool LIND, int EPT>
+__device__ __forceinline__ bool slot_valid(const GenStencil<Q, LIND, EPT>& st, int j) { return st.valid[j]; }
+template <int Q, bool LIND, int EPT>
+__device__ __forceinline__ bool slot_valid(const QubitStencil<Q, LIND, EPT>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)
 // ---------------------------------------------------------------------------------------------
-// Thread-local part of (J_re, J_im) for the elements this thread owns (optimtarget.cpp:712-799).
+// Thread-local part of (J_re, J_im) for one element (optimtarget.cpp:712-799).
 template <bool LIND>
 __device__ __forceinline__ void evalJ_part(const DevSys& S, const DevTarget& tg, int b, int it, const double2 x, double& jre,
                                            double& jim) {
@@ -326,12 +507,8 @@ __device__ __forceinline__ void evalJ_part(const DevSys& S, const DevTarget& tg,
         }
       } else {
         const double tr = tg.tstates[(size_t)b * 2 * dim + it], ti = tg.tstates[(size_t)b * 2 * dim + dim + it];
-        if (LIND) {
-          jre += (tr * x.x + ti * x.y) / pur;
-        } else {
-          jre += (tr * x.x + ti * x.y) / pur;
-          jim += -ti * x.x + tr * x.y;
-        }
+        jre += (tr * x.x + ti * x.y) / pur;
+        if (!LIND) jim += -ti * x.x + tr * x.y;
       }
       break;
     }
@@ -429,42 +606,120 @@ __device__ __forceinline__ void finalizeJ_diff(const DevTarget& tg, double re, d
   }
 }
 
-// isGuardLevel (util.cpp:259-278) for the diagonal element this thread owns
-template <int Q, bool LIND>
-__device__ __forceinline__ bool is_guard(const DevSys& S, const Elem& e) {
-  if (e.it < 0) return false;
-  if (LIND && e.dig != e.digp) return false;
-  bool g = false;
-#pragma unroll
-  for (int k = 0; k < Q; k++) {
-    const int a = digit(e.dig, k);
-    g = g || (a == S.n[k] - 1 && a >= S.ness[k]);
+// ---------------------------------------------------------------------------------------------
+// the per-workgroup machinery shared by the forward, adjoint and apply kernels
+// ---------------------------------------------------------------------------------------------
+template <int Q, bool LIND, int VAR, bool QUBIT>
+struct Team {
+  typedef Variant<VAR> V;
+  static constexpr int EPT = V::EPT;
+  typedef typename StencilSel<Q, LIND, EPT, QUBIT>::type ST;
+  ST st;
+  Lds L;
+  int cur;      // which LDS buffer holds the vector that may be stencil-read
+  int redslot;  // alternating reduction scratch slot
+
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
+    L = carve(smem, S, V::DBUF);
+    st.init(S, L);
+    cur = 0;
+    redslot = 0;
   }
-  return g;
-}
+  __device__ __forceinline__ bool ok(int j) const { return slot_valid(st, j); }
+  __device__ __forceinline__ const double2* vec() const { return L.buf[cur]; }
+
+  template <int NV>
+  __device__ __forceinline__ void sum(double (&v)[NV]) {
+    double* red = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
+    block_sum<NV, V::ONEWAVE>(v, red);
+    redslot ^= 1;
+  }
+
+  // Make `x` the stencil-readable vector.  Single buffer: a barrier before the overwrite (every
+  // thread finished reading the old content) and one after; double buffer: only the one after.
+  __device__ __forceinline__ void publish(const double2 (&x)[EPT]) {
+    if (!V::DBUF) team_sync<V::ONEWAVE>();
+    const int nxt = V::DBUF ? cur ^ 1 : cur;
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (ok(j)) L.buf[nxt][st.it[j]] = x[j];
+    cur = nxt;
+    team_sync<V::ONEWAVE>();
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ void apply_all(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = st.template apply<TRANS>(S, L, vec(), c, j, x[j]);
+  }
+
+  // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727).
+  // On exit y is in registers AND is the published vector.  Returns the number of RHS applications.
+  template <bool TRANS>
+  __device__ __forceinline__ int neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT],
+                                         double2 (&y)[EPT]) {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = b[j];
+    publish(y);
+    double err0 = 1.0;
+    int iter;
+    for (iter = 0; iter < A.maxiter; iter++) {
+      double2 yn[EPT];
+      double d[1] = {0.0};
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 t = st.template apply<TRANS>(A.S, L, vec(), c, j, y[j]);
+        yn[j].x = fma(alpha, t.x, b[j].x);
+        yn[j].y = fma(alpha, t.y, b[j].y);
+        const double dx = y[j].x - yn[j].x, dy = y[j].y - yn[j].y;
+        d[0] += ok(j) ? dx * dx + dy * dy : 0.0;
+      }
+      if (V::DBUF) {
+        // write the new iterate into the other buffer, then ONE barrier (inside the reduction)
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          y[j] = yn[j];
+          if (ok(j)) L.buf[nxt][st.it[j]] = y[j];
+        }
+        cur = nxt;
+        sum<1>(d);
+      } else {
+        sum<1>(d);  // barrier: every read of the old iterate has completed
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          y[j] = yn[j];
+          if (ok(j)) L.buf[cur][st.it[j]] = y[j];
+        }
+        team_sync<V::ONEWAVE>();
+      }
+      const double errnorm = sqrt(d[0]);
+      if (iter == 0) err0 = errnorm;
+      if (errnorm < A.abstol) { iter++; break; }
+      if (errnorm / err0 < A.reltol) { iter++; break; }
+    }
+    return iter;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // forward sweep: TimeStepper::solveODE for every initial condition of the batch
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int EPT>
-__global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs A) {
+template <int Q, bool LIND, int VAR, bool QUBIT>
+__global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef Team<Q, LIND, VAR, QUBIT> TM;
+  constexpr int EPT = TM::EPT;
   const DevSys& S = A.S;
-  const Lds L = carve(smem, S.dim, S.maxn);
-  const int b = blockIdx.x, dim = S.dim, T = blockDim.x;
-  Elem e[EPT];
-  init_elems<Q, LIND, EPT>(S, e, L.ssq);
+  TM tm;
+  tm.init(S, smem);
+  const int b = blockIdx.x, dim = S.dim;
   double2 x[EPT];
   const double* x0 = A.x0 + (size_t)b * 2 * dim;
 #pragma unroll
-  for (int j = 0; j < EPT; j++) {
-    x[j] = make_double2(0.0, 0.0);
-    if (e[j].it >= 0) {
-      x[j] = make_double2(x0[e[j].it], x0[dim + e[j].it]);
-      L.sx[e[j].it] = x[j];
-    }
-  }
-  __syncthreads();
+  for (int j = 0; j < EPT; j++) x[j] = make_double2(x0[tm.st.it[j]], x0[dim + tm.st.it[j]]);
+  team_sync<TM::V::ONEWAVE>();  // coefficient tables written by init()
+  tm.publish(x);
   // penalty bookkeeping
   const bool pen_on = A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
@@ -472,9 +727,10 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
   // it needs a block reduction per step; everything else accumulates thread-locally.
   const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
   const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
+  const bool jpairs = S.npairs > 0;
   bool guard[EPT];
 #pragma unroll
-  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && is_guard<Q, LIND>(S, e[j]);
+  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.st.is_guard(S, j);
   double pen_local = 0.0, dpdm_local = 0.0, pen_uniform = 0.0;
   double2 xm1[EPT], xm2[EPT];  // dpdm history (x_n, x_{n-1})
 #pragma unroll
@@ -482,28 +738,25 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
   unsigned long long napply = 0;
   double* traj = A.traj;
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
+  StepC<Q> c, cn;
+  load_step<Q>(A.ctl, cn, jpairs);
 
   for (int s = 0; s < A.nsub; s++) {
+    c = cn;
+    if (s + 1 < A.nsub) load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, cn, jpairs);  // prefetch the next row
     if (traj) {
       double* dst = traj + ((size_t)s * A.nb + b) * 2 * dim;
 #pragma unroll
       for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) {
-          dst[e[j].it] = x[j].x;
-          dst[dim + e[j].it] = x[j].y;
+        if (tm.ok(j)) {
+          dst[tm.st.it[j]] = x[j].x;
+          dst[dim + tm.st.it[j]] = x[j].y;
         }
     }
-    StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c);
     // rhs = M x   (ImplMidpoint::evolveFWD, timestepper.cpp:594; ExplEuler :502)
     double2 rhs[EPT];
-#pragma unroll
-    for (int j = 0; j < EPT; j++) {
-      rhs[j] = make_double2(0.0, 0.0);
-      if (e[j].it >= 0) rhs[j] = apply_elem<Q, LIND, false>(S, e[j], L.sx, L.ssq, c, x[j]);
-    }
+    tm.template apply_all<false>(S, c, x, rhs);
     napply++;
-    __syncthreads();  // all reads of x in sx done before the solver overwrites it
     if (A.stepper_ee) {
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
@@ -512,20 +765,17 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
       }
     } else {
       double2 k[EPT];
-      napply += neumann<Q, LIND, false, EPT>(A, e, L, c, 0.5 * c.h, rhs, k);
+      napply += tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         x[j].x = fma(c.h, k[j].x, x[j].x);
         x[j].y = fma(c.h, k[j].y, x[j].y);
       }
     }
-#pragma unroll
-    for (int j = 0; j < EPT; j++)
-      if (e[j].it >= 0) L.sx[e[j].it] = x[j];
-    __syncthreads();
+    tm.publish(x);
 
     // in-loop penalties, evaluated at the end of a FULL time step (timestepper.cpp:141-154)
-    if ((s + 1) % A.nstages == 0) {
+    if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
       const int n = (s + 1) / A.nstages - 1;  // step index n: state is x_{n+1}
       const double tstop = (n + 1) * A.dt;
       if (pen_on) {
@@ -538,15 +788,14 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
           double v[2] = {0.0, 0.0};
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (e[j].it >= 0) evalJ_part<LIND>(S, A.tg, b, e[j].it, x[j], v[0], v[1]);
-          block_sum<2>(v, L.red);
+            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, b, tm.st.it[j], x[j], v[0], v[1]);
+          tm.template sum<2>(v);
           pen_uniform += weight * finalizeJ<LIND>(A.tg, v[0], v[1]) * A.dt;
-          __syncthreads();
         } else if (wj_on) {
           double jr = 0.0, ji = 0.0;
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (e[j].it >= 0) evalJ_part<LIND>(S, A.tg, b, e[j].it, x[j], jr, ji);
+            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, b, tm.st.it[j], x[j], jr, ji);
           // finalizeJ is affine here: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Lindblad Jtrace)
           if (A.tg.objective_type == QD_OBJ_JTRACE) {
             pen_local -= weight * A.dt * jr;
@@ -563,7 +812,7 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
         if (n > 0) {
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (e[j].it >= 0) {
+            if (tm.ok(j)) {
               const double t1 = x[j].x * x[j].x - 2.0 * xm1[j].x * xm1[j].x + xm2[j].x * xm2[j].x;
               const double t2 = x[j].y * x[j].y - 2.0 * xm1[j].y * xm1[j].y + xm2[j].y * xm2[j].y;
               dpdm_local += dtinv4 * (t1 + t2) * (t1 + t2);
@@ -582,22 +831,21 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
   double* dst = traj ? traj + ((size_t)A.nsub * A.nb + b) * 2 * dim : nullptr;
 #pragma unroll
   for (int j = 0; j < EPT; j++)
-    if (e[j].it >= 0) {
-      xT[e[j].it] = x[j].x;
-      xT[dim + e[j].it] = x[j].y;
+    if (tm.ok(j)) {
+      xT[tm.st.it[j]] = x[j].x;
+      xT[dim + tm.st.it[j]] = x[j].y;
       if (dst) {
-        dst[e[j].it] = x[j].x;
-        dst[dim + e[j].it] = x[j].y;
+        dst[tm.st.it[j]] = x[j].x;
+        dst[dim + tm.st.it[j]] = x[j].y;
       }
     }
   double v[2] = {pen_local, dpdm_local};
-  block_sum<2>(v, L.red);
+  tm.template sum<2>(v);
   if (threadIdx.x == 0) {
     A.pen_out[b] = v[0] + pen_uniform;
     A.dpdm_out[b] = v[1] / A.ntime;
     atomicAdd(A.napply, napply);
   }
-  (void)T;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -605,46 +853,47 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_forward(const SweepArgs
 // (primal states come from the stored trajectory for Lindblad AND Schroedinger: 288 GB of HBM make
 // the reference's backward recomputation of the Schroedinger primal unnecessary)
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int EPT>
-__global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs A) {
+template <int Q, bool LIND, int VAR, bool QUBIT>
+__global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef Team<Q, LIND, VAR, QUBIT> TM;
+  constexpr int EPT = TM::EPT;
   const DevSys& S = A.S;
-  const Lds L = carve(smem, S.dim, S.maxn);
+  TM tm;
+  tm.init(S, smem);
+  team_sync<TM::V::ONEWAVE>();
   const int b = blockIdx.x, dim = S.dim;
-  Elem e[EPT];
-  init_elems<Q, LIND, EPT>(S, e, L.ssq);
-  __syncthreads();
   double2 xb[EPT], xn[EPT];  // adjoint state, primal state x_n (end of the step being reversed)
   const double* xbT = A.xbarT + (size_t)b * 2 * dim;
   const double* traj = A.traj;
   auto load_state = [&](int s, double2(&dst)[EPT]) {
     const double* src = traj + ((size_t)s * A.nb + b) * 2 * dim;
 #pragma unroll
-    for (int j = 0; j < EPT; j++) {
-      dst[j] = make_double2(0.0, 0.0);
-      if (e[j].it >= 0) dst[j] = make_double2(src[e[j].it], src[dim + e[j].it]);
-    }
+    for (int j = 0; j < EPT; j++) dst[j] = make_double2(src[tm.st.it[j]], src[dim + tm.st.it[j]]);
   };
 #pragma unroll
-  for (int j = 0; j < EPT; j++) {
-    xb[j] = make_double2(0.0, 0.0);
-    if (e[j].it >= 0) xb[j] = make_double2(xbT[e[j].it], xbT[dim + e[j].it]);
-  }
+  for (int j = 0; j < EPT; j++) xb[j] = make_double2(xbT[tm.st.it[j]], xbT[dim + tm.st.it[j]]);
   load_state(A.nsub, xn);
   const double jbar_pen = A.jbar[b * 3 + 0], jbar_dpdm = A.jbar[b * 3 + 1];
   const bool pen_on = A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
   const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
+  const bool jpairs = S.npairs > 0;
   bool guard[EPT];
 #pragma unroll
-  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && is_guard<Q, LIND>(S, e[j]);
+  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.st.is_guard(S, j);
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
   const int ntime = A.ntime;
+  double2 x[EPT], xnext[EPT];
+  load_state(A.nsub - 1, xnext);  // primal at the start of the last sub-step (prefetched one step ahead)
 
   for (int s = A.nsub - 1; s >= 0; s--) {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = xnext[j];
+    if (s > 0) load_state(s - 1, xnext);
     // ---- penalty adjoints at the end of a full step, using the primal x_n (timestepper.cpp:220-227)
-    if ((s + 1) % A.nstages == 0) {
+    if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
       const int n = (s + 1) / A.nstages;
       const double tstop = n * A.dt;
       if (dpdm_on) {  // penaltyDpDm_diff (timestepper.cpp:372-442); all five states come from HBM
@@ -656,7 +905,6 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs
         if (n < ntime - 1) load_state((n + 2) * A.nstages, p2);
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
-          if (e[j].it < 0) continue;
           const double xr = xn[j].x, xi = xn[j].y;
           double acc = 0.0;
           if (n > 1) {
@@ -687,17 +935,16 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs
             double v[2] = {0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < EPT; j++)
-              if (e[j].it >= 0) evalJ_part<LIND>(S, A.tg, b, e[j].it, xn[j], v[0], v[1]);
-            block_sum<2>(v, L.red);
+              if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, b, tm.st.it[j], xn[j], v[0], v[1]);
+            tm.template sum<2>(v);
             finalizeJ_diff<LIND>(A.tg, v[0], v[1], rb, ib);
-            __syncthreads();
           } else {
             finalizeJ_diff<LIND>(A.tg, 0.0, 0.0, rb, ib);
           }
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (e[j].it >= 0)
-              evalJ_diff_elem<LIND>(S, A.tg, b, e[j].it, xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+            if (tm.ok(j))
+              evalJ_diff_elem<LIND>(S, A.tg, b, tm.st.it[j], xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
         }
 #pragma unroll
         for (int j = 0; j < EPT; j++)
@@ -707,65 +954,47 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs
           }
       }
     }
-    // ---- primal state at the start of the sub-step
-    double2 x[EPT];
-    load_state(s, x);
     StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c);
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     double* co = A.coeff + ((size_t)b * A.nsub + s) * 2 * Q;
+    double cf[2 * Q];
+#pragma unroll
+    for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
     if (A.stepper_ee) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt * x_adj against x_{n-1}, then
       // x_adj += dt M(tstop)^T x_adj.  The table row of sub-step s holds M(tstart); M(tstop) is row s+1
       // (the last row is followed by one extra row for t = T).
+      tm.publish(x);
 #pragma unroll
       for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) L.sx[e[j].it] = x[j];
-      __syncthreads();
-      double cf[NRED];
-#pragma unroll
-      for (int i = 0; i < NRED; i++) cf[i] = 0.0;
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) {
+        if (tm.ok(j)) {
 #pragma unroll
           for (int k = 0; k < Q; k++) {
             double2 Av, Bv;
-            ladder_AB<LIND>(S, k, e[j], L.sx, L.ssq, Av, Bv);
+            tm.st.ladder(S, tm.L, tm.vec(), k, j, Av, Bv);
             cf[2 * k] += c.h * (Bv.y * xb[j].x - Bv.x * xb[j].y);
             cf[2 * k + 1] += c.h * (Av.x * xb[j].x + Av.y * xb[j].y);
           }
         }
-      block_sum<NRED>(cf, L.red);
+      tm.template sum<2 * Q>(cf);
       if (threadIdx.x < 2 * Q) co[threadIdx.x] = cf[threadIdx.x];
       StepC<Q> c1;
-      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1);
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) L.sx[e[j].it] = xb[j];
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) {
-          const double2 t = apply_elem<Q, LIND, true>(S, e[j], L.sx, L.ssq, c1, xb[j]);
-          xb[j].x = fma(c.h, t.x, xb[j].x);
-          xb[j].y = fma(c.h, t.y, xb[j].y);
-        }
-      __syncthreads();
-    } else {
-      // ImplMidpoint::evolveBWD (timestepper.cpp:631-694)
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) L.sx[e[j].it] = x[j];
-      __syncthreads();
-      double2 rhs[EPT];
+      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
+      tm.publish(xb);
+      double2 t[EPT];
+      tm.template apply_all<true>(S, c1, xb, t);
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        rhs[j] = make_double2(0.0, 0.0);
-        if (e[j].it >= 0) rhs[j] = apply_elem<Q, LIND, false>(S, e[j], L.sx, L.ssq, c, x[j]);
+        xb[j].x = fma(c.h, t[j].x, xb[j].x);
+        xb[j].y = fma(c.h, t[j].y, xb[j].y);
       }
-      __syncthreads();
+    } else {
+      // ImplMidpoint::evolveBWD (timestepper.cpp:631-694)
+      tm.publish(x);
+      double2 rhs[EPT];
+      tm.template apply_all<false>(S, c, x, rhs);
       double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
-      neumann<Q, LIND, true, EPT>(A, e, L, c, 0.5 * c.h, xb, kb);
+      tm.template neumann<true>(A, c, 0.5 * c.h, xb, kb);
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         kb[j].x *= c.h;
@@ -773,45 +1002,37 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs
       }
       {
         double2 k[EPT];  // primal stage: (I - h/2 M) k = rhs ; z = x + h/2 k
-        neumann<Q, LIND, false, EPT>(A, e, L, c, 0.5 * c.h, rhs, k);
+        tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
           k[j].x = fma(0.5 * c.h, k[j].x, x[j].x);
           k[j].y = fma(0.5 * c.h, k[j].y, x[j].y);
-          if (e[j].it >= 0) L.sx[e[j].it] = k[j];
         }
-        __syncthreads();
+        tm.publish(k);
       }
       // gradient coefficients: x^T dM/dp_k z and x^T dM/dq_k z with x := kbar
-      double cf[NRED];
-#pragma unroll
-      for (int i = 0; i < NRED; i++) cf[i] = 0.0;
 #pragma unroll
       for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) {
+        if (tm.ok(j)) {
 #pragma unroll
           for (int k = 0; k < Q; k++) {
             double2 Av, Bv;
-            ladder_AB<LIND>(S, k, e[j], L.sx, L.ssq, Av, Bv);
+            tm.st.ladder(S, tm.L, tm.vec(), k, j, Av, Bv);
             cf[2 * k] += Bv.y * kb[j].x - Bv.x * kb[j].y;
             cf[2 * k + 1] += Av.x * kb[j].x + Av.y * kb[j].y;
           }
         }
-      block_sum<NRED>(cf, L.red);  // barrier: reads of z done
+      tm.template sum<2 * Q>(cf);
       if (threadIdx.x < 2 * Q) co[threadIdx.x] = cf[threadIdx.x];
       // xbar += M^T kbar
+      tm.publish(kb);
+      double2 t[EPT];
+      tm.template apply_all<true>(S, c, kb, t);
 #pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) L.sx[e[j].it] = kb[j];
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (e[j].it >= 0) {
-          const double2 t = apply_elem<Q, LIND, true>(S, e[j], L.sx, L.ssq, c, kb[j]);
-          xb[j].x += t.x;
-          xb[j].y += t.y;
-        }
-      __syncthreads();
+      for (int j = 0; j < EPT; j++) {
+        xb[j].x += t[j].x;
+        xb[j].y += t[j].y;
+      }
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++) xn[j] = x[j];
@@ -820,9 +1041,9 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs
     double* d0 = A.xbar0 + (size_t)b * 2 * dim;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-      if (e[j].it >= 0) {
-        d0[e[j].it] = xb[j].x;
-        d0[dim + e[j].it] = xb[j].y;
+      if (tm.ok(j)) {
+        d0[tm.st.it[j]] = xb[j].x;
+        d0[dim + tm.st.it[j]] = xb[j].y;
       }
   }
 }
@@ -830,35 +1051,32 @@ __global__ void __launch_bounds__(launch_bound<EPT>()) k_adjoint(const SweepArgs
 // ---------------------------------------------------------------------------------------------
 // single operator application (test hook = MatMult / MatMultTranspose on the shell)
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int EPT>
-__global__ void __launch_bounds__(launch_bound<EPT>()) k_apply(const DevSys S, const double* __restrict__ ctlrow, int transpose,
-                                                                const double* __restrict__ xin, double* __restrict__ yout) {
+template <int Q, bool LIND, int VAR, bool QUBIT>
+__global__ void __launch_bounds__(Variant<VAR>::MAXB) k_apply(const DevSys S, const double* __restrict__ ctlrow, int transpose,
+                                                               const double* __restrict__ xin, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = carve(smem, S.dim, S.maxn);
+  typedef Team<Q, LIND, VAR, QUBIT> TM;
+  constexpr int EPT = TM::EPT;
+  TM tm;
+  tm.init(S, smem);
   const int b = blockIdx.x, dim = S.dim;
-  Elem e[EPT];
-  init_elems<Q, LIND, EPT>(S, e, L.ssq);
-  double2 x[EPT];
+  double2 x[EPT], y[EPT];
   const double* x0 = xin + (size_t)b * 2 * dim;
 #pragma unroll
-  for (int j = 0; j < EPT; j++)
-    if (e[j].it >= 0) {
-      x[j] = make_double2(x0[e[j].it], x0[dim + e[j].it]);
-      L.sx[e[j].it] = x[j];
-    }
-  __syncthreads();
+  for (int j = 0; j < EPT; j++) x[j] = make_double2(x0[tm.st.it[j]], x0[dim + tm.st.it[j]]);
+  team_sync<TM::V::ONEWAVE>();
+  tm.publish(x);
   StepC<Q> c;
-  load_step<Q>(ctlrow, c);
-  double* y = yout + (size_t)b * 2 * dim;
+  load_step<Q>(ctlrow, c, S.npairs > 0);
+  if (transpose) tm.template apply_all<true>(S, c, x, y);
+  else tm.template apply_all<false>(S, c, x, y);
+  double* yo = yout + (size_t)b * 2 * dim;
 #pragma unroll
   for (int j = 0; j < EPT; j++)
-    if (e[j].it >= 0) {
-      const double2 t = transpose ? apply_elem<Q, LIND, true>(S, e[j], L.sx, L.ssq, c, x[j])
-                                  : apply_elem<Q, LIND, false>(S, e[j], L.sx, L.ssq, c, x[j]);
-      y[e[j].it] = t.x;
-      y[dim + e[j].it] = t.y;
+    if (tm.ok(j)) {
+      yo[tm.st.it[j]] = y[j].x;
+      yo[dim + tm.st.it[j]] = y[j].y;
     }
 }
-
 
 }  // namespace qd

@@ -119,6 +119,10 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     delete h;
     return fail(QD_ERR_UNSUPPORTED, "qd_create: state dimension > 4096 needs the tiled large-system kernels (not built yet)");
   }
+  if (S.Q == 5 && S.maxn > 63) {
+    delete h;
+    return fail(QD_ERR_UNSUPPORTED, "qd_create: five oscillators are limited to 63 levels each (packed digits)");
+  }
   if (S.Q > 5) {
     delete h;
     return fail(QD_ERR_UNSUPPORTED, "qd_create: the stencil kernels are instantiated for 1..5 oscillators (as the reference's matrix-free path)");
@@ -351,8 +355,9 @@ extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, doubl
 }
 
 static int check_cfg(const LaunchCfg& cfg) {
-  const int lim = cfg.ept <= 4 ? 1024 : 512;
-  if (cfg.block > lim) return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
+  static const int maxb[6] = {64, 256, 256, 1024, 512, 1024};
+  if (cfg.var < 0 || cfg.var > 5 || cfg.block > maxb[cfg.var])
+    return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
   if (cfg.lds > 160 * 1024) return fail(QD_ERR_UNSUPPORTED, "state does not fit the 160 KiB LDS of one CU");
   return QD_OK;
 }

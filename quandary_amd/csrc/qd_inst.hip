@@ -1,16 +1,30 @@
-// qd_inst.hip — one translation unit per (number of oscillators, Schroedinger/Lindblad): compiled
-// with -DQD_Q=<1..5> -DQD_L=<0|1>.  Instantiates the persistent sweep kernels for every supported
-// elements-per-thread count and exports plain launch functions for the dispatcher in qd_kernels.hip.
+// qd_inst.hip — one translation unit per (number of oscillators, Schroedinger/Lindblad, general/qubit
+// stencil): compiled with -DQD_Q=<1..5> -DQD_L=<0|1> -DQD_B=<0|1>.  Instantiates the persistent sweep
+// kernels for the kernel variants that make sense for that case and exports plain launch functions
+// for the dispatcher in qd_kernels.hip.
 #include "qd_device.h"
 
-#ifndef QD_Q
-#error "compile with -DQD_Q=<1..5> -DQD_L=<0|1>"
+#if !defined(QD_Q) || !defined(QD_L) || !defined(QD_B)
+#error "compile with -DQD_Q=<1..5> -DQD_L=<0|1> -DQD_B=<0|1>"
 #endif
 
 namespace qd {
 
-#define QD_CAT3(a, b, c) a##b##_##c
-#define QD_NAME(base, q, l) QD_CAT3(base, q, l)
+#define QD_CAT4(a, q, l, b) a##q##_##l##_##b
+#define QD_NAME(base, q, l, b) QD_CAT4(base, q, l, b)
+
+constexpr bool kQubit = (QD_B != 0);
+constexpr bool kLind = (QD_L != 0);
+// all-qubit systems have a fixed dimension, so only the matching variants are built
+constexpr int kQubitDim = kLind ? (1 << (2 * QD_Q)) : (1 << QD_Q);
+
+template <int VAR>
+constexpr bool variant_built() {
+  if (!kQubit) return VAR <= 4;
+  if (kQubitDim <= 64) return VAR == 0;
+  if (kQubitDim <= 256) return VAR == 1;
+  return VAR == 2 || VAR == 5;
+}
 
 template <typename K>
 static hipError_t set_lds(K kern, size_t bytes) {
@@ -19,41 +33,64 @@ static hipError_t set_lds(K kern, size_t bytes) {
   return hipSuccess;
 }
 
-#define QD_EPT_SWITCH(KERNEL, ...)                                                   \
-  switch (cfg.ept) {                                                                 \
-    case 1: { auto kf = KERNEL<QD_Q, (QD_L != 0), 1>; __VA_ARGS__; } break;          \
-    case 2: { auto kf = KERNEL<QD_Q, (QD_L != 0), 2>; __VA_ARGS__; } break;          \
-    case 4: { auto kf = KERNEL<QD_Q, (QD_L != 0), 4>; __VA_ARGS__; } break;          \
-    case 8: { auto kf = KERNEL<QD_Q, (QD_L != 0), 8>; __VA_ARGS__; } break;          \
-    default: return hipErrorInvalidValue;                                            \
+template <int VAR>
+static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  if constexpr (variant_built<VAR>()) {
+    auto kf = k_forward<QD_Q, kLind, VAR, kQubit>;
+    hipError_t e = set_lds(kf, cfg.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kf, dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
   }
-
-hipError_t QD_NAME(inst_forward_, QD_Q, QD_L)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  QD_EPT_SWITCH(k_forward, {
+}
+template <int VAR>
+static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  if constexpr (variant_built<VAR>()) {
+    auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
-  })
-  return hipGetLastError();
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
 }
-
-hipError_t QD_NAME(inst_adjoint_, QD_Q, QD_L)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  QD_EPT_SWITCH(k_adjoint, {
-    hipError_t e = set_lds(kf, cfg.lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kf, dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
-  })
-  return hipGetLastError();
-}
-
-hipError_t QD_NAME(inst_apply_, QD_Q, QD_L)(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
-                                            const LaunchCfg& cfg, hipStream_t st) {
-  QD_EPT_SWITCH(k_apply, {
+template <int VAR>
+static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
+                           const LaunchCfg& cfg, hipStream_t st) {
+  if constexpr (variant_built<VAR>()) {
+    auto kf = k_apply<QD_Q, kLind, VAR, kQubit>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3(nb), dim3(cfg.block), cfg.lds, st, S, ctlrow, transpose, x, y);
-  })
-  return hipGetLastError();
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+
+#define QD_VAR_SWITCH(FN, ...)               \
+  switch (cfg.var) {                         \
+    case 0: return FN<0>(__VA_ARGS__);       \
+    case 1: return FN<1>(__VA_ARGS__);       \
+    case 2: return FN<2>(__VA_ARGS__);       \
+    case 3: return FN<3>(__VA_ARGS__);       \
+    case 4: return FN<4>(__VA_ARGS__);       \
+    case 5: return FN<5>(__VA_ARGS__);       \
+    default: return hipErrorInvalidValue;    \
+  }
+
+hipError_t QD_NAME(inst_forward_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  QD_VAR_SWITCH(go_forward, a, cfg, st)
+}
+hipError_t QD_NAME(inst_adjoint_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  QD_VAR_SWITCH(go_adjoint, a, cfg, st)
+}
+hipError_t QD_NAME(inst_apply_, QD_Q, QD_L, QD_B)(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y,
+                                                  int nb, const LaunchCfg& cfg, hipStream_t st) {
+  QD_VAR_SWITCH(go_apply, S, ctlrow, transpose, x, y, nb, cfg, st)
 }
 
 }  // namespace qd

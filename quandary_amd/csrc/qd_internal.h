@@ -77,7 +77,8 @@ struct SweepArgs {
 };
 
 struct LaunchCfg {
-  int ept;    // elements per thread (template instantiation)
+  int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)
+  int qubit;  // 1: all oscillators have two levels -> bit-trick stencil
   int block;  // threads per block (one block per initial condition)
   size_t lds;
 };
@@ -95,7 +96,6 @@ hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, co
 hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st);
 hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
-bool config_supported(int Q, int ept);
 LaunchCfg pick_config(const DevSys& S, int nb);
 
 void set_error(const std::string& msg);

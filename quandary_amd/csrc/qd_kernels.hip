@@ -114,7 +114,7 @@ __global__ void k_objective(const DevSys S, const DevTarget tg, const double* __
     evalJ_part<LIND>(S, tg, b, it, xv, v[0], v[1]);
     fidelity_part<LIND>(S, tg, b, it, xv, v[2], v[3]);
   }
-  block_sum<4>(v, red);
+  block_sum<4, false>(v, red);
   if (threadIdx.x < 4) out4[b * 4 + threadIdx.x] = v[threadIdx.x];
 }
 
@@ -209,60 +209,70 @@ __global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
-bool config_supported(int Q, int ept) { return Q >= 1 && Q <= 5 && (ept == 1 || ept == 2 || ept == 4 || ept == 8); }
-
+// Variant choice.  One workgroup per initial condition.  Few initial conditions (latency regime):
+// spread one state over as many lanes as it has elements.  Many initial conditions (throughput
+// regime): more elements per thread so that several workgroups share a CU.
 LaunchCfg pick_config(const DevSys& S, int nb) {
-  // One workgroup per initial condition.  Few initial conditions (latency regime): spread one state
-  // over as many lanes as it has elements.  Many initial conditions (throughput regime): more
-  // elements per thread so that several workgroups share a CU.
-  LaunchCfg c;
+  LaunchCfg c{};
   const int dim = S.dim;
-  int ept = 1;
-  while ((dim + ept - 1) / ept > 1024 && ept < 8) ept *= 2;
-  if (nb >= 1024 && dim >= 1024 && ept < 4) ept = 4;
-  if (const char* ev = getenv("QD_EPT")) {  // tuning override
+  bool qubit = true;
+  for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
+  c.qubit = qubit ? 1 : 0;
+  int var;
+  if (dim <= 64) var = 0;
+  else if (dim <= 256) var = 1;
+  else if (dim <= 1024) var = (qubit && nb < 512) ? 5 : 2;
+  else var = 4;
+  if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
-    if ((v == 1 || v == 2 || v == 4 || v == 8) && (dim + v - 1) / v <= (v == 8 ? 512 : 1024)) ept = v;
+    if (v >= 0 && v < NVARIANTS) var = v;
   }
-  int block = ((dim + ept - 1) / ept + 63) / 64 * 64;
-  c.ept = ept;
-  c.block = block;
-  c.lds = lds_bytes(dim, S.maxn, block, NRED);
+  auto fits = [&](int v) {
+    static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1}, maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024};
+    return (dim + ept[v] - 1) / ept[v] <= maxb[v];
+  };
+  if (!fits(var)) var = dim <= 64 ? 0 : dim <= 256 ? 1 : dim <= 1024 ? 2 : 4;
+  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1};
+  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true};
+  c.var = var;
+  c.block = ((dim + ept[var] - 1) / ept[var] + 63) / 64 * 64;
+  c.lds = lds_bytes(S, c.block, dbuf[var]);
   return c;
 }
 
-
 // ---------------------------------------------------------------------------------------------
-// dispatch to the per-(Q, Lindblad) translation units (qd_inst.hip)
+// dispatch to the per-(Q, Lindblad, qubit) translation units (qd_inst.hip)
 // ---------------------------------------------------------------------------------------------
-#define QD_DECL(q, l)                                                                                                   \
-  hipError_t inst_forward_##q##_##l(const SweepArgs&, const LaunchCfg&, hipStream_t);                                    \
-  hipError_t inst_adjoint_##q##_##l(const SweepArgs&, const LaunchCfg&, hipStream_t);                                    \
-  hipError_t inst_apply_##q##_##l(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
-QD_DECL(1, 0) QD_DECL(2, 0) QD_DECL(3, 0) QD_DECL(4, 0) QD_DECL(5, 0)
-QD_DECL(1, 1) QD_DECL(2, 1) QD_DECL(3, 1) QD_DECL(4, 1) QD_DECL(5, 1)
+#define QD_DECL(q, l, b)                                                                                               \
+  hipError_t inst_forward_##q##_##l##_##b(const SweepArgs&, const LaunchCfg&, hipStream_t);                             \
+  hipError_t inst_adjoint_##q##_##l##_##b(const SweepArgs&, const LaunchCfg&, hipStream_t);                             \
+  hipError_t inst_apply_##q##_##l##_##b(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
+#define QD_DECL_Q(l, b) QD_DECL(1, l, b) QD_DECL(2, l, b) QD_DECL(3, l, b) QD_DECL(4, l, b) QD_DECL(5, l, b)
+QD_DECL_Q(0, 0) QD_DECL_Q(1, 0) QD_DECL_Q(0, 1) QD_DECL_Q(1, 1)
 
 typedef hipError_t (*sweep_fn)(const SweepArgs&, const LaunchCfg&, hipStream_t);
 typedef hipError_t (*apply_fn)(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
-static const sweep_fn fwd_tab[2][5] = {{inst_forward_1_0, inst_forward_2_0, inst_forward_3_0, inst_forward_4_0, inst_forward_5_0},
-                                       {inst_forward_1_1, inst_forward_2_1, inst_forward_3_1, inst_forward_4_1, inst_forward_5_1}};
-static const sweep_fn adj_tab[2][5] = {{inst_adjoint_1_0, inst_adjoint_2_0, inst_adjoint_3_0, inst_adjoint_4_0, inst_adjoint_5_0},
-                                       {inst_adjoint_1_1, inst_adjoint_2_1, inst_adjoint_3_1, inst_adjoint_4_1, inst_adjoint_5_1}};
-static const apply_fn app_tab[2][5] = {{inst_apply_1_0, inst_apply_2_0, inst_apply_3_0, inst_apply_4_0, inst_apply_5_0},
-                                       {inst_apply_1_1, inst_apply_2_1, inst_apply_3_1, inst_apply_4_1, inst_apply_5_1}};
+#define QD_ROW(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b}
+// index [qubit][lindblad][Q-1]
+static const sweep_fn fwd_tab[2][2][5] = {{QD_ROW(inst_forward_, 0, 0), QD_ROW(inst_forward_, 1, 0)},
+                                          {QD_ROW(inst_forward_, 0, 1), QD_ROW(inst_forward_, 1, 1)}};
+static const sweep_fn adj_tab[2][2][5] = {{QD_ROW(inst_adjoint_, 0, 0), QD_ROW(inst_adjoint_, 1, 0)},
+                                          {QD_ROW(inst_adjoint_, 0, 1), QD_ROW(inst_adjoint_, 1, 1)}};
+static const apply_fn app_tab[2][2][5] = {{QD_ROW(inst_apply_, 0, 0), QD_ROW(inst_apply_, 1, 0)},
+                                          {QD_ROW(inst_apply_, 0, 1), QD_ROW(inst_apply_, 1, 1)}};
 
 hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if (a.S.Q < 1 || a.S.Q > 5) return hipErrorInvalidValue;
-  return fwd_tab[a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
+  return fwd_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
 }
 hipError_t launch_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if (a.S.Q < 1 || a.S.Q > 5) return hipErrorInvalidValue;
-  return adj_tab[a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
+  return adj_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
 }
 hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                         const LaunchCfg& cfg, hipStream_t st) {
   if (S.Q < 1 || S.Q > 5) return hipErrorInvalidValue;
-  return app_tab[S.lindblad ? 1 : 0][S.Q - 1](S, ctlrow, transpose, x, y, nb, cfg, st);
+  return app_tab[cfg.qubit ? 1 : 0][S.lindblad ? 1 : 0][S.Q - 1](S, ctlrow, transpose, x, y, nb, cfg, st);
 }
 
 hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,

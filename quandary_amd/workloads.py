@@ -1,0 +1,69 @@
+"""Synthetic benchmark workloads = the five BASELINE.json configs, as reference-format
+config text.  System constants follow tests/performance/configs of the reference (transfreq 4.1+0.1k,
+selfkerr 0.2, crosskerr 0.001), C4 uses the constants of tests/regression/AxC verbatim; controls are
+B-splines with two carriers {0, -selfkerr}, parameters uniform in +-2*pi*0.005 from std::mt19937(1234)
+exactly as `control_initialization = random, 0.005` / `rand_seed = 1234` would give the reference."""
+from . import config
+
+
+def _qubits(q, lindblad, ntime, dt, nspline, objective="Jtrace", linsolve="neumann", runtype="simulation", penalties=False):
+    gate = {1: "xgate", 2: "cnot"}.get(q, "cqnot")
+    lines = [
+        "nlevels = " + ",".join(["2"] * q),
+        f"ntime = {ntime}", f"dt = {dt}",
+        "transfreq = " + ",".join(f"{4.1 + 0.1 * k:.4f}" for k in range(q)),
+        "rotfreq = " + ",".join(f"{4.1 + 0.1 * k:.4f}" for k in range(q)),
+        "selfkerr = " + ",".join(["0.2"] * q),
+        "crosskerr = 0.001", "Jkl = 0.0",
+        "collapse_type = " + ("both" if lindblad else "none"),
+        "decay_time = " + ",".join(["80.0"] * q), "dephase_time = " + ",".join(["26.0"] * q),
+        "initialcondition = basis", "control_enforceBC = false",
+        f"optim_target = gate, {gate}", f"optim_objective = {objective}", "optim_regul = 1e-4",
+        "optim_penalty = " + ("0.1" if penalties else "0.0"), "optim_penalty_param = 0.5",
+        "optim_penalty_energy = " + ("0.1" if penalties else "0.0"), "optim_penalty_dpdm = 0.0", "optim_penalty_variation = 0.0",
+        f"linearsolver_type = {linsolve}", "linearsolver_maxiter = 20", "timestepper = IMR",
+        "rand_seed = 1234", "usematfree = true", f"runtype = {runtype}",
+    ]
+    for k in range(q):
+        lines += [f"control_segments{k} = spline, {nspline}", f"control_initialization{k} = random, 0.005", f"carrier_frequency{k} = 0.0, -0.2"]
+    return "\n".join(lines) + "\n"
+
+
+def _axc(ntime, linsolve="neumann", init="basis", runtype="simulation"):
+    return "\n".join([
+        "nlevels = 3, 20", f"ntime = {ntime}", "dt = 0.0001", "transfreq = 4416.66, 6840.815", "selfkerr = 230.56, 0.0",
+        "crosskerr = 1.176", "Jkl = 0.0", "rotfreq = 4416.66, 6840.815", "collapse_type = both", "decay_time = 80.0, 0.3892042",
+        "dephase_time = 26.0, 5.0", f"initialcondition = {init}", "control_segments0 = spline, 75", "control_segments1 = spline, 75",
+        "control_initialization0 = constant, 5.0", "control_initialization1 = constant, 1.0", "control_enforceBC = true",
+        "carrier_frequency0 = 0.0, -230.56, 1.176", "carrier_frequency1 = 0.0, 1.176", "optim_target = pure, 0,0",
+        "optim_objective = Jmeasure", "optim_weights = 1.0", "optim_regul = 0.00001", "optim_penalty = 1.0", "optim_penalty_param = 0.5",
+        "optim_penalty_dpdm = 0.0", "optim_penalty_energy = 0.1", "optim_penalty_variation = 0.0", f"runtype = {runtype}",
+        "usematfree = true", f"linearsolver_type = {linsolve}", "linearsolver_maxiter = 20", "rand_seed = 1234",
+    ]) + "\n"
+
+
+WORKLOADS = {
+    # name: (description, config text factory(mode))
+    "c1": ("C1 2x2 Schroedinger CNOT, 4 basis states (config_template.cfg shape)",
+           lambda mode: _qubits(2, False, 1000, 0.1, 150, runtype=mode)),
+    "c2": ("C2 2x2x2 Lindblad T1/T2, 64 basis initial conditions, ntime 1000, dt 0.01",
+           lambda mode: _qubits(3, True, 1000, 0.01, 30, runtype=mode)),
+    "c3": ("C3 2^4 Schroedinger forward + adjoint gradient, 16 initial states, B-spline controls, ntime 1000",
+           lambda mode: _qubits(4, False, 1000, 0.01, 30, runtype=mode)),
+    "q4": ("4-qubit open system (2^4 Lindblad, dim 256), 256 basis initial conditions, ntime 1000",
+           lambda mode: _qubits(4, True, 1000, 0.01, 30, runtype=mode)),
+    "c4": ("C4 3x20 Lindblad (AxC constants), 3600 basis initial conditions, ntime 2500 (500 for gradients)",
+           lambda mode: _axc(2500 if mode == "simulation" else 500, runtype=mode)),
+    "c5": ("C5 2^5 Lindblad (dim 1024), 1024 basis initial conditions, ntime 1000, fp64 stencil path",
+           lambda mode: _qubits(5, True, 1000, 0.01, 30, runtype=mode)),
+}
+
+
+def workload_spec(name, mode="simulation", overrides=None):
+    desc, fac = WORKLOADS[name]
+    cfg = config.parse_config_text(fac(mode))
+    if overrides:
+        cfg.update({k: str(v) for k, v in overrides.items()})
+    sp = config.build_spec(cfg)
+    sp.description = desc
+    return sp
