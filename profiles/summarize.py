@@ -1,0 +1,66 @@
+"""Condenses a gpurun_out/prof_<tag>/ directory written by profiles/collect.sh into small files
+that are committed under profiles/: per-kernel stats (rocprofv3 --stats) and per-launch HBM bytes
+from the PMC passes (FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B;
+MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, other widths
+uncalibrated -> both the raw and the doubled figure are kept)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, suffix):
+    return sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    res = {"tag": tag}
+    stats = find(os.path.join(out, "stats"), "kernel_stats.csv")
+    rows = []
+    for f in stats:
+        rows += list(csv.DictReader(open(f)))
+    res["kernel_stats"] = rows
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as fh:
+        if rows:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    pmc = {}
+    for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        for f in find(os.path.join(out, sub), "counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") != name:
+                    continue
+                k = r["Kernel_Name"].split("(")[0]
+                d = pmc.setdefault(k, {}).setdefault(name, [])
+                d.append(float(r["Counter_Value"]))
+    sq = {}
+    for f in find(os.path.join(out, "pmc_sq"), "counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            sq.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    summary = {}
+    for k, v in pmc.items():
+        f = v.get("FETCH_SIZE", [])
+        w = v.get("WRITE_SIZE", [])
+        fm = sum(f) / len(f) if f else None
+        wm = sum(w) / len(w) if w else None
+        summary[k] = {
+            "launches": max(len(f), len(w)),
+            "FETCH_SIZE_mean": fm, "WRITE_SIZE_mean": wm,
+            "hbm_bytes_per_launch_raw": ((fm or 0) + (wm or 0)) * 1024.0,
+            "hbm_bytes_per_launch_fetch_x2": (2 * (fm or 0) + (wm or 0)) * 1024.0,
+        }
+    for k, v in sq.items():
+        summary.setdefault(k, {})["sq_mean"] = {c: sum(x) / len(x) for c, x in v.items()}
+    res["pmc"] = summary
+    json.dump(res, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "sq_mean"} for k, v in summary.items()}, indent=1)[:3000])
+    for r in rows[:8]:
+        print({k: r[k] for k in list(r.keys())[:6]})
+
+
+if __name__ == "__main__":
+    main()

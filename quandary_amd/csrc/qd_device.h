@@ -123,7 +123,8 @@ __device__ __forceinline__ void load_step(const double* __restrict__ row, StepC<
 // LDS layout
 // ---------------------------------------------------------------------------------------------
 struct Lds {
-  double2* buf[2];  // state exchange vector(s); buf[1] == buf[0] without double buffering
+  double2* buf0;    // state exchange vector(s): buffer b starts at buf0 + b * bstride
+  int bstride;      // dim with double buffering, 0 without (both "buffers" coincide)
   double* tup;      // general stencil: tup[ofs_k + a] = (a < n_k-1) ? sqrt(a+1) : 0
   double* tdn;      //                  tdn[ofs_k + a] = sqrt(a)
   double* red;      // reduction scratch, two slots of NRED * nwaves
@@ -135,10 +136,10 @@ __host__ __device__ inline int table_len(const DevSys& S) {
 }
 __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf) {
   Lds l;
-  l.buf[0] = reinterpret_cast<double2*>(smem);
-  l.buf[1] = dbuf ? l.buf[0] + S.dim : l.buf[0];
+  l.buf0 = reinterpret_cast<double2*>(smem);
+  l.bstride = dbuf ? S.dim : 0;
   const int tl = table_len(S);
-  l.tup = reinterpret_cast<double*>(l.buf[0] + (dbuf ? 2 : 1) * (size_t)S.dim);
+  l.tup = reinterpret_cast<double*>(l.buf0 + (dbuf ? 2 : 1) * (size_t)S.dim);
   l.tdn = l.tup + tl;
   l.red = l.tdn + tl;
   return l;
@@ -257,30 +258,90 @@ struct GenStencil {
   // antisymmetric (compare control/control_T, Jkl_coupling/Jkl_coupling_T and the drift signs at
   // mastereq.cpp:1541-1542 vs :1665-1666), the dissipator diagonal is symmetric and the T1
   // off-diagonal term moves to the mirrored neighbour (L1decay / L1decay_T, mastereq.hpp:758-797).
+  // All LDS reads of the element are issued before any arithmetic (one latency, not one per oscillator);
+  // the reference's thresholds |J| > 1e-10 and |gamma_1| > 1e-12 are applied once on the host
+  // (coefficients below them arrive here as exact zeros), so there is no branch per term.
   template <bool TRANS>
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
                                            const double2 xs) const {
     const int i0 = opaque(it[j]), top = S.dim - 1;
     const unsigned db = opaque(dbra[j]), dk = opaque(dket[j]);
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
+    double l1r = 0.0, l1i = 0.0;  // T1 off-diagonal contribution
+    if (EPT == 1) {
+      // latency regime (one element per thread): all LDS reads first, then the arithmetic
+      double2 xu[Q], xd[Q], xup[Q], xdp[Q], xl[Q];
+      double su[Q], sd[Q], sup[Q], sdp[Q];
 #pragma unroll
-    for (int k = 0; k < Q; k++) {
-      double2 A, B;
-      ladder(S, L, sx, k, j, A, B);
-      hr = fma(c.q[k], A.x, fma(c.p[k], B.y, hr));
-      hi = fma(c.q[k], A.y, fma(-c.p[k], B.x, hi));
+      for (int k = 0; k < Q; k++) {
+        const int a = dig(db, k), st = S.post[k];
+        su[k] = L.tup[ofs[k] + a];
+        sd[k] = L.tdn[ofs[k] + a];
+        xu[k] = sx[min(i0 + st, top)];
+        xd[k] = sx[max(i0 - st, 0)];
+        if (LIND) {
+          const int ap = dig(dk, k), stp = S.N * st;
+          sup[k] = L.tup[ofs[k] + ap];
+          sdp[k] = L.tdn[ofs[k] + ap];
+          xup[k] = sx[min(i0 + stp, top)];
+          xdp[k] = sx[max(i0 - stp, 0)];
+          xl[k] = sx[TRANS ? max(i0 - st - stp, 0) : min(i0 + st + stp, top)];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        // A = U1 + U2 - D1 - D2,  B = U1 - U2 + D1 - D2  (see ladder())
+        double er = su[k] * xu[k].x, ei = su[k] * xu[k].y;
+        double fr = -sd[k] * xd[k].x, fi = -sd[k] * xd[k].y;
+        if (LIND) {
+          er = fma(-sdp[k], xdp[k].x, er);
+          ei = fma(-sdp[k], xdp[k].y, ei);
+          fr = fma(sup[k], xup[k].x, fr);
+          fi = fma(sup[k], xup[k].y, fi);
+          const double l1 = S.g1off[k] * (TRANS ? sd[k] * sdp[k] : su[k] * sup[k]);
+          l1r = fma(l1, xl[k].x, l1r);
+          l1i = fma(l1, xl[k].y, l1i);
+        }
+        hr = fma(c.q[k], er + fr, fma(c.p[k], ei - fi, hr));
+        hi = fma(c.q[k], ei + fi, fma(-c.p[k], er - fr, hi));
+      }
+    } else {
+      // throughput regime (several elements per thread, several waves per SIMD hide the LDS latency):
+      // stream oscillator by oscillator to keep the live register set small
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int a = dig(db, k), st = S.post[k];
+        const double su = L.tup[ofs[k] + a], sd = L.tdn[ofs[k] + a];
+        const double2 xu = sx[min(i0 + st, top)], xd = sx[max(i0 - st, 0)];
+        double er = su * xu.x, ei = su * xu.y;
+        double fr = -sd * xd.x, fi = -sd * xd.y;
+        if (LIND) {
+          const int ap = dig(dk, k), stp = S.N * st;
+          const double sup = L.tup[ofs[k] + ap], sdp = L.tdn[ofs[k] + ap];
+          const double2 xup = sx[min(i0 + stp, top)], xdp = sx[max(i0 - stp, 0)];
+          er = fma(-sdp, xdp.x, er);
+          ei = fma(-sdp, xdp.y, ei);
+          fr = fma(sup, xup.x, fr);
+          fi = fma(sup, xup.y, fi);
+          const double2 xl = sx[TRANS ? max(i0 - st - stp, 0) : min(i0 + st + stp, top)];
+          const double l1 = S.g1off[k] * (TRANS ? sd * sdp : su * sup);
+          l1r = fma(l1, xl.x, l1r);
+          l1i = fma(l1, xl.y, l1i);
+        }
+        hr = fma(c.q[k], er + fr, fma(c.p[k], ei - fi, hr));
+        hi = fma(c.q[k], ei + fi, fma(-c.p[k], er - fr, hi));
+      }
     }
     // dipole-dipole coupling (Jkl_coupling, mastereq.hpp:632-675):
     //   T1 = sqrt(i_k (i_l+1)) x(it-post_k+post_l), T2 = sqrt(i_l (i_k+1)) x(it+post_k-post_l), T3/T4 ket analogues
     //   y += J [ sin (T1 - T2 + T3 - T4) - i cos (T1 + T2 - T3 - T4) ]
-    {
+    if (S.hasJ) {
       int pair = 0;
 #pragma unroll
       for (int k = 0; k < Q; k++) {
 #pragma unroll
         for (int l = k + 1; l < Q; l++, pair++) {
           const double Jkl = S.J[pair];
-          if (!(fabs(Jkl) > 1e-10)) continue;
           const int a = dig(db, k), b = dig(db, l);
           const int sk = S.post[k], sl = S.post[l];
           const double s1 = L.tdn[ofs[k] + a] * L.tup[ofs[l] + b], s2 = L.tdn[ofs[l] + b] * L.tup[ofs[k] + a];
@@ -305,18 +366,8 @@ struct GenStencil {
     }
     double yr = TRANS ? -hr : hr, yi = TRANS ? -hi : hi;
     if (LIND) {
-      yr = fma(dd[j], xs.x, yr);
-      yi = fma(dd[j], xs.y, yi);
-#pragma unroll
-      for (int k = 0; k < Q; k++) {
-        const double g1 = S.g1[k];
-        if (!(fabs(g1) > 1e-12)) continue;
-        const int a = dig(db, k), ap = dig(dk, k), st = S.post[k] * (S.N + 1);
-        const double l1 = TRANS ? g1 * L.tdn[ofs[k] + a] * L.tdn[ofs[k] + ap] : g1 * L.tup[ofs[k] + a] * L.tup[ofs[k] + ap];
-        const double2 xn = sx[TRANS ? max(i0 - st, 0) : min(i0 + st, top)];
-        yr = fma(l1, xn.x, yr);
-        yi = fma(l1, xn.y, yi);
-      }
+      yr = fma(dd[j], xs.x, yr) + l1r;
+      yi = fma(dd[j], xs.y, yi) + l1i;
     }
     return make_double2(yr, yi);
   }
@@ -402,15 +453,44 @@ struct QubitStencil {
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
                                            const double2 xs) const {
     const int i0 = opaque(it[j]);
-    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
+    // all neighbour reads first (one LDS latency per application)
+    double2 xb[Q], xk[Q], xl[Q];
 #pragma unroll
     for (int k = 0; k < Q; k++) {
-      double2 A, B;
-      ladder(S, L, sx, k, j, A, B);
-      hr = fma(c.q[k], A.x, fma(c.p[k], B.y, hr));
-      hi = fma(c.q[k], A.y, fma(-c.p[k], B.x, hi));
+      xb[k] = sx[i0 ^ (1 << (Q - 1 - k))];
+      if (LIND) {
+        xk[k] = sx[i0 ^ (1 << (2 * Q - 1 - k))];
+        xl[k] = sx[i0 ^ ((1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k)))];
+      }
     }
-    {
+    // control part with the digit signs folded into q:  q A.x + p B.y = (+-q) xb.x + (+-q) xk.x + p (xb.y - xk.y);
+    // two accumulator pairs shorten the dependent fp64 chain (the small-system kernels are latency bound)
+    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0.0, gi = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const unsigned a = (i0 >> (Q - 1 - k)) & 1;
+      const double qb = flip_if(c.q[k], a);
+      double br = xb[k].x, bi = xb[k].y;
+      double tr = qb * xb[k].x, ti = qb * xb[k].y;
+      if (LIND) {
+        const unsigned ap = (i0 >> (2 * Q - 1 - k)) & 1;
+        const double qk = flip_if(c.q[k], ap);
+        tr = fma(qk, xk[k].x, tr);
+        ti = fma(qk, xk[k].y, ti);
+        br -= xk[k].x;
+        bi -= xk[k].y;
+      }
+      tr = fma(c.p[k], bi, tr);
+      ti = fma(-c.p[k], br, ti);
+      if (k == 1) { gr = tr; gi = ti; }
+      else if (k & 1) { gr += tr; gi += ti; }
+      else { hr += tr; hi += ti; }
+    }
+    if (Q > 1) {
+      hr += gr;
+      hi += gi;
+    }
+    if (S.hasJ) {
       // Jkl coupling for two-level systems: T1 exists iff (i_k, i_l) = (1, 0), T2 iff (0, 1), both read
       // x(it ^ (bit_k | bit_l)) with coefficient 1; T3/T4 likewise on the ket bits.
       int pair = 0;
@@ -419,22 +499,21 @@ struct QubitStencil {
 #pragma unroll
         for (int l = k + 1; l < Q; l++, pair++) {
           const double Jkl = S.J[pair];
-          if (!(fabs(Jkl) > 1e-10)) continue;
           const unsigned a = (i0 >> (Q - 1 - k)) & 1, b = (i0 >> (Q - 1 - l)) & 1;
-          const double2 xb = sx[i0 ^ ((1 << (Q - 1 - k)) | (1 << (Q - 1 - l)))];
+          const double2 xj = sx[i0 ^ ((1 << (Q - 1 - k)) | (1 << (Q - 1 - l)))];
           const double mb = (a != b) ? 1.0 : 0.0;
           // a=1,b=0: T1 (A +, B +); a=0,b=1: T2 (A -, B +)
-          double ar = mb * flip_if(xb.x, b), ai = mb * flip_if(xb.y, b);
-          double br = mb * xb.x, bi = mb * xb.y;
+          double ar = mb * flip_if(xj.x, b), ai = mb * flip_if(xj.y, b);
+          double br = mb * xj.x, bi = mb * xj.y;
           if (LIND) {
             const unsigned ap = (i0 >> (2 * Q - 1 - k)) & 1, bp = (i0 >> (2 * Q - 1 - l)) & 1;
-            const double2 xk = sx[i0 ^ ((1 << (2 * Q - 1 - k)) | (1 << (2 * Q - 1 - l)))];
+            const double2 xq = sx[i0 ^ ((1 << (2 * Q - 1 - k)) | (1 << (2 * Q - 1 - l)))];
             const double mk = (ap != bp) ? 1.0 : 0.0;
             // ap=1,bp=0: T3 (A +, B -); ap=0,bp=1: T4 (A -, B -)
-            ar += mk * flip_if(xk.x, bp);
-            ai += mk * flip_if(xk.y, bp);
-            br -= mk * xk.x;
-            bi -= mk * xk.y;
+            ar += mk * flip_if(xq.x, bp);
+            ai += mk * flip_if(xq.y, bp);
+            br -= mk * xq.x;
+            bi -= mk * xq.y;
           }
           const double co = c.cs[pair], si = c.sn[pair];
           hr += Jkl * (si * ar + co * bi);
@@ -448,15 +527,12 @@ struct QubitStencil {
       yi = fma(dd[j], xs.y, yi);
 #pragma unroll
       for (int k = 0; k < Q; k++) {
-        const double g1 = S.g1[k];
-        if (!(fabs(g1) > 1e-12)) continue;
         const int bits = (1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k));
         // forward: both digits 0 -> neighbour with both set; transpose: both 1 -> neighbour with both cleared
         const bool v = TRANS ? ((i0 & bits) == bits) : ((i0 & bits) == 0);
-        const double l1 = v ? g1 : 0.0;
-        const double2 xn = sx[i0 ^ bits];
-        yr = fma(l1, xn.x, yr);
-        yi = fma(l1, xn.y, yi);
+        const double l1 = v ? S.g1off[k] : 0.0;
+        yr = fma(l1, xl[k].x, yr);
+        yi = fma(l1, xl[k].y, yi);
       }
     }
     return make_double2(yr, yi);
@@ -626,7 +702,8 @@ struct Team {
     redslot = 0;
   }
   __device__ __forceinline__ bool ok(int j) const { return slot_valid(st, j); }
-  __device__ __forceinline__ const double2* vec() const { return L.buf[cur]; }
+  __device__ __forceinline__ double2* bufp(int b) const { return L.buf0 + b * L.bstride; }
+  __device__ __forceinline__ const double2* vec() const { return bufp(cur); }
 
   template <int NV>
   __device__ __forceinline__ void sum(double (&v)[NV]) {
@@ -642,7 +719,7 @@ struct Team {
     const int nxt = V::DBUF ? cur ^ 1 : cur;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-      if (ok(j)) L.buf[nxt][st.it[j]] = x[j];
+      if (ok(j)) bufp(nxt)[st.it[j]] = x[j];
     cur = nxt;
     team_sync<V::ONEWAVE>();
   }
@@ -650,7 +727,10 @@ struct Team {
   template <bool TRANS>
   __device__ __forceinline__ void apply_all(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
 #pragma unroll
-    for (int j = 0; j < EPT; j++) y[j] = st.template apply<TRANS>(S, L, vec(), c, j, x[j]);
+    for (int j = 0; j < EPT; j++) {
+      y[j] = st.template apply<TRANS>(S, L, vec(), c, j, x[j]);
+      if (EPT > 1) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727).
@@ -661,42 +741,37 @@ struct Team {
 #pragma unroll
     for (int j = 0; j < EPT; j++) y[j] = b[j];
     publish(y);
-    double err0 = 1.0;
+    // Stopping test of the reference (timestepper.cpp:713-720) on squared norms: errnorm < abstol  <=>
+    // d < abstol^2 and errnorm/errnorm0 < reltol  <=>  d < reltol^2 d0 (no fp64 sqrt / divide per iteration).
+    const double abs2 = A.abstol * A.abstol, rel2 = A.reltol * A.reltol;
+    double d0 = 1.0;
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
-      double2 yn[EPT];
       double d[1] = {0.0};
+      const double2* src = vec();
+      if (V::DBUF) cur ^= 1;  // the new iterate goes to the other buffer: ONE barrier (inside the reduction)
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const double2 t = st.template apply<TRANS>(A.S, L, vec(), c, j, y[j]);
-        yn[j].x = fma(alpha, t.x, b[j].x);
-        yn[j].y = fma(alpha, t.y, b[j].y);
-        const double dx = y[j].x - yn[j].x, dy = y[j].y - yn[j].y;
+        const double2 t = st.template apply<TRANS>(A.S, L, src, c, j, y[j]);
+        double2 w;
+        w.x = fma(alpha, t.x, b[j].x);
+        w.y = fma(alpha, t.y, b[j].y);
+        const double dx = y[j].x - w.x, dy = y[j].y - w.y;
         d[0] += ok(j) ? dx * dx + dy * dy : 0.0;
+        y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
+        if (V::DBUF && ok(j)) bufp(cur)[st.it[j]] = w;
+        if (EPT > 1) __builtin_amdgcn_sched_barrier(0);  // one element at a time: keeps the live register set small
       }
-      if (V::DBUF) {
-        // write the new iterate into the other buffer, then ONE barrier (inside the reduction)
-        const int nxt = cur ^ 1;
+      sum<1>(d);  // contains the barrier (multi-wave): every read of the old iterate has completed
+      if (!V::DBUF) {
 #pragma unroll
-        for (int j = 0; j < EPT; j++) {
-          y[j] = yn[j];
-          if (ok(j)) L.buf[nxt][st.it[j]] = y[j];
-        }
-        cur = nxt;
-        sum<1>(d);
-      } else {
-        sum<1>(d);  // barrier: every read of the old iterate has completed
-#pragma unroll
-        for (int j = 0; j < EPT; j++) {
-          y[j] = yn[j];
-          if (ok(j)) L.buf[cur][st.it[j]] = y[j];
-        }
+        for (int j = 0; j < EPT; j++)
+          if (ok(j)) bufp(cur)[st.it[j]] = y[j];
         team_sync<V::ONEWAVE>();
       }
-      const double errnorm = sqrt(d[0]);
-      if (iter == 0) err0 = errnorm;
-      if (errnorm < A.abstol) { iter++; break; }
-      if (errnorm / err0 < A.reltol) { iter++; break; }
+      if (iter == 0) d0 = d[0];
+      if (d[0] < abs2) { iter++; break; }
+      if (d[0] < rel2 * d0) { iter++; break; }
     }
     return iter;
   }
@@ -977,7 +1052,9 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
           }
         }
       tm.template sum<2 * Q>(cf);
-      if (threadIdx.x < 2 * Q) co[threadIdx.x] = cf[threadIdx.x];
+#pragma unroll
+      for (int i = 0; i < 2 * Q; i++)
+        if (threadIdx.x == i) co[i] = cf[i];
       StepC<Q> c1;
       load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
       tm.publish(xb);
@@ -1023,7 +1100,9 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
           }
         }
       tm.template sum<2 * Q>(cf);
-      if (threadIdx.x < 2 * Q) co[threadIdx.x] = cf[threadIdx.x];
+#pragma unroll
+      for (int i = 0; i < 2 * Q; i++)
+        if (threadIdx.x == i) co[i] = cf[i];
       // xbar += M^T kbar
       tm.publish(kb);
       double2 t[EPT];

@@ -135,6 +135,7 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     S.detune[k] = 2.0 * M_PI * (sys->transfreq[k] - sys->rotfreq[k]);
     S.xi[k] = 2.0 * M_PI * sys->selfkerr[k];
     S.g1[k] = (sys->decay_time[k] > 1e-14 && addT1) ? 1.0 / sys->decay_time[k] : 0.0;
+    S.g1off[k] = fabs(S.g1[k]) > 1e-12 ? S.g1[k] : 0.0;  // threshold of L1decay (mastereq.hpp:759)
     S.g2[k] = (sys->dephase_time[k] > 1e-14 && addT2) ? 1.0 / sys->dephase_time[k] : 0.0;
   }
   S.npairs = S.Q * (S.Q - 1) / 2;
@@ -145,6 +146,8 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     for (int l = k + 1; l < S.Q; l++) {
       S.xikl[idx] = 2.0 * M_PI * sys->crosskerr[idx];
       S.J[idx] = 2.0 * M_PI * sys->Jkl[idx];
+      if (!(fabs(S.J[idx]) > 1e-10)) S.J[idx] = 0.0;  // threshold of Jkl_coupling (mastereq.hpp:633)
+      else S.hasJ = 1;
       D.eta[idx] = 2.0 * M_PI * (sys->rotfreq[k] - sys->rotfreq[l]);
       idx++;
     }

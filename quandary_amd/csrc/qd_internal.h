@@ -18,8 +18,10 @@ namespace qd {
 // ---------------------------------------------------------------------------------------------
 struct DevSys {
   int Q, lindblad, N, dim, npairs, maxn;
+  int hasJ, pad0;  // any |J_kl| > 1e-10 (smaller couplings and |gamma_1| <= 1e-12 are zeroed on the host)
   int n[QD_MAX_OSC], ness[QD_MAX_OSC], post[QD_MAX_OSC];
   double detune[QD_MAX_OSC], xi[QD_MAX_OSC], g1[QD_MAX_OSC], g2[QD_MAX_OSC];
+  double g1off[QD_MAX_OSC];  // gamma_1 of the off-diagonal decay term: 0 unless |gamma_1| > 1e-12 (mastereq.hpp:759)
   double xikl[QD_MAX_PAIRS], J[QD_MAX_PAIRS];
 };
 

@@ -145,9 +145,11 @@ __global__ void k_reduce_coeff(const double* __restrict__ coeff, int nb, int nco
 // grad[d] = sum_s B_d(t_s) * {Blt1bar | Blt2bar}(s) + energy-penalty terms
 // (Oscillator::evalControl_diff oscillator.cpp:339-381, BSpline2nd::derivative controlbasis.cpp:68-79,
 //  BSpline0::derivative :245-254, energyPenaltyIntegral_diff timestepper.cpp:458-480)
-__global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int cs, int nsub, int ee, const double* __restrict__ coeffsum,
-                       const double* __restrict__ etable, int nstep, double ebar, double* __restrict__ grad, int ndesign) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* __restrict__ table, int cs, int nsub, int ee,
+                                             const double* __restrict__ coeffsum, const double* __restrict__ etable, int nstep,
+                                             double ebar, double* __restrict__ grad, int ndesign) {
+  // one wave per design parameter; lanes stride over the sub-steps, fixed-order wave reduction
+  const int idx = blockIdx.x, lane = threadIdx.x;
   if (idx >= ndesign) return;
   // locate (oscillator, segment, carrier, spline, part)
   int k = 0;
@@ -163,7 +165,7 @@ __global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int
   const int r = loc - g.skip;
   const int f = r / (2 * g.nsplines), l = (r % (2 * g.nsplines)) % g.nsplines, part = (r % (2 * g.nsplines)) / g.nsplines;
   if (g.type == QD_CTRL_BSPLINE && d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) {
-    grad[idx] = 0.0;
+    if (lane == 0) grad[idx] = 0.0;
     return;
   }
   const double om = d.carriers[o.car_begin + f];
@@ -181,7 +183,7 @@ __global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int
     return id == l ? 1.0 : 0.0;
   };
   double acc = 0.0;
-  for (int s = 0; s < nsub; s++) {
+  for (int s = lane; s < nsub; s += 64) {
     const double* row = table + (size_t)s * cs;
     const double t = ee ? row[1] + row[0] : row[1];
     if (!active(t)) continue;
@@ -192,7 +194,7 @@ __global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int
     acc += B * (part == 0 ? si * qbar + co * pbar : co * qbar - si * pbar);
   }
   if (ebar != 0.0) {
-    for (int n = 0; n < nstep; n++) {
+    for (int n = lane; n < nstep; n += 64) {
       const double* row = etable + (size_t)n * cs;
       const double t = row[1];
       if (!active(t)) continue;
@@ -203,7 +205,8 @@ __global__ void k_grad(const DevCtlDesc d, const double* __restrict__ table, int
       acc += B * (part == 0 ? si * qbar + co * pbar : co * qbar - si * pbar);
     }
   }
-  grad[idx] = acc;
+  acc = wave_sum(acc);
+  if (lane == 0) grad[idx] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,7 +309,7 @@ hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsu
   if (ndesign == 0) return hipSuccess;
   const int ee = nsub < 0;  // negative nsub flags the explicit-Euler gradient time (t_stop)
   const int ns = ee ? -nsub : nsub;
-  hipLaunchKernelGGL(k_grad, dim3((ndesign + 63) / 64), dim3(64), 0, st, d, table, cs, ns, ee, coeffsum, etable, nstep, ebar, grad,
+  hipLaunchKernelGGL(k_grad, dim3(ndesign), dim3(64), 0, st, d, table, cs, ns, ee, coeffsum, etable, nstep, ebar, grad,
                      ndesign);
   return hipGetLastError();
 }
