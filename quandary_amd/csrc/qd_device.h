@@ -51,6 +51,19 @@ __device__ __forceinline__ double dpp_mov(double v) {
   return __hiloint2double(h2, l2);
 }
 
+// fp32 sum over the 64 lanes (DPP adds, result wave-uniform).  Used ONLY for the stopping test of the
+// linear solver, where the squared update norm is compared with a threshold.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 // Sum over the 64 lanes of a wave; the result is wave-uniform (same bits in every lane).
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
@@ -90,6 +103,20 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red) {
     for (int w = 0; w < nw; w++) s += red[i * nw + w];
     v[i] = s;
   }
+}
+
+// Block-wide fp32 sum for the solver's stopping test (same barrier structure as block_sum).
+template <bool ONEWAVE>
+__device__ __forceinline__ float block_sum_f32(float v, double* red) {
+  v = wave_sum_f32(v);
+  if (ONEWAVE) return v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float* rf = reinterpret_cast<float*>(red);
+  if (lane == 0) rf[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nw; w++) s += rf[w];
+  return s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -226,6 +253,8 @@ struct GenStencil {
       dd[j] = d;
     }
   }
+
+  __device__ __forceinline__ void prep(const StepC<Q>&) {}
 
   // Ladder-operator neighbour sums of oscillator k (control(), mastereq.hpp:818-912):
   //   U1 = sqrt(i+1) x(it+post), U2 = sqrt(i'+1) x(it+N post), D1 = sqrt(i) x(it-post), D2 = sqrt(i') x(it-N post)
@@ -399,6 +428,22 @@ struct QubitStencil {
   int it[EPT];
   bool valid[EPT];  // only the single-wave variant can have idle lanes (dim < 64)
   double dw[EPT], dd[EPT];
+  // latency regime (EPT == 1): loop invariants kept in registers instead of being re-derived from the
+  // index bits in every operator application
+  static constexpr bool HOIST = (EPT == 1);
+  double l1f[HOIST ? Q : 1], l1t[HOIST ? Q : 1];  // T1 off-diagonal coefficient, forward / transposed
+  double qb[HOIST ? Q : 1], qk[HOIST ? Q : 1];    // controls q_k with the bra / ket digit sign of this element
+
+  // once per (sub-)step: fold the digit signs into the controls
+  __device__ __forceinline__ void prep(const StepC<Q>& c) {
+    if (HOIST) {
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        qb[k] = flip_if(c.q[k], (it[0] >> (Q - 1 - k)) & 1);
+        qk[k] = LIND ? flip_if(c.q[k], (it[0] >> (2 * Q - 1 - k)) & 1) : 0.0;
+      }
+    }
+  }
 
   __device__ __forceinline__ void init(const DevSys& S, const Lds&) {
 #pragma unroll
@@ -426,6 +471,14 @@ struct QubitStencil {
       }
       dw[j] = hd - hdp;
       dd[j] = d;
+    }
+    if (HOIST && LIND) {
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int bits = (1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k));
+        l1f[k] = ((it[0] & bits) == 0) ? S.g1off[k] : 0.0;
+        l1t[k] = ((it[0] & bits) == bits) ? S.g1off[k] : 0.0;
+      }
     }
   }
 
@@ -469,14 +522,14 @@ struct QubitStencil {
 #pragma unroll
     for (int k = 0; k < Q; k++) {
       const unsigned a = (i0 >> (Q - 1 - k)) & 1;
-      const double qb = flip_if(c.q[k], a);
+      const double sqb = HOIST ? qb[k] : flip_if(c.q[k], a);
       double br = xb[k].x, bi = xb[k].y;
-      double tr = qb * xb[k].x, ti = qb * xb[k].y;
+      double tr = sqb * xb[k].x, ti = sqb * xb[k].y;
       if (LIND) {
         const unsigned ap = (i0 >> (2 * Q - 1 - k)) & 1;
-        const double qk = flip_if(c.q[k], ap);
-        tr = fma(qk, xk[k].x, tr);
-        ti = fma(qk, xk[k].y, ti);
+        const double sqk = HOIST ? qk[k] : flip_if(c.q[k], ap);
+        tr = fma(sqk, xk[k].x, tr);
+        ti = fma(sqk, xk[k].y, ti);
         br -= xk[k].x;
         bi -= xk[k].y;
       }
@@ -530,7 +583,7 @@ struct QubitStencil {
         const int bits = (1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k));
         // forward: both digits 0 -> neighbour with both set; transpose: both 1 -> neighbour with both cleared
         const bool v = TRANS ? ((i0 & bits) == bits) : ((i0 & bits) == 0);
-        const double l1 = v ? S.g1off[k] : 0.0;
+        const double l1 = HOIST ? (TRANS ? l1t[k] : l1f[k]) : (v ? S.g1off[k] : 0.0);
         yr = fma(l1, xl[k].x, yr);
         yi = fma(l1, xl[k].y, yi);
       }
@@ -712,6 +765,12 @@ struct Team {
     redslot ^= 1;
   }
 
+  __device__ __forceinline__ float sum_f32(float v) {
+    double* red = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
+    redslot ^= 1;
+    return block_sum_f32<V::ONEWAVE>(v, red);
+  }
+
   // Make `x` the stencil-readable vector.  Single buffer: a barrier before the overwrite (every
   // thread finished reading the old content) and one after; double buffer: only the one after.
   __device__ __forceinline__ void publish(const double2 (&x)[EPT]) {
@@ -742,12 +801,17 @@ struct Team {
     for (int j = 0; j < EPT; j++) y[j] = b[j];
     publish(y);
     // Stopping test of the reference (timestepper.cpp:713-720) on squared norms: errnorm < abstol  <=>
-    // d < abstol^2 and errnorm/errnorm0 < reltol  <=>  d < reltol^2 d0 (no fp64 sqrt / divide per iteration).
-    const double abs2 = A.abstol * A.abstol, rel2 = A.reltol * A.reltol;
-    double d0 = 1.0;
+    // d < abstol^2 and errnorm/errnorm0 < reltol  <=>  d < reltol^2 d0 (no fp64 sqrt / divide per
+    // iteration).  The squared update norm is accumulated in fp64 per thread and reduced over the
+    // workgroup in fp32: it is only compared with a threshold, and the fp32 reduction is a third of
+    // the dependent latency of the fp64 one in the latency-bound small-system kernels.  Scaling by
+    // 1/abstol^2 keeps the fp32 value away from the subnormal range.
+    const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
+    const float rel2 = (float)(A.reltol * A.reltol);
+    float d0 = 1.f;
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
-      double d[1] = {0.0};
+      double dloc = 0.0;
       const double2* src = vec();
       if (V::DBUF) cur ^= 1;  // the new iterate goes to the other buffer: ONE barrier (inside the reduction)
 #pragma unroll
@@ -757,21 +821,23 @@ struct Team {
         w.x = fma(alpha, t.x, b[j].x);
         w.y = fma(alpha, t.y, b[j].y);
         const double dx = y[j].x - w.x, dy = y[j].y - w.y;
-        d[0] += ok(j) ? dx * dx + dy * dy : 0.0;
+        dloc += ok(j) ? dx * dx + dy * dy : 0.0;
         y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
         if (V::DBUF && ok(j)) bufp(cur)[st.it[j]] = w;
         if (EPT > 1) __builtin_amdgcn_sched_barrier(0);  // one element at a time: keeps the live register set small
       }
-      sum<1>(d);  // contains the barrier (multi-wave): every read of the old iterate has completed
+      // clamp: adjoint solves of badly scaled problems have update norms whose square overflows fp32; a
+      // clamped value is still far above both thresholds (the reference's reltol is 1e-20)
+      const float d = sum_f32((float)fmin(dloc * inv_abs2, 1e30));  // contains the barrier (multi-wave)
       if (!V::DBUF) {
 #pragma unroll
         for (int j = 0; j < EPT; j++)
           if (ok(j)) bufp(cur)[st.it[j]] = y[j];
         team_sync<V::ONEWAVE>();
       }
-      if (iter == 0) d0 = d[0];
-      if (d[0] < abs2) { iter++; break; }
-      if (d[0] < rel2 * d0) { iter++; break; }
+      if (iter == 0) d0 = d;
+      if (d < 1.f) { iter++; break; }
+      if (d < rel2 * d0) { iter++; break; }
     }
     return iter;
   }
@@ -819,6 +885,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   for (int s = 0; s < A.nsub; s++) {
     c = cn;
     if (s + 1 < A.nsub) load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, cn, jpairs);  // prefetch the next row
+    tm.st.prep(c);
     if (traj) {
       double* dst = traj + ((size_t)s * A.nb + b) * 2 * dim;
 #pragma unroll
@@ -1031,6 +1098,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     }
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    tm.st.prep(c);
     double* co = A.coeff + ((size_t)b * A.nsub + s) * 2 * Q;
     double cf[2 * Q];
 #pragma unroll
@@ -1057,6 +1125,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         if (threadIdx.x == i) co[i] = cf[i];
       StepC<Q> c1;
       load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
+      tm.st.prep(c1);
       tm.publish(xb);
       double2 t[EPT];
       tm.template apply_all<true>(S, c1, xb, t);
@@ -1147,6 +1216,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_apply(const DevSys S, co
   tm.publish(x);
   StepC<Q> c;
   load_step<Q>(ctlrow, c, S.npairs > 0);
+  tm.st.prep(c);
   if (transpose) tm.template apply_all<true>(S, c, x, y);
   else tm.template apply_all<false>(S, c, x, y);
   double* yo = yout + (size_t)b * 2 * dim;
