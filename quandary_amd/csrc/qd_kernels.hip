@@ -237,9 +237,10 @@ LaunchCfg pick_config(const DevSys& S, int nb) {
   if (!fits(var)) var = dim <= 64 ? 0 : dim <= 256 ? 1 : dim <= 1024 ? 2 : 4;
   static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1};
   static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true};
+  static const bool blds[NVARIANTS] = {false, false, false, false, false, false};
   c.var = var;
   c.block = ((dim + ept[var] - 1) / ept[var] + 63) / 64 * 64;
-  c.lds = lds_bytes(S, c.block, dbuf[var]);
+  c.lds = lds_bytes(S, c.block, dbuf[var], blds[var]);
   return c;
 }
 
