@@ -41,6 +41,8 @@ constexpr int NVARIANTS = 6;
 // (large elements-per-thread variants would otherwise spill)
 
 constexpr int NRED = 16;  // max values reduced at once (2*QD_MAX_OSC)
+constexpr int GMRES_MR = 10;                                     // restart length of the in-kernel GMRES
+constexpr int GMRES_NSC = (GMRES_MR + 2) + 2 * GMRES_MR + (GMRES_MR + 2) + GMRES_MR * GMRES_MR + GMRES_MR;  // scalars
 
 // ---------------------------------------------------------------------------------------------
 // reductions
@@ -158,13 +160,15 @@ struct Lds {
   double* tdn;      //                  tdn[ofs_k + a] = sqrt(a)
   double* red;      // reduction scratch, two slots of NRED * nwaves
   double2* bvec;    // BLDS variants: right-hand side of the linear solve
+  double2* kry;     // GMRES: Krylov basis, (GMRES_MR + 1) vectors of dim
+  double* ksc;      // GMRES: wave-uniform scalars (Hessenberg column, rotations, rhs, R, solution)
 };
 __host__ __device__ inline int table_len(const DevSys& S) {
   int t = 0;
   for (int k = 0; k < S.Q; k++) t += S.n[k];
   return (t + 1) & ~1;
 }
-__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds) {
+__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, bool krylov = false) {
   Lds l;
   l.buf0 = reinterpret_cast<double2*>(smem);
   l.bstride = dbuf ? S.dim : 0;
@@ -174,11 +178,19 @@ __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool 
   l.tup = reinterpret_cast<double*>(l.buf0 + nvec * (size_t)S.dim);
   l.tdn = l.tup + tl;
   l.red = l.tdn + tl;
+  l.kry = nullptr;
+  l.ksc = nullptr;
+  if (krylov) {
+    const int nw = (blockDim.x + 63) >> 6;
+    l.kry = reinterpret_cast<double2*>(l.red + 2 * NRED * nw);
+    l.ksc = reinterpret_cast<double*>(l.kry + (size_t)(GMRES_MR + 1) * S.dim);
+  }
   return l;
 }
-static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds) {
+static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, bool krylov = false) {
   return sizeof(double2) * (size_t)S.dim * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
-         sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64);
+         sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64) +
+         (krylov ? sizeof(double2) * (size_t)(GMRES_MR + 1) * S.dim + sizeof(double) * GMRES_NSC : 0);
 }
 
 // Keeps index arithmetic INSIDE the time loop: without it the compiler hoists every neighbour index,
@@ -752,8 +764,8 @@ struct Team {
   int cur;      // which LDS buffer holds the vector that may be stencil-read
   int redslot;  // alternating reduction scratch slot
 
-  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
-    L = carve(smem, S, V::DBUF, V::BLDS);
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, bool krylov = false) {
+    L = carve(smem, S, V::DBUF, V::BLDS, krylov);
     st.init(S, L);
     cur = 0;
     redslot = 0;
@@ -847,6 +859,127 @@ struct Team {
     }
     return iter;
   }
+
+  // GMRES for (I - alpha M^{(T)}) y = b: stands in for KSPSolve / KSPSolveTranspose with KSPGMRES +
+  // PCNONE (src/timestepper.cpp:541-550, call sites :602,:652,:674): zero initial guess, classical
+  // Gram-Schmidt (PETSc's default orthogonalisation), Givens rotations, stop when the recurrence
+  // residual <= max(rtol ||b||, abstol) or after maxiter iterations; restarted every GMRES_MR
+  // iterations.  One element per thread: the Krylov basis lives in LDS (the stencil reads v_j in
+  // place), the small Hessenberg problem is solved redundantly by every thread on wave-uniform
+  // scalars kept in LDS.  Returns the number of RHS applications.
+  template <bool TRANS>
+  __device__ __forceinline__ int gmres(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
+    static_assert(EPT == 1, "in-kernel GMRES is built for the one-element-per-thread variants");
+    const int dim = A.S.dim, e = st.it[0];
+    const bool on = ok(0);
+    double2* Vb = L.kry;
+    double* hc = L.ksc;               // [MR+2] current Hessenberg column
+    double* cs = hc + (GMRES_MR + 2);  // [MR]
+    double* sn = cs + GMRES_MR;        // [MR]
+    double* g = sn + GMRES_MR;         // [MR+2]
+    double* R = g + (GMRES_MR + 2);    // [MR][MR] row-major upper triangle
+    double* yk = R + GMRES_MR * GMRES_MR;
+    double2 yy = make_double2(0.0, 0.0), r = b[0];
+    int its = 0, napp = 0;
+    double ttol = 0.0;
+    for (int cycle = 0;; cycle++) {
+      double t[1] = {on ? r.x * r.x + r.y * r.y : 0.0};
+      sum<1>(t);
+      const double beta = sqrt(t[0]);
+      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+      if (beta <= ttol || its >= A.maxiter) break;
+      double2 v = make_double2(r.x / beta, r.y / beta);
+      if (on) Vb[e] = v;
+      g[0] = beta;
+      team_sync<V::ONEWAVE>();
+      int j = 0;
+      bool conv = false;
+      while (j < GMRES_MR) {
+        const double2 t2 = st.template apply<TRANS>(A.S, L, Vb + (size_t)j * dim, c, 0, v);
+        napp++;
+        double2 w = make_double2(v.x - alpha * t2.x, v.y - alpha * t2.y);
+        // classical Gram-Schmidt: all projections against the un-updated w, four per reduction
+        for (int k0 = 0; k0 <= j; k0 += 4) {
+          double h4[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int k = k0 + q;
+            double2 vk = make_double2(0.0, 0.0);
+            if (k <= j) vk = Vb[(size_t)k * dim + e];
+            h4[q] = (on && k <= j) ? w.x * vk.x + w.y * vk.y : 0.0;
+          }
+          sum<4>(h4);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (k0 + q <= j) hc[k0 + q] = h4[q];
+        }
+        for (int k = 0; k <= j; k++) {
+          const double2 vk = Vb[(size_t)k * dim + e];
+          const double h = hc[k];
+          w.x -= h * vk.x;
+          w.y -= h * vk.y;
+        }
+        double nn[1] = {on ? w.x * w.x + w.y * w.y : 0.0};
+        sum<1>(nn);
+        const double hn = sqrt(nn[0]);
+        hc[j + 1] = hn;
+        v = hn > 0.0 ? make_double2(w.x / hn, w.y / hn) : make_double2(0.0, 0.0);
+        if (on) Vb[(size_t)(j + 1) * dim + e] = v;
+        // Givens rotations on the new column, update of the rotated right-hand side
+        for (int k = 0; k < j; k++) {
+          const double a0 = hc[k], a1 = hc[k + 1], ck = cs[k], sk = sn[k];
+          hc[k] = ck * a0 + sk * a1;
+          hc[k + 1] = -sk * a0 + ck * a1;
+        }
+        const double a = hc[j], bb = hc[j + 1];
+        const double rr = sqrt(a * a + bb * bb);
+        const double cj = rr == 0.0 ? 1.0 : a / rr, sj = rr == 0.0 ? 0.0 : bb / rr;
+        cs[j] = cj;
+        sn[j] = sj;
+        hc[j] = rr;
+        const double gj = g[j];
+        g[j + 1] = -sj * gj;
+        g[j] = cj * gj;
+        for (int k = 0; k <= j; k++) R[k * GMRES_MR + j] = hc[k];
+        its++;
+        j++;
+        team_sync<V::ONEWAVE>();  // v_{j} is readable by every thread
+        if (fabs(g[j]) <= ttol || hn == 0.0) { conv = true; break; }
+        if (its >= A.maxiter) break;
+      }
+      // back substitution R yk = g, y += V yk
+      for (int rw = j - 1; rw >= 0; rw--) {
+        double sacc = g[rw];
+        for (int cc = rw + 1; cc < j; cc++) sacc -= R[rw * GMRES_MR + cc] * yk[cc];
+        yk[rw] = sacc / R[rw * GMRES_MR + rw];
+      }
+      for (int cc = 0; cc < j; cc++) {
+        const double2 vk = Vb[(size_t)cc * dim + e];
+        const double f = yk[cc];
+        yy.x += f * vk.x;
+        yy.y += f * vk.y;
+      }
+      if (conv || its >= A.maxiter) break;
+      // restart: r = b - (I - alpha M) y
+      team_sync<V::ONEWAVE>();
+      if (on) Vb[e] = yy;
+      team_sync<V::ONEWAVE>();
+      const double2 t2 = st.template apply<TRANS>(A.S, L, Vb, c, 0, yy);
+      napp++;
+      r = make_double2(b[0].x - (yy.x - alpha * t2.x), b[0].y - (yy.y - alpha * t2.y));
+      team_sync<V::ONEWAVE>();
+    }
+    y[0] = yy;
+    return napp;
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ int solve(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
+    if constexpr (EPT == 1) {
+      if (A.use_gmres) return gmres<TRANS>(A, c, alpha, b, y);
+    }
+    return neumann<TRANS>(A, c, alpha, b, y);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -859,7 +992,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   constexpr int EPT = TM::EPT;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem);
+  tm.init(S, smem, A.use_gmres != 0);
   const int b = blockIdx.x, dim = S.dim;
   double2 x[EPT];
   const double* x0 = A.x0 + (size_t)b * 2 * dim;
@@ -913,7 +1046,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
       }
     } else {
       double2 k[EPT];
-      napply += tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
+      napply += tm.template solve<false>(A, c, 0.5 * c.h, rhs, k);
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         x[j].x = fma(c.h, k[j].x, x[j].x);
@@ -1008,7 +1141,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   constexpr int EPT = TM::EPT;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem);
+  tm.init(S, smem, A.use_gmres != 0);
   team_sync<TM::V::ONEWAVE>();
   const int b = blockIdx.x, dim = S.dim;
   double2 xb[EPT], xn[EPT];  // adjoint state, primal state x_n (end of the step being reversed)
@@ -1146,7 +1279,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       double2 rhs[EPT];
       tm.template apply_all<false>(S, c, x, rhs);
       double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
-      tm.template neumann<true>(A, c, 0.5 * c.h, xb, kb);
+      tm.template solve<true>(A, c, 0.5 * c.h, xb, kb);
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         kb[j].x *= c.h;
@@ -1154,7 +1287,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       }
       {
         double2 k[EPT];  // primal stage: (I - h/2 M) k = rhs ; z = x + h/2 k
-        tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
+        tm.template solve<false>(A, c, 0.5 * c.h, rhs, k);
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
           k[j].x = fma(0.5 * c.h, k[j].x, x[j].x);

@@ -472,7 +472,8 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
   a.pen_out = d_pen.p;
   a.dpdm_out = d_dpdm.p;
   a.napply = d_napply;
-  LaunchCfg cfg = pick_config(S, nb);
+  LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+  a.use_gmres = cfg.gmres;
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
@@ -544,7 +545,8 @@ int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, co
   a.xbarT = dxbarT;
   a.jbar = djbar;
   a.coeff = d_coeff.p;
-  LaunchCfg cfg = pick_config(S, nb);
+  LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+  a.use_gmres = cfg.gmres;
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev0, stream));
   QD_HIP(launch_adjoint(a, cfg, stream));

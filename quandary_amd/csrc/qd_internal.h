@@ -59,7 +59,8 @@ struct SweepArgs {
   const double* ctl;  // step-control table [nsub][cs]
   int cs, nsub, nstages, ntime, nb;
   double dt, Tfinal;
-  int stepper_ee, linsolve, maxiter, mr;  // mr: GMRES restart length held in registers
+  int stepper_ee, linsolve, maxiter;
+  int use_gmres;  // 1: in-kernel GMRES (one-element-per-thread variants whose Krylov basis fits in LDS), else Neumann
   double abstol, reltol;
   // penalties (src/timestepper.cpp:256-480)
   double gamma_penalty, penalty_param, gamma_dpdm;
@@ -82,6 +83,7 @@ struct LaunchCfg {
   int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)
   int qubit;  // 1: all oscillators have two levels -> bit-trick stencil
   int block;  // threads per block (one block per initial condition)
+  int gmres;  // 1: Krylov storage is part of the LDS carve-up
   size_t lds;
 };
 
@@ -98,7 +100,7 @@ hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, co
 hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st);
 hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
-LaunchCfg pick_config(const DevSys& S, int nb);
+LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false);
 
 void set_error(const std::string& msg);
 

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 // Variant choice.  One workgroup per initial condition.  Few initial conditions (latency regime):
 // spread one state over as many lanes as it has elements.  Many initial conditions (throughput
 // regime): more elements per thread so that several workgroups share a CU.
-LaunchCfg pick_config(const DevSys& S, int nb) {
+LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
@@ -240,7 +240,15 @@ LaunchCfg pick_config(const DevSys& S, int nb) {
   static const bool blds[NVARIANTS] = {false, false, false, false, false, false};
   c.var = var;
   c.block = ((dim + ept[var] - 1) / ept[var] + 63) / 64 * 64;
-  c.lds = lds_bytes(S, c.block, dbuf[var], blds[var]);
+  c.gmres = 0;
+  c.lds = lds_bytes(S, c.block, dbuf[var], blds[var], false);
+  if (want_gmres && ept[var] == 1 && !getenv("QD_FORCE_NEUMANN")) {
+    const size_t with = lds_bytes(S, c.block, dbuf[var], blds[var], true);
+    if (with <= 160 * 1024) {
+      c.gmres = 1;
+      c.lds = with;
+    }
+  }
   return c;
 }
 

@@ -84,6 +84,24 @@ def test_objective_and_gradient_vs_oracle(kw, penalties):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7]])
+def test_gmres_solver_vs_oracle_gmres(kw):
+    """linearsolver_type = gmres: in-kernel GMRES (Krylov basis in LDS) against the oracle's GMRES."""
+    sp, h, orc = _pair(kw, ntime=30, linsolve="gmres", penalties=True, dt=0.05)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    # same Krylov method, same stopping rule: the mean number of RHS applications agrees closely
+    orc.reset_stats()
+    orc.evalF(sp.params0)
+    opt.evalF(sp.params0)
+    assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("stepper", ["IMR4", "IMR8", "EE"])
 def test_other_steppers(stepper):
     sp, h, orc = _pair(dict(nlevels=[3, 2], lindblad=True, jkl=0.01, detuned=True), ntime=12, stepper=stepper, penalties=True)
