@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--linsolve", default=None, choices=[None, "neumann", "gmres"])
     ap.add_argument("--ntime", type=int, default=None, help="override the number of time steps of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share one GPU for testing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,10 +121,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)  # ranks may share a GPU in this mode
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if (world > 1 and args.dist_backend == "gloo") else f"cuda:{local_rank}"
 
     mode = "simulation" if args.mode == "fwd" else "gradient"
     over = {}
@@ -136,7 +141,7 @@ def main():
 
     handle = capi.Handle(spec, device=local_rank)   # raises loudly without the HIP library / a GPU
     optim = capi.Optim(handle, spec, rank=rank, nranks=world)
-    obj = DistributedObjective(optim, dist, f"cuda:{local_rank}")
+    obj = DistributedObjective(optim, dist, red_dev)
     alpha = spec.params0
 
     def one_step():
@@ -164,7 +169,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
 

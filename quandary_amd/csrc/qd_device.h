@@ -30,13 +30,18 @@ namespace qd {
 // kernel variants
 // ---------------------------------------------------------------------------------------------
 template <int VAR> struct Variant;
-template <> struct Variant<0> { static constexpr int EPT = 1, MAXB = 64;   static constexpr bool DBUF = false, ONEWAVE = true,  BLDS = false; };
-template <> struct Variant<1> { static constexpr int EPT = 1, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; };
-template <> struct Variant<2> { static constexpr int EPT = 4, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; };
-template <> struct Variant<3> { static constexpr int EPT = 4, MAXB = 1024; static constexpr bool DBUF = false, ONEWAVE = false, BLDS = false; };
-template <> struct Variant<4> { static constexpr int EPT = 8, MAXB = 512;  static constexpr bool DBUF = false, ONEWAVE = false, BLDS = false; };
-template <> struct Variant<5> { static constexpr int EPT = 1, MAXB = 1024; static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; };
-constexpr int NVARIANTS = 6;
+template <> struct Variant<0> { static constexpr int EPT = 1, MAXB = 64;   static constexpr bool DBUF = false, ONEWAVE = true,  BLDS = false; static constexpr int ICPB = 1; };
+template <> struct Variant<1> { static constexpr int EPT = 1, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
+template <> struct Variant<2> { static constexpr int EPT = 4, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
+template <> struct Variant<3> { static constexpr int EPT = 4, MAXB = 1024; static constexpr bool DBUF = false, ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
+template <> struct Variant<4> { static constexpr int EPT = 8, MAXB = 512;  static constexpr bool DBUF = false, ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
+template <> struct Variant<5> { static constexpr int EPT = 1, MAXB = 1024; static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
+// V6: two initial conditions interleaved in ONE wave (dim <= 64): two independent dependency chains per
+// lane hide the LDS / fp64 latencies that bound the single-wave kernels
+template <> struct Variant<6> { static constexpr int EPT = 2, MAXB = 64;   static constexpr bool DBUF = false, ONEWAVE = true,  BLDS = false; static constexpr int ICPB = 2; };
+// V7: the same for dim <= 256 (four waves, two initial conditions per workgroup, one barrier serves both)
+template <> struct Variant<7> { static constexpr int EPT = 2, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 2; };
+constexpr int NVARIANTS = 8;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 
@@ -123,6 +128,26 @@ __device__ __forceinline__ float block_sum_f32(float v, double* red) {
   return s;
 }
 
+template <int NV, bool ONEWAVE>
+__device__ __forceinline__ void block_sum_f32v(float (&v)[NV], double* red) {
+#pragma unroll
+  for (int i = 0; i < NV; i++) v[i] = wave_sum_f32(v[i]);
+  if (ONEWAVE) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float* rf = reinterpret_cast<float*>(red);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) rf[i * nw + wave] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    float s = 0.f;
+    for (int w = 0; w < nw; w++) s += rf[i * nw + w];
+    v[i] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // step controls (wave-uniform, streamed from the table by scalar loads, prefetched one step ahead)
 // ---------------------------------------------------------------------------------------------
@@ -168,13 +193,13 @@ __host__ __device__ inline int table_len(const DevSys& S) {
   for (int k = 0; k < S.Q; k++) t += S.n[k];
   return (t + 1) & ~1;
 }
-__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, bool krylov = false) {
+__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, bool krylov = false, int icpb = 1) {
   Lds l;
   l.buf0 = reinterpret_cast<double2*>(smem);
-  l.bstride = dbuf ? S.dim : 0;
+  l.bstride = dbuf ? S.dim * icpb : 0;
   const int tl = table_len(S);
-  const int nvec = (dbuf ? 2 : 1) + (blds ? 1 : 0);
-  l.bvec = l.buf0 + (dbuf ? 2 : 1) * (size_t)S.dim;
+  const int nvec = ((dbuf ? 2 : 1) + (blds ? 1 : 0)) * icpb;
+  l.bvec = l.buf0 + (dbuf ? 2 : 1) * (size_t)S.dim * icpb;
   l.tup = reinterpret_cast<double*>(l.buf0 + nvec * (size_t)S.dim);
   l.tdn = l.tup + tl;
   l.red = l.tdn + tl;
@@ -187,8 +212,8 @@ __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool 
   }
   return l;
 }
-static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, bool krylov = false) {
-  return sizeof(double2) * (size_t)S.dim * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
+static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, bool krylov = false, int icpb = 1) {
+  return sizeof(double2) * (size_t)S.dim * icpb * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
          sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64) +
          (krylov ? sizeof(double2) * (size_t)(GMRES_MR + 1) * S.dim + sizeof(double) * GMRES_NSC : 0);
 }
@@ -207,7 +232,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 // ---------------------------------------------------------------------------------------------
 // general stencil (runtime level counts)
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int EPT>
+template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct GenStencil {
   static constexpr int DB = (Q <= 4) ? 8 : 6;  // bits per packed digit (levels <= 255, or <= 63 for Q = 5)
   int it[EPT];         // storage index (clamped to dim-1 for slots beyond the vector)
@@ -235,7 +260,7 @@ struct GenStencil {
       }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int raw = (int)threadIdx.x + j * (int)blockDim.x;
+      const int raw = (int)threadIdx.x + (j % EPE) * (int)blockDim.x;  // slot j = (initial condition j / EPE, element j % EPE)
       valid[j] = raw < S.dim;
       it[j] = valid[j] ? raw : S.dim - 1;
       const int I = LIND ? it[j] % S.N : it[j];
@@ -314,8 +339,8 @@ struct GenStencil {
     const unsigned db = opaque(dbra[j]), dk = opaque(dket[j]);
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
     double l1r = 0.0, l1i = 0.0;  // T1 off-diagonal contribution
-    if (EPT == 1) {
-      // latency regime (one element per thread): all LDS reads first, then the arithmetic
+    if (EPE == 1) {
+      // latency regime (one element per thread and initial condition): all LDS reads first, then the arithmetic
       double2 xu[Q], xd[Q], xup[Q], xdp[Q], xl[Q];
       double su[Q], sd[Q], sup[Q], sdp[Q];
 #pragma unroll
@@ -439,14 +464,14 @@ __device__ __forceinline__ double flip_if(double v, unsigned cond) {  // cond ? 
   return __hiloint2double(__double2hiint(v) ^ (int)(cond << 31), __double2loint(v));
 }
 
-template <int Q, bool LIND, int EPT>
+template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct QubitStencil {
   int it[EPT];
   bool valid[EPT];  // only the single-wave variant can have idle lanes (dim < 64)
   double dw[EPT], dd[EPT];
   // latency regime (EPT == 1): loop invariants kept in registers instead of being re-derived from the
   // index bits in every operator application
-  static constexpr bool HOIST = (EPT == 1);
+  static constexpr bool HOIST = (EPE == 1);  // every slot of the thread is the SAME element (of different initial conditions)
   double l1f[HOIST ? Q : 1], l1t[HOIST ? Q : 1];  // T1 off-diagonal coefficient, forward / transposed
   double qb[HOIST ? Q : 1], qk[HOIST ? Q : 1];    // controls q_k with the bra / ket digit sign of this element
 
@@ -464,7 +489,7 @@ struct QubitStencil {
   __device__ __forceinline__ void init(const DevSys& S, const Lds&) {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int raw = (int)threadIdx.x + j * (int)blockDim.x;
+      const int raw = (int)threadIdx.x + (j % EPE) * (int)blockDim.x;  // slot j = (initial condition j / EPE, element j % EPE)
       valid[j] = raw < S.dim;
       it[j] = raw & (S.dim - 1);  // dim is a power of two
       double hd = 0.0, hdp = 0.0, d = 0.0;
@@ -610,16 +635,16 @@ struct QubitStencil {
   __device__ __forceinline__ bool is_guard(const DevSys&, int) const { return false; }  // nessential == nlevels == 2 ... see host check
 };
 
-template <int Q, bool LIND, int EPT, bool QUBIT>
-struct StencilSel { typedef GenStencil<Q, LIND, EPT> type; };
-template <int Q, bool LIND, int EPT>
-struct StencilSel<Q, LIND, EPT, true> { typedef QubitStencil<Q, LIND, EPT> type; };
+template <int Q, bool LIND, int EPT, int EPE, bool QUBIT>
+struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
+template <int Q, bool LIND, int EPT, int EPE>
+struct StencilSel<Q, LIND, EPT, EPE, true> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
 
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
-template <int Q, bool LIND, int EPT>
-__device__ __forceinline__ bool slot_valid(const GenStencil<Q, LIND, EPT>& st, int j) { return st.valid[j]; }
-template <int Q, bool LIND, int EPT>
-__device__ __forceinline__ bool slot_valid(const QubitStencil<Q, LIND, EPT>& st, int j) { return st.valid[j]; }
+template <int Q, bool LIND, int EPT, int EPE>
+__device__ __forceinline__ bool slot_valid(const GenStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
+template <int Q, bool LIND, int EPT, int EPE>
+__device__ __forceinline__ bool slot_valid(const QubitStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)
@@ -757,22 +782,36 @@ __device__ __forceinline__ void finalizeJ_diff(const DevTarget& tg, double re, d
 template <int Q, bool LIND, int VAR, bool QUBIT>
 struct Team {
   typedef Variant<VAR> V;
-  static constexpr int EPT = V::EPT;
-  typedef typename StencilSel<Q, LIND, EPT, QUBIT>::type ST;
+  static constexpr int EPT = V::EPT;    // slots per thread
+  static constexpr int ICPB = V::ICPB;  // initial conditions per workgroup (interleaved in the same threads)
+  static constexpr int EPE = EPT / ICPB;  // elements per thread of ONE initial condition
+  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT>::type ST;
   ST st;
   Lds L;
   int cur;      // which LDS buffer holds the vector that may be stencil-read
   int redslot;  // alternating reduction scratch slot
+  int dim;
+  int ic0;      // first initial condition of this workgroup
+  int nb;       // batch size
 
-  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, bool krylov = false) {
-    L = carve(smem, S, V::DBUF, V::BLDS, krylov);
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, int nbatch, bool krylov = false) {
+    L = carve(smem, S, V::DBUF, V::BLDS, krylov, ICPB);
     st.init(S, L);
     cur = 0;
     redslot = 0;
+    dim = S.dim;
+    nb = nbatch;
+    ic0 = blockIdx.x * ICPB;
   }
-  __device__ __forceinline__ bool ok(int j) const { return slot_valid(st, j); }
+  // slot j belongs to initial condition ic(j); a workgroup past the end of the batch re-reads the last one
+  __device__ __forceinline__ int icslot(int j) const { return j / EPE; }
+  __device__ __forceinline__ bool icvalid(int s) const { return ICPB == 1 || ic0 + s < nb; }  // ICPB == 1: grid == batch
+  __device__ __forceinline__ int ic(int j) const { return ICPB == 1 ? ic0 : min(ic0 + icslot(j), nb - 1); }
+  __device__ __forceinline__ bool ok(int j) const { return slot_valid(st, j) && icvalid(icslot(j)); }
   __device__ __forceinline__ double2* bufp(int b) const { return L.buf0 + b * L.bstride; }
   __device__ __forceinline__ const double2* vec() const { return bufp(cur); }
+  __device__ __forceinline__ const double2* vecj(int j) const { return bufp(cur) + icslot(j) * dim; }
+  __device__ __forceinline__ int lidx(int j) const { return icslot(j) * dim + st.it[j]; }  // LDS index of slot j
 
   template <int NV>
   __device__ __forceinline__ void sum(double (&v)[NV]) {
@@ -787,6 +826,13 @@ struct Team {
     return block_sum_f32<V::ONEWAVE>(v, red);
   }
 
+  template <int NV>
+  __device__ __forceinline__ void sum_f32v(float (&v)[NV]) {
+    double* red = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
+    redslot ^= 1;
+    block_sum_f32v<NV, V::ONEWAVE>(v, red);
+  }
+
   // Make `x` the stencil-readable vector.  Single buffer: a barrier before the overwrite (every
   // thread finished reading the old content) and one after; double buffer: only the one after.
   __device__ __forceinline__ void publish(const double2 (&x)[EPT]) {
@@ -794,7 +840,7 @@ struct Team {
     const int nxt = V::DBUF ? cur ^ 1 : cur;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-      if (ok(j)) bufp(nxt)[st.it[j]] = x[j];
+      if (ok(j)) bufp(nxt)[lidx(j)] = x[j];
     cur = nxt;
     team_sync<V::ONEWAVE>();
   }
@@ -803,7 +849,7 @@ struct Team {
   __device__ __forceinline__ void apply_all(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      y[j] = st.template apply<TRANS>(S, L, vec(), c, j, x[j]);
+      y[j] = st.template apply<TRANS>(S, L, vecj(j), c, j, x[j]);
     }
   }
 
@@ -815,7 +861,7 @@ struct Team {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       y[j] = b[j];
-      if (V::BLDS && ok(j)) L.bvec[st.it[j]] = b[j];  // read back by the owning thread only: no barrier needed
+      if (V::BLDS && ok(j)) L.bvec[lidx(j)] = b[j];  // read back by the owning thread only: no barrier needed
     }
     publish(y);
     // Stopping test of the reference (timestepper.cpp:713-720) on squared norms: errnorm < abstol  <=>
@@ -829,28 +875,42 @@ struct Team {
     float d0 = 1.f;
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
-      double dloc = 0.0;
+      double dloc[ICPB];
+#pragma unroll
+      for (int q = 0; q < ICPB; q++) dloc[q] = 0.0;
       const double2* src = vec();
       if (V::DBUF) cur ^= 1;  // the new iterate goes to the other buffer: ONE barrier (inside the reduction)
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const double2 t = st.template apply<TRANS>(A.S, L, src, c, j, y[j]);
-        const double2 bj = V::BLDS ? L.bvec[st.it[j]] : b[j];
+        const double2 t = st.template apply<TRANS>(A.S, L, src + icslot(j) * dim, c, j, y[j]);
+        const double2 bj = V::BLDS ? L.bvec[lidx(j)] : b[j];
         double2 w;
         w.x = fma(alpha, t.x, bj.x);
         w.y = fma(alpha, t.y, bj.y);
         const double dx = y[j].x - w.x, dy = y[j].y - w.y;
-        dloc += ok(j) ? dx * dx + dy * dy : 0.0;
+        dloc[icslot(j)] += ok(j) ? dx * dx + dy * dy : 0.0;
         y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
-        if (V::DBUF && ok(j)) bufp(cur)[st.it[j]] = w;
+        if (V::DBUF && ok(j)) bufp(cur)[lidx(j)] = w;
       }
       // clamp: adjoint solves of badly scaled problems have update norms whose square overflows fp32; a
-      // clamped value is still far above both thresholds (the reference's reltol is 1e-20)
-      const float d = sum_f32((float)fmin(dloc * inv_abs2, 1e30));  // contains the barrier (multi-wave)
+      // clamped value is still far above both thresholds (the reference's reltol is 1e-20).  With several
+      // initial conditions per workgroup all of them iterate until the slowest has converged (the others
+      // only get more accurate).
+      float d = 0.f;
+      if (ICPB == 1) {
+        d = sum_f32((float)fmin(dloc[0] * inv_abs2, 1e30));  // contains the barrier (multi-wave)
+      } else {
+        float dq[ICPB];
+#pragma unroll
+        for (int q = 0; q < ICPB; q++) dq[q] = (float)fmin(dloc[q] * inv_abs2, 1e30);
+        sum_f32v<ICPB>(dq);
+#pragma unroll
+        for (int q = 0; q < ICPB; q++) d = fmaxf(d, dq[q]);
+      }
       if (!V::DBUF) {
 #pragma unroll
         for (int j = 0; j < EPT; j++)
-          if (ok(j)) bufp(cur)[st.it[j]] = y[j];
+          if (ok(j)) bufp(cur)[lidx(j)] = y[j];
         team_sync<V::ONEWAVE>();
       }
       if (iter == 0) d0 = d;
@@ -890,7 +950,7 @@ struct Team {
       if (beta <= ttol || its >= A.maxiter) break;
       double2 v = make_double2(r.x / beta, r.y / beta);
       if (on) Vb[e] = v;
-      g[0] = beta;
+      double gcur = beta;  // last entry of the rotated right-hand side
       team_sync<V::ONEWAVE>();
       int j = 0;
       bool conv = false;
@@ -925,26 +985,28 @@ struct Team {
         hc[j + 1] = hn;
         v = hn > 0.0 ? make_double2(w.x / hn, w.y / hn) : make_double2(0.0, 0.0);
         if (on) Vb[(size_t)(j + 1) * dim + e] = v;
-        // Givens rotations on the new column, update of the rotated right-hand side
+        // Givens rotations on the new column, update of the rotated right-hand side.  Every thread does
+        // this redundantly on wave-uniform values; LDS locations are only ever written with values that
+        // do not depend on an earlier write of the same phase (no read-modify-write), so waves of one
+        // workgroup cannot observe each other's partial updates.
+        double cur_h = hc[0];
         for (int k = 0; k < j; k++) {
-          const double a0 = hc[k], a1 = hc[k + 1], ck = cs[k], sk = sn[k];
-          hc[k] = ck * a0 + sk * a1;
-          hc[k + 1] = -sk * a0 + ck * a1;
+          const double a1 = hc[k + 1], ck = cs[k], sk = sn[k];
+          R[k * GMRES_MR + j] = ck * cur_h + sk * a1;
+          cur_h = -sk * cur_h + ck * a1;
         }
-        const double a = hc[j], bb = hc[j + 1];
+        const double a = cur_h, bb = hn;
         const double rr = sqrt(a * a + bb * bb);
         const double cj = rr == 0.0 ? 1.0 : a / rr, sj = rr == 0.0 ? 0.0 : bb / rr;
         cs[j] = cj;
         sn[j] = sj;
-        hc[j] = rr;
-        const double gj = g[j];
-        g[j + 1] = -sj * gj;
-        g[j] = cj * gj;
-        for (int k = 0; k <= j; k++) R[k * GMRES_MR + j] = hc[k];
+        R[j * GMRES_MR + j] = rr;
+        g[j] = cj * gcur;
+        gcur = -sj * gcur;
         its++;
         j++;
         team_sync<V::ONEWAVE>();  // v_{j} is readable by every thread
-        if (fabs(g[j]) <= ttol || hn == 0.0) { conv = true; break; }
+        if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter) break;
       }
       // back substitution R yk = g, y += V yk
@@ -989,15 +1051,17 @@ template <int Q, bool LIND, int VAR, bool QUBIT>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team<Q, LIND, VAR, QUBIT> TM;
-  constexpr int EPT = TM::EPT;
+  constexpr int EPT = TM::EPT, ICPB = TM::ICPB;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem, A.use_gmres != 0);
-  const int b = blockIdx.x, dim = S.dim;
+  tm.init(S, smem, A.nb, A.use_gmres != 0);
+  const int dim = S.dim;
   double2 x[EPT];
-  const double* x0 = A.x0 + (size_t)b * 2 * dim;
 #pragma unroll
-  for (int j = 0; j < EPT; j++) x[j] = make_double2(x0[tm.st.it[j]], x0[dim + tm.st.it[j]]);
+  for (int j = 0; j < EPT; j++) {
+    const double* x0 = A.x0 + (size_t)tm.ic(j) * 2 * dim;
+    x[j] = make_double2(x0[tm.st.it[j]], x0[dim + tm.st.it[j]]);
+  }
   team_sync<TM::V::ONEWAVE>();  // coefficient tables written by init()
   tm.publish(x);
   // penalty bookkeeping
@@ -1010,8 +1074,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   const bool jpairs = S.npairs > 0;
   bool guard[EPT];
 #pragma unroll
-  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.st.is_guard(S, j);
-  double pen_local = 0.0, dpdm_local = 0.0, pen_uniform = 0.0;
+  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.ok(j) && tm.st.is_guard(S, j);
+  double pen_local[ICPB], dpdm_local[ICPB], pen_uniform[ICPB];
+#pragma unroll
+  for (int q = 0; q < ICPB; q++) pen_local[q] = dpdm_local[q] = pen_uniform[q] = 0.0;
   double2 xm1[EPT], xm2[EPT];  // dpdm history (x_n, x_{n-1})
 #pragma unroll
   for (int j = 0; j < EPT; j++) xm1[j] = xm2[j] = x[j];
@@ -1026,10 +1092,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
     if (s + 1 < A.nsub) load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, cn, jpairs);  // prefetch the next row
     tm.st.prep(c);
     if (traj) {
-      double* dst = traj + ((size_t)s * A.nb + b) * 2 * dim;
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (tm.ok(j)) {
+          double* dst = traj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
           dst[tm.st.it[j]] = x[j].x;
           dst[dim + tm.st.it[j]] = x[j].y;
         }
@@ -1066,28 +1132,32 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
           weight = 1.0 / A.penalty_param * exp(-(a * a));
         }
         if (wj_reduce) {
-          double v[2] = {0.0, 0.0};
+          double v[2 * ICPB];
+#pragma unroll
+          for (int q = 0; q < 2 * ICPB; q++) v[q] = 0.0;
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, b, tm.st.it[j], x[j], v[0], v[1]);
-          tm.template sum<2>(v);
-          pen_uniform += weight * finalizeJ<LIND>(A.tg, v[0], v[1]) * A.dt;
+            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], x[j], v[2 * tm.icslot(j)], v[2 * tm.icslot(j) + 1]);
+          tm.template sum<2 * ICPB>(v);
+#pragma unroll
+          for (int q = 0; q < ICPB; q++) pen_uniform[q] += weight * finalizeJ<LIND>(A.tg, v[2 * q], v[2 * q + 1]) * A.dt;
         } else if (wj_on) {
-          double jr = 0.0, ji = 0.0;
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, b, tm.st.it[j], x[j], jr, ji);
-          // finalizeJ is affine here: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Lindblad Jtrace)
+            if (tm.ok(j)) {
+              double jr = 0.0, ji = 0.0;
+              evalJ_part<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], x[j], jr, ji);
+              // finalizeJ is affine here: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Lindblad Jtrace)
+              pen_local[tm.icslot(j)] += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
+            }
           if (A.tg.objective_type == QD_OBJ_JTRACE) {
-            pen_local -= weight * A.dt * jr;
-            pen_uniform += weight * A.dt;
-          } else {
-            pen_local += weight * A.dt * jr;
+#pragma unroll
+            for (int q = 0; q < ICPB; q++) pen_uniform[q] += weight * A.dt;
           }
         }
 #pragma unroll
         for (int j = 0; j < EPT; j++)
-          if (guard[j]) pen_local += (x[j].x * x[j].x + x[j].y * x[j].y) / A.ntime;
+          if (guard[j]) pen_local[tm.icslot(j)] += (x[j].x * x[j].x + x[j].y * x[j].y) / A.ntime;
       }
       if (dpdm_on) {
         if (n > 0) {
@@ -1096,7 +1166,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
             if (tm.ok(j)) {
               const double t1 = x[j].x * x[j].x - 2.0 * xm1[j].x * xm1[j].x + xm2[j].x * xm2[j].x;
               const double t2 = x[j].y * x[j].y - 2.0 * xm1[j].y * xm1[j].y + xm2[j].y * xm2[j].y;
-              dpdm_local += dtinv4 * (t1 + t2) * (t1 + t2);
+              dpdm_local[tm.icslot(j)] += dtinv4 * (t1 + t2) * (t1 + t2);
             }
         }
 #pragma unroll
@@ -1108,24 +1178,35 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
     }
   }
   // final state (+ last trajectory slot)
-  double* xT = A.xT + (size_t)b * 2 * dim;
-  double* dst = traj ? traj + ((size_t)A.nsub * A.nb + b) * 2 * dim : nullptr;
 #pragma unroll
   for (int j = 0; j < EPT; j++)
     if (tm.ok(j)) {
+      double* xT = A.xT + (size_t)tm.ic(j) * 2 * dim;
       xT[tm.st.it[j]] = x[j].x;
       xT[dim + tm.st.it[j]] = x[j].y;
-      if (dst) {
+      if (traj) {
+        double* dst = traj + ((size_t)A.nsub * A.nb + tm.ic(j)) * 2 * dim;
         dst[tm.st.it[j]] = x[j].x;
         dst[dim + tm.st.it[j]] = x[j].y;
       }
     }
-  double v[2] = {pen_local, dpdm_local};
-  tm.template sum<2>(v);
+  double v[2 * ICPB];
+#pragma unroll
+  for (int q = 0; q < ICPB; q++) {
+    v[2 * q] = pen_local[q];
+    v[2 * q + 1] = dpdm_local[q];
+  }
+  tm.template sum<2 * ICPB>(v);
   if (threadIdx.x == 0) {
-    A.pen_out[b] = v[0] + pen_uniform;
-    A.dpdm_out[b] = v[1] / A.ntime;
-    atomicAdd(A.napply, napply);
+    int nvalid = 0;
+#pragma unroll
+    for (int q = 0; q < ICPB; q++)
+      if (tm.icvalid(q)) {
+        A.pen_out[tm.ic0 + q] = v[2 * q] + pen_uniform[q];
+        A.dpdm_out[tm.ic0 + q] = v[2 * q + 1] / A.ntime;
+        nvalid++;
+      }
+    atomicAdd(A.napply, napply * nvalid);
   }
 }
 
@@ -1138,24 +1219,34 @@ template <int Q, bool LIND, int VAR, bool QUBIT>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team<Q, LIND, VAR, QUBIT> TM;
-  constexpr int EPT = TM::EPT;
+  constexpr int EPT = TM::EPT, ICPB = TM::ICPB;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem, A.use_gmres != 0);
+  tm.init(S, smem, A.nb, A.use_gmres != 0);
   team_sync<TM::V::ONEWAVE>();
-  const int b = blockIdx.x, dim = S.dim;
+  const int dim = S.dim;
   double2 xb[EPT], xn[EPT];  // adjoint state, primal state x_n (end of the step being reversed)
-  const double* xbT = A.xbarT + (size_t)b * 2 * dim;
   const double* traj = A.traj;
   auto load_state = [&](int s, double2(&dst)[EPT]) {
-    const double* src = traj + ((size_t)s * A.nb + b) * 2 * dim;
 #pragma unroll
-    for (int j = 0; j < EPT; j++) dst[j] = make_double2(src[tm.st.it[j]], src[dim + tm.st.it[j]]);
+    for (int j = 0; j < EPT; j++) {
+      const double* src = traj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
+      dst[j] = make_double2(src[tm.st.it[j]], src[dim + tm.st.it[j]]);
+    }
   };
 #pragma unroll
-  for (int j = 0; j < EPT; j++) xb[j] = make_double2(xbT[tm.st.it[j]], xbT[dim + tm.st.it[j]]);
+  for (int j = 0; j < EPT; j++) {
+    const double* xbT = A.xbarT + (size_t)tm.ic(j) * 2 * dim;
+    xb[j] = make_double2(xbT[tm.st.it[j]], xbT[dim + tm.st.it[j]]);
+  }
   load_state(A.nsub, xn);
-  const double jbar_pen = A.jbar[b * 3 + 0], jbar_dpdm = A.jbar[b * 3 + 1];
+  double jbar_pen[ICPB], jbar_dpdm[ICPB];
+#pragma unroll
+  for (int q = 0; q < ICPB; q++) {
+    const int bq = min(tm.ic0 + q, A.nb - 1);
+    jbar_pen[q] = A.jbar[bq * 3 + 0];
+    jbar_dpdm[q] = A.jbar[bq * 3 + 1];
+  }
   const bool pen_on = A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
@@ -1163,7 +1254,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   const bool jpairs = S.npairs > 0;
   bool guard[EPT];
 #pragma unroll
-  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.st.is_guard(S, j);
+  for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.ok(j) && tm.st.is_guard(S, j);
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
   const int ntime = A.ntime;
   double2 x[EPT], xnext[EPT];
@@ -1178,7 +1269,6 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       const int n = (s + 1) / A.nstages;
       const double tstop = n * A.dt;
       if (dpdm_on) {  // penaltyDpDm_diff (timestepper.cpp:372-442); all five states come from HBM
-        const double Jb = jbar_dpdm / ntime;
         double2 m2[EPT], m1[EPT], p1[EPT], p2[EPT];
         if (n > 1) load_state((n - 2) * A.nstages, m2);
         if (n > 0) load_state((n - 1) * A.nstages, m1);
@@ -1186,6 +1276,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         if (n < ntime - 1) load_state((n + 2) * A.nstages, p2);
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
+          const double Jb = jbar_dpdm[tm.icslot(j)] / ntime;
           const double xr = xn[j].x, xi = xn[j].y;
           double acc = 0.0;
           if (n > 1) {
@@ -1211,37 +1302,54 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         if (wj_on) {
           const double a = (tstop - A.Tfinal) / A.penalty_param;
           const double weight = 1.0 / A.penalty_param * exp(-(a * a));
-          double rb = 1.0, ib = 0.0;
+          double rb[ICPB], ib[ICPB];
           if (wj_reduce) {
-            double v[2] = {0.0, 0.0};
+            double v[2 * ICPB];
+#pragma unroll
+            for (int q = 0; q < 2 * ICPB; q++) v[q] = 0.0;
 #pragma unroll
             for (int j = 0; j < EPT; j++)
-              if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, b, tm.st.it[j], xn[j], v[0], v[1]);
-            tm.template sum<2>(v);
-            finalizeJ_diff<LIND>(A.tg, v[0], v[1], rb, ib);
+              if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], xn[j], v[2 * tm.icslot(j)], v[2 * tm.icslot(j) + 1]);
+            tm.template sum<2 * ICPB>(v);
+#pragma unroll
+            for (int q = 0; q < ICPB; q++) finalizeJ_diff<LIND>(A.tg, v[2 * q], v[2 * q + 1], rb[q], ib[q]);
           } else {
-            finalizeJ_diff<LIND>(A.tg, 0.0, 0.0, rb, ib);
+#pragma unroll
+            for (int q = 0; q < ICPB; q++) finalizeJ_diff<LIND>(A.tg, 0.0, 0.0, rb[q], ib[q]);
           }
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (tm.ok(j))
-              evalJ_diff_elem<LIND>(S, A.tg, b, tm.st.it[j], xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+            if (tm.ok(j)) {
+              const int q = tm.icslot(j);
+              evalJ_diff_elem<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], xn[j], xb[j], weight * rb[q] * jbar_pen[q] * A.dt,
+                                    weight * ib[q] * jbar_pen[q] * A.dt);
+            }
         }
 #pragma unroll
         for (int j = 0; j < EPT; j++)
           if (guard[j]) {
-            xb[j].x += 2.0 * xn[j].x * jbar_pen / ntime;
-            xb[j].y += 2.0 * xn[j].y * jbar_pen / ntime;
+            xb[j].x += 2.0 * xn[j].x * jbar_pen[tm.icslot(j)] / ntime;
+            xb[j].y += 2.0 * xn[j].y * jbar_pen[tm.icslot(j)] / ntime;
           }
       }
     }
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     tm.st.prep(c);
-    double* co = A.coeff + ((size_t)b * A.nsub + s) * 2 * Q;
-    double cf[2 * Q];
+    double cf[2 * Q * ICPB];
 #pragma unroll
-    for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
+    for (int i = 0; i < 2 * Q * ICPB; i++) cf[i] = 0.0;
+    auto store_coeffs = [&]() {
+      tm.template sum<2 * Q * ICPB>(cf);
+#pragma unroll
+      for (int q = 0; q < ICPB; q++)
+        if (tm.icvalid(q)) {
+          double* co = A.coeff + ((size_t)(tm.ic0 + q) * A.nsub + s) * 2 * Q;
+#pragma unroll
+          for (int i = 0; i < 2 * Q; i++)
+            if (threadIdx.x == i) co[i] = cf[q * 2 * Q + i];
+        }
+    };
     if (A.stepper_ee) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt * x_adj against x_{n-1}, then
       // x_adj += dt M(tstop)^T x_adj.  The table row of sub-step s holds M(tstart); M(tstop) is row s+1
@@ -1253,15 +1361,12 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 #pragma unroll
           for (int k = 0; k < Q; k++) {
             double2 Av, Bv;
-            tm.st.ladder(S, tm.L, tm.vec(), k, j, Av, Bv);
-            cf[2 * k] += c.h * (Bv.y * xb[j].x - Bv.x * xb[j].y);
-            cf[2 * k + 1] += c.h * (Av.x * xb[j].x + Av.y * xb[j].y);
+            tm.st.ladder(S, tm.L, tm.vecj(j), k, j, Av, Bv);
+            cf[tm.icslot(j) * 2 * Q + 2 * k] += c.h * (Bv.y * xb[j].x - Bv.x * xb[j].y);
+            cf[tm.icslot(j) * 2 * Q + 2 * k + 1] += c.h * (Av.x * xb[j].x + Av.y * xb[j].y);
           }
         }
-      tm.template sum<2 * Q>(cf);
-#pragma unroll
-      for (int i = 0; i < 2 * Q; i++)
-        if (threadIdx.x == i) co[i] = cf[i];
+      store_coeffs();
       StepC<Q> c1;
       load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
       tm.st.prep(c1);
@@ -1302,15 +1407,12 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 #pragma unroll
           for (int k = 0; k < Q; k++) {
             double2 Av, Bv;
-            tm.st.ladder(S, tm.L, tm.vec(), k, j, Av, Bv);
-            cf[2 * k] += Bv.y * kb[j].x - Bv.x * kb[j].y;
-            cf[2 * k + 1] += Av.x * kb[j].x + Av.y * kb[j].y;
+            tm.st.ladder(S, tm.L, tm.vecj(j), k, j, Av, Bv);
+            cf[tm.icslot(j) * 2 * Q + 2 * k] += Bv.y * kb[j].x - Bv.x * kb[j].y;
+            cf[tm.icslot(j) * 2 * Q + 2 * k + 1] += Av.x * kb[j].x + Av.y * kb[j].y;
           }
         }
-      tm.template sum<2 * Q>(cf);
-#pragma unroll
-      for (int i = 0; i < 2 * Q; i++)
-        if (threadIdx.x == i) co[i] = cf[i];
+      store_coeffs();
       // xbar += M^T kbar
       tm.publish(kb);
       double2 t[EPT];
@@ -1325,10 +1427,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     for (int j = 0; j < EPT; j++) xn[j] = x[j];
   }
   if (A.xbar0) {
-    double* d0 = A.xbar0 + (size_t)b * 2 * dim;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (tm.ok(j)) {
+        double* d0 = A.xbar0 + (size_t)tm.ic(j) * 2 * dim;
         d0[tm.st.it[j]] = xb[j].x;
         d0[dim + tm.st.it[j]] = xb[j].y;
       }
@@ -1340,17 +1442,19 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 // ---------------------------------------------------------------------------------------------
 template <int Q, bool LIND, int VAR, bool QUBIT>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_apply(const DevSys S, const double* __restrict__ ctlrow, int transpose,
-                                                               const double* __restrict__ xin, double* __restrict__ yout) {
+                                                               const double* __restrict__ xin, double* __restrict__ yout, int nb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team<Q, LIND, VAR, QUBIT> TM;
   constexpr int EPT = TM::EPT;
   TM tm;
-  tm.init(S, smem);
-  const int b = blockIdx.x, dim = S.dim;
+  tm.init(S, smem, nb);
+  const int dim = S.dim;
   double2 x[EPT], y[EPT];
-  const double* x0 = xin + (size_t)b * 2 * dim;
 #pragma unroll
-  for (int j = 0; j < EPT; j++) x[j] = make_double2(x0[tm.st.it[j]], x0[dim + tm.st.it[j]]);
+  for (int j = 0; j < EPT; j++) {
+    const double* x0 = xin + (size_t)tm.ic(j) * 2 * dim;
+    x[j] = make_double2(x0[tm.st.it[j]], x0[dim + tm.st.it[j]]);
+  }
   team_sync<TM::V::ONEWAVE>();
   tm.publish(x);
   StepC<Q> c;
@@ -1358,10 +1462,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_apply(const DevSys S, co
   tm.st.prep(c);
   if (transpose) tm.template apply_all<true>(S, c, x, y);
   else tm.template apply_all<false>(S, c, x, y);
-  double* yo = yout + (size_t)b * 2 * dim;
 #pragma unroll
   for (int j = 0; j < EPT; j++)
     if (tm.ok(j)) {
+      double* yo = yout + (size_t)tm.ic(j) * 2 * dim;
       yo[tm.st.it[j]] = y[j].x;
       yo[dim + tm.st.it[j]] = y[j].y;
     }

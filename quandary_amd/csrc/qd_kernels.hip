@@ -216,11 +216,16 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 // spread one state over as many lanes as it has elements.  Many initial conditions (throughput
 // regime): more elements per thread so that several workgroups share a CU.
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
+  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2};
+  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256};
+  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true};
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
   c.qubit = qubit ? 1 : 0;
+  const bool gm = want_gmres && !getenv("QD_FORCE_NEUMANN");
+  auto fits = [&](int v) { return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v]; };
   int var;
   if (dim <= 64) var = 0;
   else if (dim <= 256) var = 1;
@@ -228,22 +233,22 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   else var = 4;
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
-    if (v >= 0 && v < NVARIANTS) var = v;
+    if (v >= 0 && v < 6 && fits(v)) var = v;
   }
-  auto fits = [&](int v) {
-    static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1}, maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024};
-    return (dim + ept[v] - 1) / ept[v] <= maxb[v];
-  };
   if (!fits(var)) var = dim <= 64 ? 0 : dim <= 256 ? 1 : dim <= 1024 ? 2 : 4;
-  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1};
-  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true};
-  static const bool blds[NVARIANTS] = {false, false, false, false, false, false};
+  if (qubit) {  // the qubit translation units only build the variants that match their fixed dimension
+    const bool okv = dim <= 64 ? var == 0 : dim <= 256 ? var == 1 : (var == 2 || var == 5);
+    if (!okv) var = dim <= 64 ? 0 : dim <= 256 ? 1 : 2;
+  } else if (var == 5) {
+    var = 2;
+  }
+  const int epe = ept[var] / icpb[var];
   c.var = var;
-  c.block = ((dim + ept[var] - 1) / ept[var] + 63) / 64 * 64;
+  c.block = ((dim + epe - 1) / epe + 63) / 64 * 64;
   c.gmres = 0;
-  c.lds = lds_bytes(S, c.block, dbuf[var], blds[var], false);
-  if (want_gmres && ept[var] == 1 && !getenv("QD_FORCE_NEUMANN")) {
-    const size_t with = lds_bytes(S, c.block, dbuf[var], blds[var], true);
+  c.lds = lds_bytes(S, c.block, dbuf[var], false, false, icpb[var]);
+  if (gm && ept[var] == 1) {
+    const size_t with = lds_bytes(S, c.block, dbuf[var], false, true, icpb[var]);
     if (with <= 160 * 1024) {
       c.gmres = 1;
       c.lds = with;
