@@ -214,6 +214,52 @@ def test_two_rank_sharding_matches_single_rank():
     h.close()
 
 
+def test_stepper_level_forward_and_adjoint_with_host_seeds():
+    """qd_forward / qd_adjoint (host-pointer entry points = solveODE / solveAdjointODE for a batch):
+    seed the adjoint with an arbitrary cotangent and compare the gradient with finite differences of
+    <seed, x_T(alpha)> computed by the oracle's forward sweep."""
+    sp, h, orc = _pair(dict(nlevels=[3, 2], lindblad=True, jkl=0.01, detuned=True, target="pure", objective="Jmeasure"), ntime=16)
+    opt = capi.Optim(h, sp)
+    nb = opt.ninit_local
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(nb)])
+    rng = np.random.default_rng(5)
+    seed = rng.standard_normal(x0.shape)
+    h.set_params(sp.params0)
+    res = h.forward(x0, store_trajectory=True)
+    g = h.adjoint(seed, np.zeros((nb, 3)))
+    _, _, fin = orc.evalF(sp.params0, want_final=True)
+    np.testing.assert_allclose(res["final_states"], fin, rtol=0, atol=1e-9)
+
+    def phi(a):
+        return float(np.sum(seed * orc.evalF(a, want_final=True)[2]))
+
+    for i in rng.choice(sp.params0.size, 3, replace=False):
+        e = np.zeros_like(sp.params0)
+        e[i] = 1e-5
+        fd = (phi(sp.params0 + e) - phi(sp.params0 - e)) / 2e-5
+        assert g[i] == pytest.approx(fd, rel=2e-5, abs=1e-9)
+    opt.close(); h.close(); orc.close()
+
+
+def test_largest_supported_state():
+    """dim = 4096 (8x8 Lindblad): the largest state of the single-workgroup kernels, 8 elements/thread."""
+    sp, h, orc = _pair(dict(nlevels=[8, 8], lindblad=True, target="pure", objective="Jmeasure", init="pure, 1, 2"), ntime=4, nspline=6)
+    assert h.dim == 4096
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
+def test_unsupported_sizes_fail_loudly():
+    sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0")  # dim 6561
+    with pytest.raises(capi.QuandaryAmdError, match="4096"):
+        capi.Handle(sp)
+
+
 def test_error_paths():
     sp = synthetic_spec([2, 2], lindblad=False, ntime=5)
     h = capi.Handle(sp)
