@@ -260,6 +260,23 @@ def test_unsupported_sizes_fail_loudly():
         capi.Handle(sp)
 
 
+def test_chunked_adjoint_when_trajectory_does_not_fit(monkeypatch):
+    """A shard whose stored trajectory exceeds HBM is re-propagated and reversed in chunks
+    (qd_optim_adjoint_local); the budget is faked through QD_TRAJ_BUDGET_MB."""
+    sp = synthetic_spec([2, 2], lindblad=True, ntime=20, penalties=True)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    # one trajectory = 21 states x 16 initial conditions x 32 doubles = 86 kB; allow ~5 initial conditions
+    monkeypatch.setenv("QD_TRAJ_BUDGET_MB", str(21 * 5 * 32 * 8 / 1048576.0))
+    val2, g2 = opt.evalGradF(sp.params0)
+    monkeypatch.delenv("QD_TRAJ_BUDGET_MB")
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-13, abs=1e-15), k
+    np.testing.assert_allclose(g2, g, rtol=1e-11, atol=1e-15)
+    opt.close(); h.close()
+
+
 def test_error_paths():
     sp = synthetic_spec([2, 2], lindblad=False, ntime=5)
     h = capi.Handle(sp)
