@@ -5,9 +5,19 @@ A "step" is one pass of the hot path over one batch of synthetic input: one forw
 (OptimProblem::evalF) of ALL initial conditions of the workload through all ntime time steps
 (`--mode grad`: forward + adjoint + gradient, OptimProblem::evalGradF).  Metric (BASELINE.json):
 Lindblad time-steps x initial-conditions per second, whole job.  Default workload = BASELINE.json
-configs[1] (C2: 2x2x2 Lindblad, T1/T2, 64 basis initial conditions, fp64).  With N > 1 ranks the
-initial conditions are sharded contiguously over the GPUs (strong scaling: total work fixed) and the
-seven objective sums / the gradient are all-reduced with RCCL (torch.distributed backend "nccl").
+configs[1] (C2: 2x2x2 Lindblad, T1/T2, 64 basis initial conditions, fp64).
+
+N > 1 ranks, one per GPU; the path shards over initial conditions (independent units) with the
+reference's two exchange steps: the seven objective sums and the gradient are all-reduced with RCCL
+(torch.distributed backend "nccl").
+  --scaling weak   (default) every GPU propagates one full set of the workload's initial conditions;
+                   the batch is the basis replicated N times, the objective is the mean over all
+                   N x ninit members (so the value equals the 1-GPU objective).  A single C2-sized
+                   basis (64 workgroups) does not even fill one MI355X (256 CUs), so dividing it
+                   further only idles GPUs; per-GPU work fixed is the meaningful multi-GPU regime here.
+  --scaling strong the reference's np_init decomposition (src/main.cpp:133-160): the ninit initial
+                   conditions are split contiguously over the ranks, total work fixed (use with the
+                   large batches: --workload c4 / c5).
 
 Prints ONE JSON line on rank 0.
 """
@@ -86,6 +96,28 @@ def cpu_baseline(spec, mode, target_wall_s=3.0):
     }
 
 
+def flops_per_apply(spec):
+    """Canonical fp64 operation count of one y = M x: diagonal 6, each ladder neighbour 8,
+    T1 off-diagonal 4, each dipole-dipole neighbour 8; Schroedinger has no ket side."""
+    sy = spec.system
+    Q = sy.nosc
+    lind = sy.lindblad_type != 0
+    n = [sy.nlevels[k] for k in range(Q)]
+    per = 6.0
+    for k in range(Q):
+        frac = (n[k] - 1.0) / n[k]
+        per += (32.0 if lind else 16.0) * frac
+        if lind and sy.lindblad_type in (1, 3) and sy.decay_time[k] > 0:
+            per += 4.0 * frac * frac
+    pair = 0
+    for k in range(Q):
+        for l in range(k + 1, Q):
+            if abs(sy.Jkl[pair]) > 1e-10:
+                per += (32.0 if lind else 16.0) * ((n[k] - 1.0) / n[k]) * ((n[l] - 1.0) / n[l])
+            pair += 1
+    return per * spec.dim
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +128,8 @@ def main():
     ap.add_argument("--linsolve", default=None, choices=[None, "neumann", "gmres"])
     ap.add_argument("--ntime", type=int, default=None, help="override the number of time steps of the workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one full set of initial conditions per GPU (default); strong = split the set over the GPUs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo lets several ranks share one GPU for testing")
     args = ap.parse_args()
@@ -136,12 +170,17 @@ def main():
     if args.ntime:
         over["ntime"] = args.ntime
     spec = workload_spec(args.workload, mode, over)
-    if spec.ninit % world:
+    weak = world > 1 and args.scaling == "weak"
+    if not weak and spec.ninit % world:
         raise SystemExit(f"number of GPUs ({world}) must divide the number of initial conditions ({spec.ninit})")
 
     handle = capi.Handle(spec, device=local_rank)   # raises loudly without the HIP library / a GPU
-    optim = capi.Optim(handle, spec, rank=rank, nranks=world)
-    obj = DistributedObjective(optim, dist, red_dev)
+    if weak:
+        optim = capi.Optim(handle, spec, rank=0, nranks=1)   # the whole set on every GPU
+        obj = DistributedObjective(optim, dist, red_dev, replicas=world)
+    else:
+        optim = capi.Optim(handle, spec, rank=rank, nranks=world)
+        obj = DistributedObjective(optim, dist, red_dev)
     alpha = spec.params0
 
     def one_step():
@@ -174,15 +213,27 @@ def main():
         elapsed, kern_ms = float(t[0]), float(t[1])
 
     ntime, ninit, dim = spec.time.ntime, spec.ninit, spec.dim
-    units_total = ninit * ntime * args.steps
+    ninit_local = ninit if weak else ninit // world
+    ninit_global = ninit_local * world
+    units_total = ninit_global * ntime * args.steps
     value = units_total / elapsed
     # roofline of the dominant kernel (k_forward / k_forward + k_adjoint): algorithmic HBM bytes per
     # (time step x initial condition) = 32*dim (forward: read + write the state once per step, fp64) or
     # 96*dim (forward + adjoint); units per launch = local initial conditions x ntime.
     alg_bytes = (32 if args.mode == "fwd" else 96) * dim
-    units_per_launch = (ninit // world) * ntime
+    units_per_launch = ninit_local * ntime
     kern_s = kern_ms / 1e3 / args.steps
     achieved = alg_bytes * units_per_launch / kern_s / 1e9
+    # secondary roofline: canonical fp64 flops of the fused step against the MEASURED
+    # v_fma_f64 rate of this device (the state never leaves the CU between steps, so for the small
+    # systems the HBM figure above only says "not HBM bound")
+    mean_applies = applies / args.steps
+    f_apply = flops_per_apply(spec)
+    f_step = mean_applies * f_apply + (12.0 * max(mean_applies - 1.0, 0.0) + 4.0) * dim
+    if args.mode == "grad":
+        f_step *= 3.0  # adjoint step = two more solves of the same size + the gradient contraction (~1 apply)
+    fp64_peak = capi.measure_fp64_peak(local_rank) if rank == 0 else 0.0
+    fp64_achieved = f_step * units_per_launch / kern_s / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
@@ -202,7 +253,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if (weak or world == 1) else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -210,8 +261,10 @@ def main():
                 "workload": spec.description,
                 "name": args.workload,
                 "mode": "forward sweep (evalF)" if args.mode == "fwd" else "forward + adjoint gradient (evalGradF)",
-                "system_dim": dim, "ninit": ninit, "ntime": ntime, "dt": spec.time.dt,
-                "timestepper": "IMR", "linearsolver": "neumann (in-kernel)", "parallelism": f"initial conditions sharded over {world} GPU(s)",
+                "system_dim": dim, "ninit": ninit_global, "ninit_per_gpu": ninit_local, "ntime": ntime, "dt": spec.time.dt,
+                "timestepper": "IMR", "linearsolver": "neumann (in-kernel)",
+                "parallelism": (f"{world} GPU(s): one full set of {ninit} initial conditions per GPU (weak)" if weak else
+                                f"{ninit} initial conditions split over {world} GPU(s)"),
                 "rhs_applications_per_step": applies / args.steps,
                 "objective": val["objective"],
             },
@@ -221,6 +274,10 @@ def main():
                 "kernel": "k_forward" if args.mode == "fwd" else "k_forward+k_adjoint",
                 "kernel_ms_per_launch": kern_s * 1e3,
                 "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": units_per_launch,
+                "fp64_valu": {"achieved": fp64_achieved, "peak": fp64_peak, "unit": "TFLOP/s",
+                              "frac": fp64_achieved / fp64_peak if fp64_peak > 0 else None,
+                              "flops_per_unit": f_step, "peak_kind": "measured v_fma_f64 micro-benchmark (qd_measure_fp64_peak)",
+                              "active_cu_frac": min(1.0, ninit_local / 256.0)},
             },
         }
         if args.mode == "grad":

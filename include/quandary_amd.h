@@ -192,8 +192,7 @@ int qd_set_penalty(qd_handle* h, const qd_penalty* pen);
 
 int qd_forward(qd_handle* h, const double* x0, int nb, int store_trajectory, qd_forward_out* out);
 /* xbarT: [nb][2*dim] terminal adjoint seed; jbar: [nb][3] = beta_i*{gamma_penalty,
- * gamma_dpdm, gamma_energy} as passed to solveAdjointODE; jbar_weightedJ: [nb][2]
- * (Jbar_re, Jbar_im from finalizeJ_diff per state, used by the weighted-J penalty);
+ * gamma_dpdm, gamma_energy} as passed to solveAdjointODE (timestepper.cpp:184);
  * grad: [ndesign] summed over the local batch (overwritten). */
 int qd_adjoint(qd_handle* h, const double* xbarT, const double* jbar, int nb, double* grad);
 
@@ -204,6 +203,10 @@ double qd_last_mean_applies(const qd_handle* h);
  * (hipEvent bracket on the handle's stream). */
 double qd_last_forward_ms(const qd_handle* h);
 double qd_last_adjoint_ms(const qd_handle* h);
+/* Measurement hook for the secondary (fp64 vector) roofline: runs a register-only
+ * v_fma_f64 micro-benchmark on the device and returns the sustained TFLOP/s in
+ * *tflops (the fp64 peak is to be measured, not quoted). */
+int qd_measure_fp64_peak(int device_ordinal, double* tflops);
 
 /* ---------------------------------------------------------------------------
  * Objective level: OptimProblem::evalF / evalGradF over the local shard of

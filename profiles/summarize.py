@@ -56,6 +56,24 @@ def main():
     for k, v in sq.items():
         summary.setdefault(k, {})["sq_mean"] = {c: sum(x) / len(x) for c, x in v.items()}
     res["pmc"] = summary
+    # per-launch HBM bytes of the sweep kernels -> profiles/pmc_latest.json (read by bench.py for
+    # roofline.traffic); key = "<workload>_<mode>", taken from a tag like r1_c2_fwd
+    parts = tag.split("_")
+    if len(parts) >= 3:
+        key = "_".join(parts[-2:])
+        tot, names = 0.0, []
+        for k, v in summary.items():
+            if ("k_forward" in k or "k_adjoint" in k) and "hbm_bytes_per_launch_fetch_x2" in v:
+                tot += v["hbm_bytes_per_launch_fetch_x2"]
+                names.append(k[:60])
+        if names:
+            latest_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json")
+            latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
+            latest[key] = {"hbm_bytes_per_launch": tot, "kernels": names, "source": f"profiles/{tag}_summary.json",
+                           "correction": "FETCH_SIZE x2 (gfx950, calibrated on this kernel's 8-byte loads) + WRITE_SIZE, units of 1 KiB"}
+            json.dump(latest, open(latest_path, "w"), indent=1)
+            # gpurun only merges gpurun_out/ back: leave a copy there
+            json.dump(latest, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
     json.dump(res, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "sq_mean"} for k, v in summary.items()}, indent=1)[:3000])
     for r in rows[:8]:

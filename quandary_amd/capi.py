@@ -171,7 +171,7 @@ EXPORTS = [
     "qd_last_error", "qd_version", "qd_device_count", "qd_create", "qd_destroy", "qd_dim", "qd_dim_rho",
     "qd_dim_ess", "qd_ndesign", "qd_set_params", "qd_eval_controls", "qd_apply_rhs", "qd_get_state",
     "qd_set_target", "qd_set_penalty", "qd_forward", "qd_adjoint", "qd_last_mean_applies",
-    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
+    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
 ]
@@ -215,6 +215,7 @@ def load_library(path=None):
     for f in ("qd_last_mean_applies", "qd_last_forward_ms", "qd_last_adjoint_ms"):
         getattr(lib, f).argtypes = [vp]
         getattr(lib, f).restype = C.c_double
+    lib.qd_measure_fp64_peak.argtypes = [C.c_int, C.POINTER(C.c_double)]
     lib.qd_optim_create.argtypes = [vp, C.POINTER(qd_objective), C.c_int, C.c_int, C.POINTER(vp)]
     lib.qd_optim_destroy.argtypes = [vp]
     lib.qd_optim_destroy.restype = None
@@ -230,6 +231,14 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def measure_fp64_peak(device=0):
+    """Sustained fp64 FMA rate of the device in TFLOP/s (register-only micro-benchmark)."""
+    lib = load_library()
+    v = C.c_double(0.0)
+    _check(lib, lib.qd_measure_fp64_peak(device, C.byref(v)), "qd_measure_fp64_peak")
+    return v.value
 
 
 def _check(lib, rc, what):

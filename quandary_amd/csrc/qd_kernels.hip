@@ -329,3 +329,61 @@ hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsu
 }
 
 }  // namespace qd
+
+// ---------------------------------------------------------------------------------------------
+// fp64 vector peak (measurement hook): 8 independent FMA chains per lane, registers only
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fma_peak(double* out, int iters, double a, double b) {
+  double v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = (double)(threadIdx.x + i) * 1e-3;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = fma(v[i], a, b);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += v[i];
+  if (s == 12345.678) out[0] = s;  // never true; keeps the chains alive
+}
+
+extern "C" int qd_measure_fp64_peak(int device_ordinal, double* tflops) {
+  if (!tflops) {
+    qd::set_error("qd_measure_fp64_peak: null output");
+    return QD_ERR_INVALID;
+  }
+  if (hipSetDevice(device_ordinal) != hipSuccess) {
+    qd::set_error("qd_measure_fp64_peak: no such device");
+    return QD_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return QD_ERR_DEVICE;
+  double* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(double)) != hipSuccess) return QD_ERR_NOMEM;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int blocks = prop.multiProcessorCount * 16, threads = 256, iters = 1 << 15;
+  hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999, 1e-9);  // warm-up (clock ramp)
+  hipError_t err = hipSuccess;
+  float ms = 0.f;
+  for (int rep = 0; rep < 3; rep++) {  // best of three
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999, 1e-9);
+    (void)hipEventRecord(e1, 0);
+    err = hipEventSynchronize(e1);
+    float m = 0.f;
+    (void)hipEventElapsedTime(&m, e0, e1);
+    if (err != hipSuccess) break;
+    if (rep == 0 || m < ms) ms = m;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  if (err != hipSuccess || ms <= 0.f) {
+    qd::set_error("qd_measure_fp64_peak: kernel failed");
+    return QD_ERR_DEVICE;
+  }
+  *tflops = 2.0 * 8.0 * (double)iters * (double)blocks * (double)threads / (ms * 1e-3) / 1e12;
+  return QD_OK;
+}

@@ -5,15 +5,18 @@ collectives per gradient (src/optimproblem.cpp:454-460 and :527):
     forward(local shard) -> all-reduce(7 sums) -> seeds from the GLOBAL sums -> adjoint(local shard)
                          -> all-reduce(gradient)
 
-No state or trajectory ever leaves its GPU.  ``torch.distributed`` with backend "nccl" is RCCL over
+With `replicas = R` every rank holds a complete set of initial conditions (a batch of R identical
+sets, objective = mean over all members: weak scaling); the reduced sums and the gradient are
+divided by R.  No state or trajectory ever leaves its GPU.  ``torch.distributed`` with backend "nccl" is RCCL over
 xGMI on ROCm; the same code runs with "gloo" on CPU for the tests.  `backend_obj` is anything with
 forward_local / finalize / adjoint_local (quandary_amd.capi.Optim on a GPU)."""
 import numpy as np
 
 
 class DistributedObjective:
-    def __init__(self, backend_obj, dist=None, device="cpu"):
+    def __init__(self, backend_obj, dist=None, device="cpu", replicas=1):
         self.b = backend_obj
+        self.scale = 1.0 / replicas
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.device = device
 
@@ -24,7 +27,7 @@ class DistributedObjective:
 
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        return t.cpu().numpy() * self.scale
 
     def evalF(self, alpha):
         sums = self._allreduce(self.b.forward_local(alpha, False))

@@ -26,7 +26,7 @@ class _OracleShard:
         return self.o.adjoint_local(alpha, self.rank, self.nranks, sums)
 
 
-def _worker(rank, world, port, cfg_text, q):
+def _worker(rank, world, port, cfg_text, q, replicated=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -40,7 +40,10 @@ def _worker(rank, world, port, cfg_text, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sp = config.build_spec(config.parse_config_text(cfg_text))
     orc = Oracle(sp)
-    obj = DistributedObjective(_OracleShard(orc, rank, world), dist, "cpu")
+    if replicated:  # weak scaling: every rank holds the whole set, sums and gradient are averaged
+        obj = DistributedObjective(_OracleShard(orc, 0, 1), dist, "cpu", replicas=world)
+    else:
+        obj = DistributedObjective(_OracleShard(orc, rank, world), dist, "cpu")
     val, g = obj.evalGradF(sp.params0)
     val2 = obj.evalF(sp.params0)
     q.put((rank, val, g, val2))
@@ -48,8 +51,8 @@ def _worker(rank, world, port, cfg_text, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lindblad,objective", [(True, "Jtrace"), (False, "Jtrace")])
-def test_two_ranks_reproduce_single_rank(lindblad, objective):
+@pytest.mark.parametrize("lindblad,objective,replicated", [(True, "Jtrace", False), (False, "Jtrace", False), (False, "Jtrace", True)])
+def test_two_ranks_reproduce_single_rank(lindblad, objective, replicated):
     import torch.multiprocessing as mp
 
     from oracle.oracle import Oracle
@@ -64,7 +67,7 @@ def test_two_ranks_reproduce_single_rank(lindblad, objective):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_text, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg_text, q, replicated)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
