@@ -29,19 +29,36 @@ namespace qd {
 // ---------------------------------------------------------------------------------------------
 // kernel variants
 // ---------------------------------------------------------------------------------------------
+// EPT    elements (slots) per thread          MAXB   largest block (= register budget via __launch_bounds__)
+// DBUF   two LDS copies of the exchange vector (one barrier per solver iteration instead of two)
+// ICPB   initial conditions interleaved in one workgroup
+// COL    column-per-wave layout (ColStencil)
+// LEAN   throughput regime: no register-carried prefetches, the vectors that are idle during a linear
+//        solve are parked in L2/HBM explicitly (SweepArgs::stash) instead of being spilled by the compiler
+template <int EPT_, int MAXB_, bool DBUF_, bool ONEWAVE_, int ICPB_ = 1, bool COL_ = false, bool LEAN_ = false>
+struct VariantDef {
+  static constexpr int EPT = EPT_, MAXB = MAXB_, ICPB = ICPB_, FENCE = 1;
+  static constexpr bool DBUF = DBUF_, ONEWAVE = ONEWAVE_, BLDS = false, COL = COL_, LEAN = LEAN_;
+};
 template <int VAR> struct Variant;
-template <> struct Variant<0> { static constexpr int EPT = 1, MAXB = 64;   static constexpr bool DBUF = false, ONEWAVE = true,  BLDS = false; static constexpr int ICPB = 1; };
-template <> struct Variant<1> { static constexpr int EPT = 1, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
-template <> struct Variant<2> { static constexpr int EPT = 4, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
-template <> struct Variant<3> { static constexpr int EPT = 4, MAXB = 1024; static constexpr bool DBUF = false, ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
-template <> struct Variant<4> { static constexpr int EPT = 8, MAXB = 512;  static constexpr bool DBUF = false, ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
-template <> struct Variant<5> { static constexpr int EPT = 1, MAXB = 1024; static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 1; };
+template <> struct Variant<0> : VariantDef<1, 64, false, true> {};     // dim <= 64: one wave, no barriers
+template <> struct Variant<1> : VariantDef<1, 256, true, false> {};    // dim <= 256
+template <> struct Variant<2> : VariantDef<4, 256, true, false> {};    // dim <= 1024, many initial conditions
+template <> struct Variant<3> : VariantDef<4, 1024, false, false, 1, false, true> {};
+template <> struct Variant<4> : VariantDef<8, 512, false, false, 1, false, true> {};  // dim <= 4096 (Schroedinger, or N > 64)
+template <> struct Variant<5> : VariantDef<1, 1024, true, false> {};   // dim <= 1024, few initial conditions
 // V6: two initial conditions interleaved in ONE wave (dim <= 64): two independent dependency chains per
 // lane hide the LDS / fp64 latencies that bound the single-wave kernels
-template <> struct Variant<6> { static constexpr int EPT = 2, MAXB = 64;   static constexpr bool DBUF = false, ONEWAVE = true,  BLDS = false; static constexpr int ICPB = 2; };
+template <> struct Variant<6> : VariantDef<2, 64, false, true, 2> {};
 // V7: the same for dim <= 256 (four waves, two initial conditions per workgroup, one barrier serves both)
-template <> struct Variant<7> { static constexpr int EPT = 2, MAXB = 256;  static constexpr bool DBUF = true,  ONEWAVE = false, BLDS = false; static constexpr int ICPB = 2; };
-constexpr int NVARIANTS = 8;
+template <> struct Variant<7> : VariantDef<2, 256, true, false, 2> {};
+// V8/V9/V10: column-per-wave layout for large density matrices (N <= 64, dim up to 4096): lane = row of
+// rho, every wave owns EPT whole columns -> all ket-side quantities are wave-uniform, all bra-side
+// quantities are loop invariants of the thread (ColStencil below)
+template <> struct Variant<8> : VariantDef<4, 1024, true, false, 1, true, true> {};
+template <> struct Variant<9> : VariantDef<8, 512, true, false, 1, true, true> {};
+template <> struct Variant<10> : VariantDef<6, 640, true, false, 1, true, true> {};
+constexpr int NVARIANTS = 11;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 
@@ -175,6 +192,29 @@ __device__ __forceinline__ void load_step(const double* __restrict__ row, StepC<
   }
 }
 
+// Moves a wave-uniform double from vector to scalar registers (the table rows are fetched with vector
+// loads because the compiler cannot prove them read-only).
+__device__ __forceinline__ double to_scalar(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <int Q>
+__device__ __forceinline__ void scalarize(StepC<Q>& c, bool with_pairs) {
+  constexpr int NP = Q * (Q - 1) / 2;
+  c.h = to_scalar(c.h);
+#pragma unroll
+  for (int k = 0; k < Q; k++) {
+    c.p[k] = to_scalar(c.p[k]);
+    c.q[k] = to_scalar(c.q[k]);
+  }
+  if (with_pairs) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      c.cs[k] = to_scalar(c.cs[k]);
+      c.sn[k] = to_scalar(c.sn[k]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS layout
 // ---------------------------------------------------------------------------------------------
@@ -185,6 +225,7 @@ struct Lds {
   double* tdn;      //                  tdn[ofs_k + a] = sqrt(a)
   double* red;      // reduction scratch, two slots of NRED * nwaves
   double2* bvec;    // BLDS variants: right-hand side of the linear solve
+  double2* coltab;  // column stencil: coltab[c * Q + k] = (sqrt(i'_k + 1) or 0 at the top level, sqrt(i'_k)) of column c
   double2* kry;     // GMRES: Krylov basis, (GMRES_MR + 1) vectors of dim
   double* ksc;      // GMRES: wave-uniform scalars (Hessenberg column, rotations, rhs, R, solution)
 };
@@ -193,7 +234,8 @@ __host__ __device__ inline int table_len(const DevSys& S) {
   for (int k = 0; k < S.Q; k++) t += S.n[k];
   return (t + 1) & ~1;
 }
-__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, bool krylov = false, int icpb = 1) {
+__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, bool krylov = false, int icpb = 1,
+                                     bool col = false) {
   Lds l;
   l.buf0 = reinterpret_cast<double2*>(smem);
   l.bstride = dbuf ? S.dim * icpb : 0;
@@ -205,6 +247,8 @@ __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool 
   l.red = l.tdn + tl;
   l.kry = nullptr;
   l.ksc = nullptr;
+  l.coltab = nullptr;
+  if (col) l.coltab = reinterpret_cast<double2*>(l.red + 2 * NRED * ((blockDim.x + 63) >> 6));  // never together with krylov
   if (krylov) {
     const int nw = (blockDim.x + 63) >> 6;
     l.kry = reinterpret_cast<double2*>(l.red + 2 * NRED * nw);
@@ -212,14 +256,27 @@ __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool 
   }
   return l;
 }
-static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, bool krylov = false, int icpb = 1) {
-  return sizeof(double2) * (size_t)S.dim * icpb * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
+static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, bool krylov = false, int icpb = 1, bool col = false) {
+  return (col ? sizeof(double2) * (size_t)S.N * S.Q : 0) + sizeof(double2) * (size_t)S.dim * icpb * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
          sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64) +
          (krylov ? sizeof(double2) * (size_t)(GMRES_MR + 1) * S.dim + sizeof(double) * GMRES_NSC : 0);
 }
 
 // Keeps index arithmetic INSIDE the time loop: without it the compiler hoists every neighbour index,
 // digit and coefficient of every owned element out of the loop and spills hundreds of registers.
+// Scheduling fence between the elements of a thread (throughput variants): without it the machine
+// scheduler hoists the LDS reads of ALL owned elements above the arithmetic of the first one (maximal
+// latency hiding for a single wave) and the live ranges no longer fit the register budget.  Several
+// waves per SIMD hide the latency instead.
+template <int EPT>
+__device__ __forceinline__ void slot_fence() {
+  if (EPT > 1) {
+    asm volatile("" ::: "memory");  // orders the memory operations already at the IR / DAG level
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int EPE> __device__ __forceinline__ int at_use(int v);
 __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
@@ -227,6 +284,12 @@ __device__ __forceinline__ int opaque(int v) {
 __device__ __forceinline__ unsigned opaque(unsigned v) {
   asm volatile("" : "+v"(v));
   return v;
+}
+// index of an owned element at a point of use: the throughput variants re-derive everything that
+// depends on it (targets, weights, addresses) instead of keeping it in registers across the time loop
+template <int EPE>
+__device__ __forceinline__ int at_use(int v) {
+  return EPE > 1 ? opaque(v) : v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -635,16 +698,198 @@ struct QubitStencil {
   __device__ __forceinline__ bool is_guard(const DevSys&, int) const { return false; }  // nessential == nlevels == 2 ... see host check
 };
 
-template <int Q, bool LIND, int EPT, int EPE, bool QUBIT>
+
+// ---------------------------------------------------------------------------------------------
+// column stencil (Lindblad, runtime level counts, N <= 64): lane = row I of rho, wave w owns the columns
+// I' = w, w + nw, w + 2 nw, ...  (vectorised index it = I' N + I, util.cpp:150).  Every ket-side
+// quantity (digits of I', ladder coefficients, neighbour columns) is wave-uniform and lives on the
+// scalar unit or in one broadcast LDS read; every bra-side quantity is an invariant of the thread.
+// Nothing per slot has to be kept in vector registers except the two diagonal coefficients.
+// ---------------------------------------------------------------------------------------------
+template <int Q, int EPT>
+struct ColStencil {
+  static constexpr int DB = (Q <= 4) ? 8 : 6;
+  int it[EPT];
+  bool valid[EPT];
+  double dw[EPT], dd[EPT];
+  int N, row, col0, cstride;
+  unsigned dbra;
+  double su[Q], sd[Q];    // sqrt(i_k + 1) (0 at the top level), sqrt(i_k) of this thread's row
+  double g1u[Q], g1d[Q];  // gamma_1 su / gamma_1 sd (T1 off-diagonal, forward / transposed)
+  int rup[Q], rdn[Q];     // row of the bra "up" / "down" neighbour, clamped into the column
+  int ofs[Q];
+
+  __device__ __forceinline__ static int dig(unsigned d, int k) { return (int)((d >> (DB * k)) & ((1u << DB) - 1u)); }
+  __device__ __forceinline__ int colof(int j) const { return min(col0 + j * cstride, N - 1); }  // wave-uniform
+
+  __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
+    N = S.N;
+    const int lane = threadIdx.x & 63;
+    col0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    cstride = (int)(blockDim.x >> 6);
+    const bool rowok = lane < N;
+    row = rowok ? lane : N - 1;
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      ofs[k] = o;
+      o += S.n[k];
+    }
+    for (int k = 0; k < Q; k++)
+      for (int a = threadIdx.x; a < S.n[k]; a += blockDim.x) {
+        L.tup[ofs[k] + a] = (a < S.n[k] - 1) ? sqrt((double)(a + 1)) : 0.0;
+        L.tdn[ofs[k] + a] = sqrt((double)a);
+      }
+    for (int e = threadIdx.x; e < N * Q; e += blockDim.x) {
+      const int cc = e / Q, k = e % Q;
+      const int ap = (cc / S.post[k]) % S.n[k];
+      L.coltab[e] = make_double2((ap < S.n[k] - 1) ? sqrt((double)(ap + 1)) : 0.0, sqrt((double)ap));
+    }
+    int ia[Q];
+    dbra = 0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      ia[k] = (row / S.post[k]) % S.n[k];
+      dbra |= (unsigned)ia[k] << (DB * k);
+      su[k] = (ia[k] < S.n[k] - 1) ? sqrt((double)(ia[k] + 1)) : 0.0;
+      sd[k] = sqrt((double)ia[k]);
+      g1u[k] = S.g1off[k] * su[k];
+      g1d[k] = S.g1off[k] * sd[k];
+      rup[k] = min(row + S.post[k], N - 1);
+      rdn[k] = max(row - S.post[k], 0);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int craw = col0 + j * cstride, cc = min(craw, N - 1);
+      valid[j] = rowok && craw < N;
+      it[j] = cc * N + row;
+      int ipa[Q];
+#pragma unroll
+      for (int k = 0; k < Q; k++) ipa[k] = (cc / S.post[k]) % S.n[k];
+      double hd = 0.0, hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        hd += S.detune[k] * ia[k] - S.xi[k] / 2.0 * ia[k] * (ia[k] - 1);
+        hdp += S.detune[k] * ipa[k] - S.xi[k] / 2.0 * ipa[k] * (ipa[k] - 1);
+        d += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          hd -= S.xikl[pair] * ia[k] * ia[l];
+          hdp -= S.xikl[pair] * ipa[k] * ipa[l];
+          pair++;
+        }
+      }
+      dw[j] = hd - hdp;
+      dd[j] = d;
+    }
+  }
+
+  __device__ __forceinline__ void prep(const StepC<Q>&) {}
+
+  // see GenStencil::ladder
+  __device__ __forceinline__ void ladder(const DevSys& S, const Lds& L, const double2* __restrict__ sx, int k, int j, double2& A,
+                                         double2& B) const {
+    const int cc = colof(j), cN = cc * N, st = S.post[k];
+    const int cu = min(cc + st, N - 1) * N, cd = max(cc - st, 0) * N;
+    const double2 ct = L.coltab[cc * Q + k];
+    const int r0 = opaque(row), ru = opaque(rup[k]), rd = opaque(rdn[k]);  // addresses are re-derived, not hoisted
+    const double2 xu = sx[cN + ru], xd = sx[cN + rd], xup = sx[cu + r0], xdp = sx[cd + r0];
+    const double er = fma(-ct.y, xdp.x, su[k] * xu.x), ei = fma(-ct.y, xdp.y, su[k] * xu.y);    // U1 - D2
+    const double fr = fma(ct.x, xup.x, -sd[k] * xd.x), fi = fma(ct.x, xup.y, -sd[k] * xd.y);    // U2 - D1
+    A.x = er + fr;
+    A.y = ei + fi;
+    B.x = er - fr;
+    B.y = ei - fi;
+  }
+
+  // HASJ = false: the caller has checked S.hasJ == 0; the slot loop is then free of branches and two
+  // slots can be in flight (Variant::FENCE)
+  template <bool TRANS, bool HASJ = true>
+  __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                           const double2 xs) const {
+    const int cc = colof(j), cN = cc * N;
+    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
+    double l1r = 0.0, l1i = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const int st = S.post[k];
+      const int cu = min(cc + st, N - 1) * N, cd = max(cc - st, 0) * N;
+      const double2 ct = L.coltab[cc * Q + k];
+      const int r0 = opaque(row), ru = opaque(rup[k]), rd = opaque(rdn[k]);  // addresses are re-derived, not hoisted
+      const double2 xu = sx[cN + ru], xd = sx[cN + rd], xup = sx[cu + r0], xdp = sx[cd + r0];
+      const double er = fma(-ct.y, xdp.x, su[k] * xu.x), ei = fma(-ct.y, xdp.y, su[k] * xu.y);
+      const double fr = fma(ct.x, xup.x, -sd[k] * xd.x), fi = fma(ct.x, xup.y, -sd[k] * xd.y);
+      hr = fma(c.q[k], er + fr, fma(c.p[k], ei - fi, hr));
+      hi = fma(c.q[k], ei + fi, fma(-c.p[k], er - fr, hi));
+      {  // T1 off-diagonal term; without decay the coefficient is an exact zero
+        const double2 xl = sx[TRANS ? cd + rd : cu + ru];
+        const double l1 = TRANS ? g1d[k] * ct.y : g1u[k] * ct.x;
+        l1r = fma(l1, xl.x, l1r);
+        l1i = fma(l1, xl.y, l1i);
+      }
+    }
+    if (HASJ && S.hasJ) {  // dipole-dipole coupling: the generic formulation of GenStencil::apply
+      const int i0 = opaque(it[j]), top = S.dim - 1;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+#pragma unroll
+        for (int l = k + 1; l < Q; l++, pair++) {
+          const double Jkl = S.J[pair];
+          if (Jkl == 0.0) continue;
+          const unsigned db = opaque(dbra);
+          const int a = dig(db, k), b = dig(db, l);
+          const int sk = S.post[k], sl = S.post[l];
+          const double s1 = L.tdn[ofs[k] + a] * L.tup[ofs[l] + b], s2 = L.tdn[ofs[l] + b] * L.tup[ofs[k] + a];
+          const double2 x1 = sx[min(max(i0 - sk + sl, 0), top)], x2 = sx[min(max(i0 + sk - sl, 0), top)];
+          double ar = s1 * x1.x - s2 * x2.x, ai = s1 * x1.y - s2 * x2.y;
+          double br = s1 * x1.x + s2 * x2.x, bi = s1 * x1.y + s2 * x2.y;
+          const int ap = (cc / sk) % S.n[k], bp = (cc / sl) % S.n[l];
+          const int skp = N * sk, slp = N * sl;
+          const double s3 = L.tdn[ofs[k] + ap] * L.tup[ofs[l] + bp], s4 = L.tdn[ofs[l] + bp] * L.tup[ofs[k] + ap];
+          const double2 x3 = sx[min(max(i0 - skp + slp, 0), top)], x4 = sx[min(max(i0 + skp - slp, 0), top)];
+          ar += s3 * x3.x - s4 * x4.x;
+          ai += s3 * x3.y - s4 * x4.y;
+          br -= s3 * x3.x + s4 * x4.x;
+          bi -= s3 * x3.y + s4 * x4.y;
+          const double co = c.cs[pair], si = c.sn[pair];
+          hr += Jkl * (si * ar + co * bi);
+          hi += Jkl * (si * ai - co * br);
+        }
+      }
+    }
+    const double yr = fma(dd[j], xs.x, TRANS ? -hr : hr) + l1r, yi = fma(dd[j], xs.y, TRANS ? -hi : hi) + l1i;
+    return make_double2(yr, yi);
+  }
+
+  // isGuardLevel (util.cpp:259-278) for a diagonal element
+  __device__ __forceinline__ bool is_guard(const DevSys& S, int j) const {
+    if (!valid[j] || colof(j) != row) return false;
+    bool g = false;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const int a = dig(dbra, k);
+      g = g || (a == S.n[k] - 1 && a >= S.ness[k]);
+    }
+    return g;
+  }
+};
+
+template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false>
 struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, bool LIND, int EPT, int EPE>
-struct StencilSel<Q, LIND, EPT, EPE, true> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
+struct StencilSel<Q, LIND, EPT, EPE, true, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
+template <int Q, int EPT, int EPE>
+struct StencilSel<Q, true, EPT, EPE, false, true> { typedef ColStencil<Q, EPT> type; };
 
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
 template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const GenStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
 template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const QubitStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
+template <int Q, int EPT>
+__device__ __forceinline__ bool slot_valid(const ColStencil<Q, EPT>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)
@@ -785,7 +1030,7 @@ struct Team {
   static constexpr int EPT = V::EPT;    // slots per thread
   static constexpr int ICPB = V::ICPB;  // initial conditions per workgroup (interleaved in the same threads)
   static constexpr int EPE = EPT / ICPB;  // elements per thread of ONE initial condition
-  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT>::type ST;
+  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL>::type ST;
   ST st;
   Lds L;
   int cur;      // which LDS buffer holds the vector that may be stencil-read
@@ -795,7 +1040,7 @@ struct Team {
   int nb;       // batch size
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, int nbatch, bool krylov = false) {
-    L = carve(smem, S, V::DBUF, V::BLDS, krylov, ICPB);
+    L = carve(smem, S, V::DBUF, V::BLDS, krylov, ICPB, V::COL);
     st.init(S, L);
     cur = 0;
     redslot = 0;
@@ -845,11 +1090,43 @@ struct Team {
     team_sync<V::ONEWAVE>();
   }
 
-  template <bool TRANS>
-  __device__ __forceinline__ void apply_all(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+  template <bool TRANS, bool HASJ>
+  __device__ __forceinline__ double2 apply_slot(const DevSys& S, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                                const double2 xs) const {
+    if constexpr (V::COL) return st.template apply<TRANS, HASJ>(S, L, sx, c, j, xs);
+    else return st.template apply<TRANS>(S, L, sx, c, j, xs);
+  }
+
+  template <bool TRANS, bool HASJ>
+  __device__ __forceinline__ void apply_sweep(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      y[j] = st.template apply<TRANS>(S, L, vecj(j), c, j, x[j]);
+      y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x[j]);
+      if ((j % V::FENCE) == V::FENCE - 1) slot_fence<EPE>();
+    }
+  }
+  template <bool TRANS>
+  __device__ __forceinline__ void apply_all(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+    if (V::COL && !S.hasJ) apply_sweep<TRANS, false>(S, c, x, y);
+    else apply_sweep<TRANS, true>(S, c, x, y);
+  }
+
+  // one Neumann update of every owned element: y <- b + alpha M^{(T)} y, squared update norm into dloc
+  template <bool TRANS, bool HASJ>
+  __device__ __forceinline__ void neumann_sweep(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ src,
+                                                const double2 (&b)[EPT], double2 (&y)[EPT], double (&dloc)[ICPB]) {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const double2 t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, y[j]);
+      const double2 bj = V::BLDS ? L.bvec[lidx(j)] : b[j];
+      double2 w;
+      w.x = fma(alpha, t.x, bj.x);
+      w.y = fma(alpha, t.y, bj.y);
+      const double dx = y[j].x - w.x, dy = y[j].y - w.y;
+      dloc[icslot(j)] += ok(j) ? dx * dx + dy * dy : 0.0;
+      y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
+      if (V::DBUF && ok(j)) bufp(cur)[lidx(j)] = w;
+      if ((j % V::FENCE) == V::FENCE - 1) slot_fence<EPE>();
     }
   }
 
@@ -880,18 +1157,8 @@ struct Team {
       for (int q = 0; q < ICPB; q++) dloc[q] = 0.0;
       const double2* src = vec();
       if (V::DBUF) cur ^= 1;  // the new iterate goes to the other buffer: ONE barrier (inside the reduction)
-#pragma unroll
-      for (int j = 0; j < EPT; j++) {
-        const double2 t = st.template apply<TRANS>(A.S, L, src + icslot(j) * dim, c, j, y[j]);
-        const double2 bj = V::BLDS ? L.bvec[lidx(j)] : b[j];
-        double2 w;
-        w.x = fma(alpha, t.x, bj.x);
-        w.y = fma(alpha, t.y, bj.y);
-        const double dx = y[j].x - w.x, dy = y[j].y - w.y;
-        dloc[icslot(j)] += ok(j) ? dx * dx + dy * dy : 0.0;
-        y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
-        if (V::DBUF && ok(j)) bufp(cur)[lidx(j)] = w;
-      }
+      if (V::COL && !A.S.hasJ) neumann_sweep<TRANS, false>(A, c, alpha, src, b, y, dloc);
+      else neumann_sweep<TRANS, true>(A, c, alpha, src, b, y, dloc);
       // clamp: adjoint solves of badly scaled problems have update norms whose square overflows fp32; a
       // clamped value is still far above both thresholds (the reference's reltol is 1e-20).  With several
       // initial conditions per workgroup all of them iterate until the slowest has converged (the others
@@ -1084,12 +1351,21 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   unsigned long long napply = 0;
   double* traj = A.traj;
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
+  // latency-bound variants prefetch the next table row; the throughput variants (several waves per
+  // SIMD) load the row where it is used and keep it in scalar registers
+  constexpr bool PREFETCH = !TM::V::LEAN;
+  constexpr bool XSTASH = TM::V::LEAN;  // explicit staging of the state through L2/HBM instead of compiler spills
   StepC<Q> c, cn;
-  load_step<Q>(A.ctl, cn, jpairs);
+  if (PREFETCH) load_step<Q>(A.ctl, cn, jpairs);
 
   for (int s = 0; s < A.nsub; s++) {
-    c = cn;
-    if (s + 1 < A.nsub) load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, cn, jpairs);  // prefetch the next row
+    if (PREFETCH) {
+      c = cn;
+      if (s + 1 < A.nsub) load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, cn, jpairs);  // prefetch the next row
+    } else {
+      load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+      scalarize<Q>(c, jpairs);
+    }
     tm.st.prep(c);
     if (traj) {
 #pragma unroll
@@ -1104,6 +1380,16 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
     double2 rhs[EPT];
     tm.template apply_all<false>(S, c, x, rhs);
     napply++;
+    if (XSTASH && !A.stepper_ee) {  // x is not needed during the linear solve: park it in the output buffer
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (tm.ok(j)) {
+          double* xs = A.xT + (size_t)tm.ic(j) * 2 * dim;
+          const int e = at_use<TM::EPE>(tm.st.it[j]);
+          xs[e] = x[j].x;
+          xs[dim + e] = x[j].y;
+        }
+    }
     if (A.stepper_ee) {
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
@@ -1113,6 +1399,14 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
     } else {
       double2 k[EPT];
       napply += tm.template solve<false>(A, c, 0.5 * c.h, rhs, k);
+      if (XSTASH) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const double* xs = A.xT + (size_t)tm.ic(j) * 2 * dim;
+          const int e = at_use<TM::EPE>(tm.st.it[j]);
+          x[j] = make_double2(xs[e], xs[dim + e]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         x[j].x = fma(c.h, k[j].x, x[j].x);
@@ -1137,7 +1431,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
           for (int q = 0; q < 2 * ICPB; q++) v[q] = 0.0;
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], x[j], v[2 * tm.icslot(j)], v[2 * tm.icslot(j) + 1]);
+            if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, tm.ic(j), at_use<TM::EPE>(tm.st.it[j]), x[j], v[2 * tm.icslot(j)], v[2 * tm.icslot(j) + 1]);
           tm.template sum<2 * ICPB>(v);
 #pragma unroll
           for (int q = 0; q < ICPB; q++) pen_uniform[q] += weight * finalizeJ<LIND>(A.tg, v[2 * q], v[2 * q + 1]) * A.dt;
@@ -1146,7 +1440,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
           for (int j = 0; j < EPT; j++)
             if (tm.ok(j)) {
               double jr = 0.0, ji = 0.0;
-              evalJ_part<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], x[j], jr, ji);
+              evalJ_part<LIND>(S, A.tg, tm.ic(j), at_use<TM::EPE>(tm.st.it[j]), x[j], jr, ji);
               // finalizeJ is affine here: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Lindblad Jtrace)
               pen_local[tm.icslot(j)] += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
             }
@@ -1239,7 +1533,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     const double* xbT = A.xbarT + (size_t)tm.ic(j) * 2 * dim;
     xb[j] = make_double2(xbT[tm.st.it[j]], xbT[dim + tm.st.it[j]]);
   }
-  load_state(A.nsub, xn);
+  // Latency-bound variants (few elements per thread) carry x_{n+1} in registers and prefetch x_{n-1} one
+  // step ahead; the throughput variants re-read them (L2 / HBM) to keep the register footprint small.
+  constexpr bool CARRY = !TM::V::LEAN;
+  if (CARRY) load_state(A.nsub, xn);
   double jbar_pen[ICPB], jbar_dpdm[ICPB];
 #pragma unroll
   for (int q = 0; q < ICPB; q++) {
@@ -1257,17 +1554,22 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.ok(j) && tm.st.is_guard(S, j);
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
   const int ntime = A.ntime;
-  double2 x[EPT], xnext[EPT];
-  load_state(A.nsub - 1, xnext);  // primal at the start of the last sub-step (prefetched one step ahead)
+  double2 x[EPT], xnext[CARRY ? EPT : 1];
+  if (CARRY) load_state(A.nsub - 1, reinterpret_cast<double2(&)[EPT]>(xnext));  // primal at the start of the last sub-step
 
   for (int s = A.nsub - 1; s >= 0; s--) {
+    if (CARRY) {
 #pragma unroll
-    for (int j = 0; j < EPT; j++) x[j] = xnext[j];
-    if (s > 0) load_state(s - 1, xnext);
+      for (int j = 0; j < EPT; j++) x[j] = xnext[CARRY ? j : 0];
+      if (s > 0) load_state(s - 1, reinterpret_cast<double2(&)[EPT]>(xnext));
+    } else {
+      load_state(s, x);
+    }
     // ---- penalty adjoints at the end of a full step, using the primal x_n (timestepper.cpp:220-227)
     if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
       const int n = (s + 1) / A.nstages;
       const double tstop = n * A.dt;
+      if (!CARRY) load_state(s + 1, xn);
       if (dpdm_on) {  // penaltyDpDm_diff (timestepper.cpp:372-442); all five states come from HBM
         double2 m2[EPT], m1[EPT], p1[EPT], p2[EPT];
         if (n > 1) load_state((n - 2) * A.nstages, m2);
@@ -1309,7 +1611,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
             for (int q = 0; q < 2 * ICPB; q++) v[q] = 0.0;
 #pragma unroll
             for (int j = 0; j < EPT; j++)
-              if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], xn[j], v[2 * tm.icslot(j)], v[2 * tm.icslot(j) + 1]);
+              if (tm.ok(j)) evalJ_part<LIND>(S, A.tg, tm.ic(j), at_use<TM::EPE>(tm.st.it[j]), xn[j], v[2 * tm.icslot(j)], v[2 * tm.icslot(j) + 1]);
             tm.template sum<2 * ICPB>(v);
 #pragma unroll
             for (int q = 0; q < ICPB; q++) finalizeJ_diff<LIND>(A.tg, v[2 * q], v[2 * q + 1], rb[q], ib[q]);
@@ -1321,7 +1623,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
           for (int j = 0; j < EPT; j++)
             if (tm.ok(j)) {
               const int q = tm.icslot(j);
-              evalJ_diff_elem<LIND>(S, A.tg, tm.ic(j), tm.st.it[j], xn[j], xb[j], weight * rb[q] * jbar_pen[q] * A.dt,
+              evalJ_diff_elem<LIND>(S, A.tg, tm.ic(j), at_use<TM::EPE>(tm.st.it[j]), xn[j], xb[j], weight * rb[q] * jbar_pen[q] * A.dt,
                                     weight * ib[q] * jbar_pen[q] * A.dt);
             }
         }
@@ -1335,6 +1637,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     }
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    if (!CARRY) scalarize<Q>(c, jpairs);
     tm.st.prep(c);
     double cf[2 * Q * ICPB];
 #pragma unroll
@@ -1379,10 +1682,46 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         xb[j].y = fma(c.h, t[j].y, xb[j].y);
       }
     } else {
-      // ImplMidpoint::evolveBWD (timestepper.cpp:631-694)
+      // ImplMidpoint::evolveBWD (timestepper.cpp:631-694).  The two linear solves are independent; the
+      // primal one goes first so that x and rhs are dead during the adjoint solve (register pressure of
+      // the several-elements-per-thread variants).
       tm.publish(x);
-      double2 rhs[EPT];
-      tm.template apply_all<false>(S, c, x, rhs);
+      double2 z[EPT];  // primal stage: (I - h/2 M) k = M x ; z = x + h/2 k
+      constexpr bool STASH = TM::V::LEAN;  // explicit staging through L2/HBM while a solve runs (see SweepArgs::stash)
+      auto park = [&](int slot, const double2(&v)[EPT]) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (tm.ok(j)) {
+            double* d = A.stash + ((size_t)slot * A.nb + tm.ic(j)) * 2 * dim;
+            const int e = at_use<TM::EPE>(tm.st.it[j]);
+            d[e] = v[j].x;
+            d[dim + e] = v[j].y;
+          }
+      };
+      auto unpark = [&](int slot, double2(&v)[EPT]) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const double* d = A.stash + ((size_t)slot * A.nb + tm.ic(j)) * 2 * dim;
+          const int e = at_use<TM::EPE>(tm.st.it[j]);
+          v[j] = make_double2(d[e], d[dim + e]);
+        }
+      };
+      {
+        double2 rhs[EPT];
+        tm.template apply_all<false>(S, c, x, rhs);
+        if (STASH) park(0, xb);  // xbar is dead weight during the primal solve; x is re-read from the trajectory
+        tm.template solve<false>(A, c, 0.5 * c.h, rhs, z);
+      }
+      if (STASH) load_state(s, x);
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        z[j].x = fma(0.5 * c.h, z[j].x, x[j].x);
+        z[j].y = fma(0.5 * c.h, z[j].y, x[j].y);
+      }
+      if (STASH) {
+        park(1, z);
+        unpark(0, xb);
+      }
       double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
       tm.template solve<true>(A, c, 0.5 * c.h, xb, kb);
 #pragma unroll
@@ -1390,16 +1729,8 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         kb[j].x *= c.h;
         kb[j].y *= c.h;
       }
-      {
-        double2 k[EPT];  // primal stage: (I - h/2 M) k = rhs ; z = x + h/2 k
-        tm.template solve<false>(A, c, 0.5 * c.h, rhs, k);
-#pragma unroll
-        for (int j = 0; j < EPT; j++) {
-          k[j].x = fma(0.5 * c.h, k[j].x, x[j].x);
-          k[j].y = fma(0.5 * c.h, k[j].y, x[j].y);
-        }
-        tm.publish(k);
-      }
+      if (STASH) unpark(1, z);
+      tm.publish(z);
       // gradient coefficients: x^T dM/dp_k z and x^T dM/dq_k z with x := kbar
 #pragma unroll
       for (int j = 0; j < EPT; j++)
@@ -1423,8 +1754,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         xb[j].y += t[j].y;
       }
     }
+    if (CARRY) {
 #pragma unroll
-    for (int j = 0; j < EPT; j++) xn[j] = x[j];
+      for (int j = 0; j < EPT; j++) xn[j] = x[j];
+    }
   }
   if (A.xbar0) {
 #pragma unroll

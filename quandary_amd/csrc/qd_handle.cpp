@@ -63,7 +63,7 @@ extern "C" void qd_destroy(qd_handle* h) {
   (void)hipSetDevice(h->device);
   for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_pen, &h->d_dpdm, &h->d_out4,
-                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y})
+                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
   if (h->d_oscs) (void)hipFree(h->d_oscs);
@@ -358,8 +358,8 @@ extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, doubl
 }
 
 static int check_cfg(const LaunchCfg& cfg) {
-  static const int maxb[8] = {64, 256, 256, 1024, 512, 1024, 64, 256};
-  if (cfg.var < 0 || cfg.var > 7 || cfg.block > maxb[cfg.var])
+  static const int maxb[11] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640};
+  if (cfg.var < 0 || cfg.var > 10 || cfg.block > maxb[cfg.var])
     return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
   if (cfg.lds > 160 * 1024) return fail(QD_ERR_UNSUPPORTED, "state does not fit the 160 KiB LDS of one CU");
   return QD_OK;
@@ -539,8 +539,10 @@ int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, co
   int r;
   const size_t ncol = (size_t)nsub * 2 * S.Q;
   if ((r = d_coeff.ensure((size_t)nb * ncol)) || (r = d_coeffsum.ensure(ncol))) return r;
+  if ((r = d_stash.ensure((size_t)2 * nb * 2 * S.dim))) return r;
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
+  a.stash = d_stash.p;
   a.traj = d_traj.p;
   a.xbarT = dxbarT;
   a.jbar = djbar;

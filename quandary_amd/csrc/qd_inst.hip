@@ -24,7 +24,7 @@ constexpr bool variant_built() {
   // raise per-wave throughput (C2: 1.12 ms vs 1.50 ms per 1000 steps and initial condition) but the
   // batches of this problem class never exceed the number of SIMDs (ninit <= dim), so the whole sweep
   // is as slow as its slowest wave and one initial condition per wave wins (38.6M vs 26.7M units/s).
-  if (!kQubit) return VAR <= 4;
+  if (!kQubit) return VAR <= 4 || (kLind && VAR >= 8 && VAR <= 10);  // V8/V9: column layout, Lindblad only
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
   return VAR == 2 || VAR == 5;
@@ -85,6 +85,9 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
     case 5: return FN<5>(__VA_ARGS__);       \
     case 6: return FN<6>(__VA_ARGS__);       \
     case 7: return FN<7>(__VA_ARGS__);       \
+    case 8: return FN<8>(__VA_ARGS__);       \
+    case 9: return FN<9>(__VA_ARGS__);       \
+    case 10: return FN<10>(__VA_ARGS__);     \
     default: return hipErrorInvalidValue;    \
   }
 

@@ -77,6 +77,8 @@ struct SweepArgs {
   const double* jbar;   // [nb][3]
   double* coeff;        // [nb][nsub][2Q]  (x^T dM/dp_k z, x^T dM/dq_k z)
   double* xbar0;        // [nb][2*dim] adjoint at t=0 (diagnostic) or nullptr
+  double* stash;        // [2][nb][2*dim] staging area of the several-elements-per-thread variants (adjoint state / midpoint state
+                        // parked in L2/HBM while a linear solve runs, instead of compiler-chosen scratch spills)
 };
 
 struct LaunchCfg {

@@ -215,25 +215,32 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 // Variant choice.  One workgroup per initial condition.  Few initial conditions (latency regime):
 // spread one state over as many lanes as it has elements.  Many initial conditions (throughput
 // regime): more elements per thread so that several workgroups share a CU.
+constexpr int QD_COL_DEFAULT = 9;
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
-  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2};
-  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256};
-  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true};
+  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2, 4, 8, 6}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1};
+  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640};
+  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true, true, true, true};
+  static const bool colv[NVARIANTS] = {false, false, false, false, false, false, false, false, true, true, true};
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
   c.qubit = qubit ? 1 : 0;
   const bool gm = want_gmres && !getenv("QD_FORCE_NEUMANN");
-  auto fits = [&](int v) { return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v]; };
+  // column layout (V8/V9): one wave per column of rho, N <= 64 lanes used
+  auto colblock = [&](int v) { return 64 * ((S.N + ept[v] - 1) / ept[v]); };
+  auto fits = [&](int v) {
+    if (colv[v]) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= maxb[v] && lds_bytes(S, colblock(v), true, false, false, 1, true) <= 160 * 1024;
+    return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v];
+  };
   int var;
   if (dim <= 64) var = 0;
   else if (dim <= 256) var = 1;
   else if (dim <= 1024) var = (qubit && nb < 512) ? 5 : 2;
-  else var = 4;
+  else var = fits(QD_COL_DEFAULT) ? QD_COL_DEFAULT : 4;
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
-    if (v >= 0 && v < 6 && fits(v)) var = v;
+    if (v >= 0 && v < NVARIANTS && v != 6 && v != 7 && fits(v)) var = v;
   }
   if (!fits(var)) var = dim <= 64 ? 0 : dim <= 256 ? 1 : dim <= 1024 ? 2 : 4;
   if (qubit) {  // the qubit translation units only build the variants that match their fixed dimension
@@ -244,9 +251,9 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   }
   const int epe = ept[var] / icpb[var];
   c.var = var;
-  c.block = ((dim + epe - 1) / epe + 63) / 64 * 64;
+  c.block = colv[var] ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
   c.gmres = 0;
-  c.lds = lds_bytes(S, c.block, dbuf[var], false, false, icpb[var]);
+  c.lds = lds_bytes(S, c.block, dbuf[var], false, false, icpb[var], colv[var]);
   if (gm && ept[var] == 1) {
     const size_t with = lds_bytes(S, c.block, dbuf[var], false, true, icpb[var]);
     if (with <= 160 * 1024) {

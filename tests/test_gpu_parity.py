@@ -84,6 +84,32 @@ def test_objective_and_gradient_vs_oracle(kw, penalties):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("var", ["8", "9", "10"])
+@pytest.mark.parametrize("kw", [SHAPES[3], SHAPES[5], SHAPES[7]])
+def test_column_layout_variants(kw, var, monkeypatch):
+    """Column-per-wave kernels (V8/V9/V10, the default for Lindblad systems with dim > 1024) forced onto
+    the 3x20 system, a small system with dipole-dipole coupling and one with guard levels."""
+    monkeypatch.setenv("QD_VAR", var)
+    if kw["nlevels"] == [3, 20]:
+        kw = {**kw, "init": "basis, 0"}
+    sp, h, orc = _pair(kw, ntime=20, penalties=True)
+    rng = np.random.default_rng(7)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    x = rng.standard_normal((2, 2 * h.dim))
+    t = 0.37 * sp.time.ntime * sp.time.dt
+    for tr in (False, True):
+        yo = orc.apply_rhs(t, x, transpose=tr)
+        np.testing.assert_allclose(h.apply_rhs(t, x, transpose=tr), yo, rtol=1e-13, atol=1e-13 * np.abs(yo).max())
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7]])
 def test_gmres_solver_vs_oracle_gmres(kw):
     """linearsolver_type = gmres: in-kernel GMRES (Krylov basis in LDS) against the oracle's GMRES."""
