@@ -104,6 +104,19 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// value of the next (UP = true) / previous lane of the wave; lanes without a source get 0
+template <bool UP>
+__device__ __forceinline__ double lane_shift(double v) {
+  constexpr int CTRL = UP ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */;
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <bool UP>
+__device__ __forceinline__ double2 lane_shift(double2 v) {
+  return make_double2(lane_shift<UP>(v.x), lane_shift<UP>(v.y));
+}
+
 template <bool ONEWAVE>
 __device__ __forceinline__ void team_sync() {
   if (!ONEWAVE) __syncthreads();
@@ -700,8 +713,8 @@ struct QubitStencil {
 
 
 // ---------------------------------------------------------------------------------------------
-// column stencil (Lindblad, runtime level counts, N <= 64): lane = row I of rho, wave w owns the columns
-// I' = w, w + nw, w + 2 nw, ...  (vectorised index it = I' N + I, util.cpp:150).  Every ket-side
+// column stencil (Lindblad, runtime level counts, N <= 64): lane = row I of rho, wave w owns the EPT columns
+// I' = w EPT .. w EPT + EPT - 1  (vectorised index it = I' N + I, util.cpp:150).  Every ket-side
 // quantity (digits of I', ladder coefficients, neighbour columns) is wave-uniform and lives on the
 // scalar unit or in one broadcast LDS read; every bra-side quantity is an invariant of the thread.
 // Nothing per slot has to be kept in vector registers except the two diagonal coefficients.
@@ -712,7 +725,7 @@ struct ColStencil {
   int it[EPT];
   bool valid[EPT];
   double dw[EPT], dd[EPT];
-  int N, row, col0, cstride;
+  int N, row, col0;
   unsigned dbra;
   double su[Q], sd[Q];    // sqrt(i_k + 1) (0 at the top level), sqrt(i_k) of this thread's row
   double g1u[Q], g1d[Q];  // gamma_1 su / gamma_1 sd (T1 off-diagonal, forward / transposed)
@@ -720,13 +733,12 @@ struct ColStencil {
   int ofs[Q];
 
   __device__ __forceinline__ static int dig(unsigned d, int k) { return (int)((d >> (DB * k)) & ((1u << DB) - 1u)); }
-  __device__ __forceinline__ int colof(int j) const { return min(col0 + j * cstride, N - 1); }  // wave-uniform
+  __device__ __forceinline__ int colof(int j) const { return min(col0 + j, N - 1); }  // wave-uniform
 
   __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
     N = S.N;
     const int lane = threadIdx.x & 63;
-    col0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    cstride = (int)(blockDim.x >> 6);
+    col0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * EPT;  // wave w owns the columns w EPT .. w EPT + EPT - 1
     const bool rowok = lane < N;
     row = rowok ? lane : N - 1;
     int o = 0;
@@ -760,7 +772,7 @@ struct ColStencil {
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int craw = col0 + j * cstride, cc = min(craw, N - 1);
+      const int craw = col0 + j, cc = min(craw, N - 1);
       valid[j] = rowok && craw < N;
       it[j] = cc * N + row;
       int ipa[Q];
@@ -805,9 +817,15 @@ struct ColStencil {
 
   // HASJ = false: the caller has checked S.hasJ == 0; the slot loop is then free of branches and two
   // slots can be in flight (Variant::FENCE)
+  // The last oscillator has stride 1 (post[Q-1] == 1): its bra neighbours are the adjacent LANES of the
+  // same slot and its ket neighbours the adjacent SLOTS of the same thread, so they come from registers
+  // (`xs` = own element, `xprev` / `xnext` = elements of slot j-1 / j+1 of the vector being read) instead
+  // of LDS; only the first / last column of a wave's block reads the neighbouring wave's column.  A
+  // neighbour that does not exist always has a zero coefficient, the value fetched for it is arbitrary
+  // but finite (idle lanes and slots compute on clamped indices).
   template <bool TRANS, bool HASJ = true>
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
-                                           const double2 xs) const {
+                                           const double2 xs, const double2 xprev, const double2 xnext) const {
     const int cc = colof(j), cN = cc * N;
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
     double l1r = 0.0, l1i = 0.0;
@@ -817,13 +835,20 @@ struct ColStencil {
       const int cu = min(cc + st, N - 1) * N, cd = max(cc - st, 0) * N;
       const double2 ct = L.coltab[cc * Q + k];
       const int r0 = opaque(row), ru = opaque(rup[k]), rd = opaque(rdn[k]);  // addresses are re-derived, not hoisted
-      const double2 xu = sx[cN + ru], xd = sx[cN + rd], xup = sx[cu + r0], xdp = sx[cd + r0];
+      const bool last = (k == Q - 1);
+      const bool reg_up = last && j < EPT - 1, reg_dn = last && j > 0;  // compile-time after unrolling
+      const double2 xu = last ? lane_shift<true>(xs) : sx[cN + ru];
+      const double2 xd = last ? lane_shift<false>(xs) : sx[cN + rd];
+      const double2 xup = reg_up ? xnext : sx[cu + r0];
+      const double2 xdp = reg_dn ? xprev : sx[cd + r0];
       const double er = fma(-ct.y, xdp.x, su[k] * xu.x), ei = fma(-ct.y, xdp.y, su[k] * xu.y);
       const double fr = fma(ct.x, xup.x, -sd[k] * xd.x), fi = fma(ct.x, xup.y, -sd[k] * xd.y);
       hr = fma(c.q[k], er + fr, fma(c.p[k], ei - fi, hr));
       hi = fma(c.q[k], ei + fi, fma(-c.p[k], er - fr, hi));
       {  // T1 off-diagonal term; without decay the coefficient is an exact zero
-        const double2 xl = sx[TRANS ? cd + rd : cu + ru];
+        double2 xl;
+        if (TRANS) xl = reg_dn ? lane_shift<false>(xprev) : sx[cd + rd];
+        else xl = reg_up ? lane_shift<true>(xnext) : sx[cu + ru];
         const double l1 = TRANS ? g1d[k] * ct.y : g1u[k] * ct.x;
         l1r = fma(l1, xl.x, l1r);
         l1i = fma(l1, xl.y, l1i);
@@ -1090,10 +1115,11 @@ struct Team {
     team_sync<V::ONEWAVE>();
   }
 
+  // xprev / xnext: elements of slots j-1 / j+1 of the vector being read (column layout only)
   template <bool TRANS, bool HASJ>
   __device__ __forceinline__ double2 apply_slot(const DevSys& S, const double2* __restrict__ sx, const StepC<Q>& c, int j,
-                                                const double2 xs) const {
-    if constexpr (V::COL) return st.template apply<TRANS, HASJ>(S, L, sx, c, j, xs);
+                                                const double2 xs, const double2 xprev, const double2 xnext) const {
+    if constexpr (V::COL) return st.template apply<TRANS, HASJ>(S, L, sx, c, j, xs, xprev, xnext);
     else return st.template apply<TRANS>(S, L, sx, c, j, xs);
   }
 
@@ -1101,7 +1127,7 @@ struct Team {
   __device__ __forceinline__ void apply_sweep(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x[j]);
+      y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x[j], x[j > 0 ? j - 1 : 0], x[j + 1 < EPT ? j + 1 : j]);
       if ((j % V::FENCE) == V::FENCE - 1) slot_fence<EPE>();
     }
   }
@@ -1115,9 +1141,12 @@ struct Team {
   template <bool TRANS, bool HASJ>
   __device__ __forceinline__ void neumann_sweep(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ src,
                                                 const double2 (&b)[EPT], double2 (&y)[EPT], double (&dloc)[ICPB]) {
+    double2 yprev = y[0];  // OLD iterate of slot j-1 (Jacobi update)
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const double2 t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, y[j]);
+      const double2 yold = y[j];
+      const double2 t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, yold, yprev, y[j + 1 < EPT ? j + 1 : j]);
+      yprev = yold;
       const double2 bj = V::BLDS ? L.bvec[lidx(j)] : b[j];
       double2 w;
       w.x = fma(alpha, t.x, bj.x);
