@@ -238,7 +238,11 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"{args.workload}_{args.mode}", {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(pmc)).get(f"{args.workload}_{args.mode}", {})
+            if ent.get("hbm_bytes_per_unit") is not None:  # profiled with a shorter time grid: scale to this launch
+                traffic = ent["hbm_bytes_per_unit"] * units_per_launch
+            else:
+                traffic = ent.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 

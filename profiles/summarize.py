@@ -66,10 +66,17 @@ def main():
             if ("k_forward" in k or "k_adjoint" in k) and "hbm_bytes_per_launch_fetch_x2" in v:
                 tot += v["hbm_bytes_per_launch_fetch_x2"]
                 names.append(k[:60])
+        units = None  # units (time steps x initial conditions) per launch of the profiled command
+        try:
+            line = [l for l in open(os.path.join(out, "bench_pmc_fetch.log")) if l.startswith("{")][-1]
+            units = json.loads(line)["roofline"]["units_per_launch"]
+        except Exception:
+            pass
         if names:
             latest_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json")
             latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
-            latest[key] = {"hbm_bytes_per_launch": tot, "kernels": names, "source": f"profiles/{tag}_summary.json",
+            latest[key] = {"hbm_bytes_per_launch": tot, "units_per_launch": units,
+                           "hbm_bytes_per_unit": (tot / units) if units else None, "kernels": names, "source": f"profiles/{tag}_summary.json",
                            "correction": "FETCH_SIZE x2 (gfx950, calibrated on this kernel's 8-byte loads) + WRITE_SIZE, units of 1 KiB"}
             json.dump(latest, open(latest_path, "w"), indent=1)
             # gpurun only merges gpurun_out/ back: leave a copy there

@@ -310,6 +310,7 @@ __device__ __forceinline__ int at_use(int v) {
 // ---------------------------------------------------------------------------------------------
 template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct GenStencil {
+  static constexpr bool NEEDS_SLOTS = false;  // apply() reads every neighbour from LDS
   static constexpr int DB = (Q <= 4) ? 8 : 6;  // bits per packed digit (levels <= 255, or <= 63 for Q = 5)
   int it[EPT];         // storage index (clamped to dim-1 for slots beyond the vector)
   bool valid[EPT];
@@ -542,6 +543,7 @@ __device__ __forceinline__ double flip_if(double v, unsigned cond) {  // cond ? 
 
 template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct QubitStencil {
+  static constexpr bool NEEDS_SLOTS = false;
   int it[EPT];
   bool valid[EPT];  // only the single-wave variant can have idle lanes (dim < 64)
   double dw[EPT], dd[EPT];
@@ -721,6 +723,7 @@ struct QubitStencil {
 // ---------------------------------------------------------------------------------------------
 template <int Q, int EPT>
 struct ColStencil {
+  static constexpr bool NEEDS_SLOTS = true;  // apply() takes the thread's other elements of the vector being read
   static constexpr int DB = (Q <= 4) ? 8 : 6;
   int it[EPT];
   bool valid[EPT];
@@ -819,13 +822,14 @@ struct ColStencil {
   // slots can be in flight (Variant::FENCE)
   // The last oscillator has stride 1 (post[Q-1] == 1): its bra neighbours are the adjacent LANES of the
   // same slot and its ket neighbours the adjacent SLOTS of the same thread, so they come from registers
-  // (`xs` = own element, `xprev` / `xnext` = elements of slot j-1 / j+1 of the vector being read) instead
+  // (`xall` = the thread's elements of the vector being read: own element xall[j], slots j-1 / j+1) instead
   // of LDS; only the first / last column of a wave's block reads the neighbouring wave's column.  A
   // neighbour that does not exist always has a zero coefficient, the value fetched for it is arbitrary
   // but finite (idle lanes and slots compute on clamped indices).
   template <bool TRANS, bool HASJ = true>
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
-                                           const double2 xs, const double2 xprev, const double2 xnext) const {
+                                           const double2 (&xall)[EPT]) const {
+    const double2 xs = xall[j], xprev = xall[j > 0 ? j - 1 : 0], xnext = xall[j + 1 < EPT ? j + 1 : j];
     const int cc = colof(j), cN = cc * N;
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
     double l1r = 0.0, l1i = 0.0;
@@ -901,12 +905,178 @@ struct ColStencil {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// qubit stencil, four elements per thread (Lindblad, dim = 4^Q, block = dim / 4): element of slot j is
+// it = tid | j << (2Q-2).  Bits 0 .. 2Q-3 of `it` belong to the thread, the two top bits (ket digits of
+// oscillators 1 and 0) are the slot number, i.e. compile-time constants after unrolling.  Hence
+//   * every digit sign and T1 validity is either a thread invariant or a constant (nothing per element),
+//   * the LDS offset of a neighbour is a thread invariant plus an immediate slot offset,
+//   * the ket neighbours of oscillators 0 and 1 are the thread's OWN other slots (registers, no LDS).
+// ---------------------------------------------------------------------------------------------
+template <int Q>
+struct QubitSlotStencil {
+  static_assert(Q >= 2, "needs two oscillators for the slot bits");
+  static constexpr bool NEEDS_SLOTS = true;
+  static constexpr int EPT = 4;
+  static constexpr int TB = 2 * Q - 2;                 // number of thread bits
+  static constexpr unsigned SLOT_BYTES = 16u << TB;    // LDS distance of consecutive slots
+  int it[EPT];
+  bool valid[EPT];
+  double dw[EPT], dd[EPT];
+  unsigned ab[Q], ak[Q], al[Q];  // byte offsets (slot 0) of the bra / ket (k >= 2) / T1 (k >= 2) neighbour of oscillator k
+  double qb[Q], qk[Q];           // q_k with the sign of the bra / (k >= 2) ket digit of this thread [per step]
+  double l1f[Q], l1t[Q];         // thread part of the T1 off-diagonal coefficient, forward / transposed
+
+  __device__ __forceinline__ static constexpr int brabit(int k) { return Q - 1 - k; }
+  __device__ __forceinline__ static constexpr int ketbit(int k) { return 2 * Q - 1 - k; }
+  // slot bit of oscillator k < 2: bit (1 - k) of the slot number
+  __device__ __forceinline__ static constexpr int slotbit(int j, int k) { return (j >> (1 - k)) & 1; }
+
+  __device__ __forceinline__ void init(const DevSys& S, const Lds&) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      it[j] = (int)(tid | ((unsigned)j << TB));
+      valid[j] = true;
+      double hd = 0.0, hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int a = (it[j] >> brabit(k)) & 1, ap = (it[j] >> ketbit(k)) & 1;
+        hd += S.detune[k] * a;
+        hdp += S.detune[k] * ap;
+        d += S.g2[k] * (a * ap - 0.5 * (a + ap)) - S.g1[k] / 2.0 * (a + ap);
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          const int b = (it[j] >> brabit(l)) & 1, bp = (it[j] >> ketbit(l)) & 1;
+          hd -= S.xikl[pair] * a * b;
+          hdp -= S.xikl[pair] * ap * bp;
+          pair++;
+        }
+      }
+      dw[j] = hd - hdp;
+      dd[j] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const unsigned bb = 1u << brabit(k), kb = 1u << ketbit(k);
+      ab[k] = (tid ^ bb) << 4;
+      ak[k] = k >= 2 ? (tid ^ kb) << 4 : 0u;
+      al[k] = k >= 2 ? (tid ^ bb ^ kb) << 4 : ab[k];
+      const bool bra0 = (tid & bb) == 0;
+      if (k >= 2) {
+        const bool ket0 = (tid & kb) == 0;
+        l1f[k] = (bra0 && ket0) ? S.g1off[k] : 0.0;
+        l1t[k] = (!bra0 && !ket0) ? S.g1off[k] : 0.0;
+      } else {  // the ket digit is a slot bit: only the bra condition is a thread property
+        l1f[k] = bra0 ? S.g1off[k] : 0.0;
+        l1t[k] = !bra0 ? S.g1off[k] : 0.0;
+      }
+      qb[k] = qk[k] = 0.0;
+    }
+  }
+
+  __device__ __forceinline__ void prep(const StepC<Q>& c) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      qb[k] = flip_if(c.q[k], (tid >> brabit(k)) & 1);
+      if (k >= 2) qk[k] = flip_if(c.q[k], (tid >> ketbit(k)) & 1);
+    }
+  }
+
+  __device__ __forceinline__ static double2 at(const double2* __restrict__ sx, unsigned byteoff, int slot) {
+    return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sx) + byteoff + (unsigned)slot * SLOT_BYTES);
+  }
+
+  // gradient contraction (once per step): plain LDS formulation, see QubitStencil::ladder
+  __device__ __forceinline__ void ladder(const DevSys&, const Lds&, const double2* __restrict__ sx, int k, int j, double2& A,
+                                         double2& B) const {
+    const int i0 = opaque(it[j]);
+    const unsigned a = (i0 >> brabit(k)) & 1, ap = (i0 >> ketbit(k)) & 1;
+    const double2 xb = sx[i0 ^ (1 << brabit(k))], xk = sx[i0 ^ (1 << ketbit(k))];
+    A.x = flip_if(xb.x, a) + flip_if(xk.x, ap);
+    A.y = flip_if(xb.y, a) + flip_if(xk.y, ap);
+    B.x = xb.x - xk.x;
+    B.y = xb.y - xk.y;
+  }
+
+  template <bool TRANS, bool HASJ = true>
+  __device__ __forceinline__ double2 apply(const DevSys& S, const Lds&, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                           const double2 (&xall)[EPT]) const {
+    const double2 xs = xall[j];
+    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0.0, gi = 0.0;
+    double l1r = 0.0, l1i = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const double2 xb = at(sx, ab[k], j);
+      double2 xk;
+      double sqk;
+      if (k < 2) {  // ket neighbour = own slot with the slot bit flipped; sign of the slot bit is a constant
+        xk = xall[j ^ (1 << (1 - k))];
+        sqk = slotbit(j, k) ? -c.q[k] : c.q[k];
+      } else {
+        xk = at(sx, ak[k], j);
+        sqk = qk[k];
+      }
+      double tr = fma(sqk, xk.x, qb[k] * xb.x), ti = fma(sqk, xk.y, qb[k] * xb.y);
+      tr = fma(c.p[k], xb.y - xk.y, tr);
+      ti = fma(-c.p[k], xb.x - xk.x, ti);
+      if (k & 1) { gr += tr; gi += ti; }
+      else { hr += tr; hi += ti; }
+      // T1 off-diagonal: forward needs both digits 0 (neighbour has both set), transposed both 1
+      const bool slot_ok = k >= 2 || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
+      if (slot_ok) {
+        const double2 xl = at(sx, al[k], k < 2 ? (j ^ (1 << (1 - k))) : j);
+        const double l1 = TRANS ? l1t[k] : l1f[k];
+        l1r = fma(l1, xl.x, l1r);
+        l1i = fma(l1, xl.y, l1i);
+      }
+    }
+    hr += gr;
+    hi += gi;
+    if (HASJ && S.hasJ) {  // see QubitStencil::apply
+      const int i0 = opaque(it[j]);
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+#pragma unroll
+        for (int l = k + 1; l < Q; l++, pair++) {
+          const double Jkl = S.J[pair];
+          const unsigned a = (i0 >> brabit(k)) & 1, b = (i0 >> brabit(l)) & 1;
+          const double2 xj = sx[i0 ^ ((1 << brabit(k)) | (1 << brabit(l)))];
+          const double mb = (a != b) ? 1.0 : 0.0;
+          double ar = mb * flip_if(xj.x, b), ai = mb * flip_if(xj.y, b);
+          double br = mb * xj.x, bi = mb * xj.y;
+          const unsigned ap = (i0 >> ketbit(k)) & 1, bp = (i0 >> ketbit(l)) & 1;
+          const double2 xq = sx[i0 ^ ((1 << ketbit(k)) | (1 << ketbit(l)))];
+          const double mk = (ap != bp) ? 1.0 : 0.0;
+          ar += mk * flip_if(xq.x, bp);
+          ai += mk * flip_if(xq.y, bp);
+          br -= mk * xq.x;
+          bi -= mk * xq.y;
+          const double co = c.cs[pair], si = c.sn[pair];
+          hr += Jkl * (si * ar + co * bi);
+          hi += Jkl * (si * ai - co * br);
+        }
+      }
+    }
+    const double yr = fma(dd[j], xs.x, TRANS ? -hr : hr) + l1r, yi = fma(dd[j], xs.y, TRANS ? -hi : hi) + l1i;
+    return make_double2(yr, yi);
+  }
+
+  __device__ __forceinline__ bool is_guard(const DevSys&, int) const { return false; }
+};
+
 template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false>
 struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, bool LIND, int EPT, int EPE>
 struct StencilSel<Q, LIND, EPT, EPE, true, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, int EPT, int EPE>
 struct StencilSel<Q, true, EPT, EPE, false, true> { typedef ColStencil<Q, EPT> type; };
+template <int Q>
+struct StencilSel<Q, true, 4, 4, true, false> { typedef QubitSlotStencil<Q> type; };
 
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
 template <int Q, bool LIND, int EPT, int EPE>
@@ -915,6 +1085,8 @@ template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const QubitStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
 template <int Q, int EPT>
 __device__ __forceinline__ bool slot_valid(const ColStencil<Q, EPT>& st, int j) { return st.valid[j]; }
+template <int Q>
+__device__ __forceinline__ bool slot_valid(const QubitSlotStencil<Q>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)
@@ -1115,25 +1287,25 @@ struct Team {
     team_sync<V::ONEWAVE>();
   }
 
-  // xprev / xnext: elements of slots j-1 / j+1 of the vector being read (column layout only)
+  // xall: the thread's elements of the vector being read (used by the stencils that take neighbours from registers)
   template <bool TRANS, bool HASJ>
   __device__ __forceinline__ double2 apply_slot(const DevSys& S, const double2* __restrict__ sx, const StepC<Q>& c, int j,
-                                                const double2 xs, const double2 xprev, const double2 xnext) const {
-    if constexpr (V::COL) return st.template apply<TRANS, HASJ>(S, L, sx, c, j, xs, xprev, xnext);
-    else return st.template apply<TRANS>(S, L, sx, c, j, xs);
+                                                const double2 (&xall)[EPT]) const {
+    if constexpr (ST::NEEDS_SLOTS) return st.template apply<TRANS, HASJ>(S, L, sx, c, j, xall);
+    else return st.template apply<TRANS>(S, L, sx, c, j, xall[j]);
   }
 
   template <bool TRANS, bool HASJ>
   __device__ __forceinline__ void apply_sweep(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x[j], x[j > 0 ? j - 1 : 0], x[j + 1 < EPT ? j + 1 : j]);
+      y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x);
       if ((j % V::FENCE) == V::FENCE - 1) slot_fence<EPE>();
     }
   }
   template <bool TRANS>
   __device__ __forceinline__ void apply_all(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
-    if (V::COL && !S.hasJ) apply_sweep<TRANS, false>(S, c, x, y);
+    if (ST::NEEDS_SLOTS && !S.hasJ) apply_sweep<TRANS, false>(S, c, x, y);
     else apply_sweep<TRANS, true>(S, c, x, y);
   }
 
@@ -1141,17 +1313,17 @@ struct Team {
   template <bool TRANS, bool HASJ>
   __device__ __forceinline__ void neumann_sweep(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ src,
                                                 const double2 (&b)[EPT], double2 (&y)[EPT], double (&dloc)[ICPB]) {
-    double2 yprev = y[0];  // OLD iterate of slot j-1 (Jacobi update)
+    double2 yold[EPT];  // the iterate being read (Jacobi update): y is overwritten slot by slot
+#pragma unroll
+    for (int j = 0; j < EPT; j++) yold[j] = y[j];
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const double2 yold = y[j];
-      const double2 t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, yold, yprev, y[j + 1 < EPT ? j + 1 : j]);
-      yprev = yold;
+      const double2 t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, yold);
       const double2 bj = V::BLDS ? L.bvec[lidx(j)] : b[j];
       double2 w;
       w.x = fma(alpha, t.x, bj.x);
       w.y = fma(alpha, t.y, bj.y);
-      const double dx = y[j].x - w.x, dy = y[j].y - w.y;
+      const double dx = yold[j].x - w.x, dy = yold[j].y - w.y;
       dloc[icslot(j)] += ok(j) ? dx * dx + dy * dy : 0.0;
       y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
       if (V::DBUF && ok(j)) bufp(cur)[lidx(j)] = w;
@@ -1186,7 +1358,7 @@ struct Team {
       for (int q = 0; q < ICPB; q++) dloc[q] = 0.0;
       const double2* src = vec();
       if (V::DBUF) cur ^= 1;  // the new iterate goes to the other buffer: ONE barrier (inside the reduction)
-      if (V::COL && !A.S.hasJ) neumann_sweep<TRANS, false>(A, c, alpha, src, b, y, dloc);
+      if (ST::NEEDS_SLOTS && !A.S.hasJ) neumann_sweep<TRANS, false>(A, c, alpha, src, b, y, dloc);
       else neumann_sweep<TRANS, true>(A, c, alpha, src, b, y, dloc);
       // clamp: adjoint solves of badly scaled problems have update norms whose square overflows fp32; a
       // clamped value is still far above both thresholds (the reference's reltol is 1e-20).  With several
