@@ -266,7 +266,7 @@ def main():
                 "name": args.workload,
                 "mode": "forward sweep (evalF)" if args.mode == "fwd" else "forward + adjoint gradient (evalGradF)",
                 "system_dim": dim, "ninit": ninit_global, "ninit_per_gpu": ninit_local, "ntime": ntime, "dt": spec.time.dt,
-                "timestepper": "IMR", "linearsolver": "neumann (in-kernel)",
+                "timestepper": "IMR", "linearsolver": ("gmres" if spec.solver.linsolve == 0 else "neumann") + " (in-kernel)",
                 "parallelism": (f"{world} GPU(s): one full set of {ninit} initial conditions per GPU (weak)" if weak else
                                 f"{ninit} initial conditions split over {world} GPU(s)"),
                 "rhs_applications_per_step": applies / args.steps,

@@ -63,8 +63,10 @@ constexpr int NVARIANTS = 11;
 // (large elements-per-thread variants would otherwise spill)
 
 constexpr int NRED = 16;  // max values reduced at once (2*QD_MAX_OSC)
-constexpr int GMRES_MR = 10;                                     // restart length of the in-kernel GMRES
-constexpr int GMRES_NSC = (GMRES_MR + 2) + 2 * GMRES_MR + (GMRES_MR + 2) + GMRES_MR * GMRES_MR + GMRES_MR;  // scalars
+constexpr int GMRES_MR = 10;    // restart length of the GMRES whose Krylov basis lives in LDS
+constexpr int GMRES_MR_G = 30;  // restart length with the basis in global memory (= PETSc's default KSPGMRES restart)
+constexpr int gmres_nsc(int mr) { return (mr + 2) + 2 * mr + (mr + 2) + mr * mr + mr; }  // scalars of the Hessenberg problem
+constexpr int GMRES_NSC = gmres_nsc(GMRES_MR);
 
 // ---------------------------------------------------------------------------------------------
 // reductions
@@ -247,7 +249,9 @@ __host__ __device__ inline int table_len(const DevSys& S) {
   for (int k = 0; k < S.Q; k++) t += S.n[k];
   return (t + 1) & ~1;
 }
-__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, bool krylov = false, int icpb = 1,
+// krylov: 0 = Neumann only, 1 = GMRES with the Krylov basis in LDS, 2 = GMRES with the basis in global
+// memory (only the small Hessenberg problem lives in LDS)
+__device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, int krylov = 0, int icpb = 1,
                                      bool col = false) {
   Lds l;
   l.buf0 = reinterpret_cast<double2*>(smem);
@@ -258,21 +262,26 @@ __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool 
   l.tup = reinterpret_cast<double*>(l.buf0 + nvec * (size_t)S.dim);
   l.tdn = l.tup + tl;
   l.red = l.tdn + tl;
+  double* p = l.red + 2 * NRED * ((blockDim.x + 63) >> 6);
   l.kry = nullptr;
   l.ksc = nullptr;
   l.coltab = nullptr;
-  if (col) l.coltab = reinterpret_cast<double2*>(l.red + 2 * NRED * ((blockDim.x + 63) >> 6));  // never together with krylov
-  if (krylov) {
-    const int nw = (blockDim.x + 63) >> 6;
-    l.kry = reinterpret_cast<double2*>(l.red + 2 * NRED * nw);
-    l.ksc = reinterpret_cast<double*>(l.kry + (size_t)(GMRES_MR + 1) * S.dim);
+  if (col) {
+    l.coltab = reinterpret_cast<double2*>(p);
+    p += 2 * (size_t)S.N * S.Q;
   }
+  if (krylov == 1) {
+    l.kry = reinterpret_cast<double2*>(p);
+    p += 2 * (size_t)(GMRES_MR + 1) * S.dim;
+  }
+  if (krylov) l.ksc = p;
   return l;
 }
-static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, bool krylov = false, int icpb = 1, bool col = false) {
+static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, int krylov = 0, int icpb = 1, bool col = false) {
   return (col ? sizeof(double2) * (size_t)S.N * S.Q : 0) + sizeof(double2) * (size_t)S.dim * icpb * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
          sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64) +
-         (krylov ? sizeof(double2) * (size_t)(GMRES_MR + 1) * S.dim + sizeof(double) * GMRES_NSC : 0);
+         (krylov == 1 ? sizeof(double2) * (size_t)(GMRES_MR + 1) * S.dim + sizeof(double) * GMRES_NSC : 0) +
+         (krylov == 2 ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
 }
 
 // Keeps index arithmetic INSIDE the time loop: without it the compiler hoists every neighbour index,
@@ -1236,7 +1245,7 @@ struct Team {
   int ic0;      // first initial condition of this workgroup
   int nb;       // batch size
 
-  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, int nbatch, bool krylov = false) {
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, int nbatch, int krylov = 0) {
     L = carve(smem, S, V::DBUF, V::BLDS, krylov, ICPB, V::COL);
     st.init(S, L);
     cur = 0;
@@ -1503,10 +1512,149 @@ struct Team {
     return napp;
   }
 
+  // The same GMRES for any number of elements per thread and any dimension: the Krylov basis lives in
+  // global memory (A.kry, [nb][GMRES_MR_G + 1][dim] interleaved complex; every thread only ever touches
+  // its own elements of the basis vectors), the vector the stencil reads is published in LDS like a
+  // Neumann iterate.  On exit y is in registers (NOT published).
+  template <bool TRANS>
+  __device__ __forceinline__ int gmres_g(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
+    static_assert(ICPB == 1, "one initial condition per workgroup");
+    double2* __restrict__ Vg = reinterpret_cast<double2*>(A.kry) + (size_t)ic0 * (GMRES_MR_G + 1) * dim;
+    double* hc = L.ksc;
+    double* cs = hc + (GMRES_MR_G + 2);
+    double* sn = cs + GMRES_MR_G;
+    double* g = sn + GMRES_MR_G;
+    double* R = g + (GMRES_MR_G + 2);
+    double* yk = R + GMRES_MR_G * GMRES_MR_G;
+    double2 yy[EPT], r[EPT], v[EPT], w[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      yy[j] = make_double2(0.0, 0.0);
+      r[j] = b[j];
+    }
+    int its = 0, napp = 0;
+    double ttol = 0.0;
+    for (int cycle = 0;; cycle++) {
+      double t1[1] = {0.0};
+#pragma unroll
+      for (int j = 0; j < EPT; j++) t1[0] += ok(j) ? r[j].x * r[j].x + r[j].y * r[j].y : 0.0;
+      sum<1>(t1);
+      const double beta = sqrt(t1[0]);
+      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+      if (beta <= ttol || its >= A.maxiter) break;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        v[j] = make_double2(r[j].x / beta, r[j].y / beta);
+        if (ok(j)) Vg[at_use<EPE>(st.it[j])] = v[j];
+      }
+      publish(v);
+      double gcur = beta;
+      int jj = 0;
+      bool conv = false;
+      while (jj < GMRES_MR_G) {
+        double2 t2[EPT];
+        if (ST::NEEDS_SLOTS && !A.S.hasJ) apply_sweep<TRANS, false>(A.S, c, v, t2);
+        else apply_sweep<TRANS, true>(A.S, c, v, t2);
+        napp++;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) w[j] = make_double2(v[j].x - alpha * t2[j].x, v[j].y - alpha * t2[j].y);
+        for (int k0 = 0; k0 <= jj; k0 += 4) {  // classical Gram-Schmidt, four projections per reduction
+          double h4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int k = k0 + q;
+            if (k <= jj) {
+#pragma unroll
+              for (int j = 0; j < EPT; j++)
+                if (ok(j)) {
+                  const double2 vk = Vg[(size_t)k * dim + at_use<EPE>(st.it[j])];
+                  h4[q] += w[j].x * vk.x + w[j].y * vk.y;
+                }
+            }
+          }
+          sum<4>(h4);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (k0 + q <= jj) hc[k0 + q] = h4[q];
+        }
+        for (int k = 0; k <= jj; k++) {
+          const double h = hc[k];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            const double2 vk = Vg[(size_t)k * dim + at_use<EPE>(st.it[j])];
+            w[j].x -= h * vk.x;
+            w[j].y -= h * vk.y;
+          }
+        }
+        double nn[1] = {0.0};
+#pragma unroll
+        for (int j = 0; j < EPT; j++) nn[0] += ok(j) ? w[j].x * w[j].x + w[j].y * w[j].y : 0.0;
+        sum<1>(nn);
+        const double hn = sqrt(nn[0]);
+        hc[jj + 1] = hn;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          v[j] = hn > 0.0 ? make_double2(w[j].x / hn, w[j].y / hn) : make_double2(0.0, 0.0);
+          if (ok(j)) Vg[(size_t)(jj + 1) * dim + at_use<EPE>(st.it[j])] = v[j];
+        }
+        // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
+        double cur_h = hc[0];
+        for (int k = 0; k < jj; k++) {
+          const double a1 = hc[k + 1], ck = cs[k], sk = sn[k];
+          R[k * GMRES_MR_G + jj] = ck * cur_h + sk * a1;
+          cur_h = -sk * cur_h + ck * a1;
+        }
+        const double a0 = cur_h, bb = hn;
+        const double rr = sqrt(a0 * a0 + bb * bb);
+        const double cj = rr == 0.0 ? 1.0 : a0 / rr, sj = rr == 0.0 ? 0.0 : bb / rr;
+        cs[jj] = cj;
+        sn[jj] = sj;
+        R[jj * GMRES_MR_G + jj] = rr;
+        g[jj] = cj * gcur;
+        gcur = -sj * gcur;
+        its++;
+        jj++;
+        publish(v);  // v_{jj} becomes the stencil-readable vector; its barriers also order the scalar writes
+        if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
+        if (its >= A.maxiter) break;
+      }
+      for (int rw = jj - 1; rw >= 0; rw--) {
+        double sacc = g[rw];
+        for (int cc = rw + 1; cc < jj; cc++) sacc -= R[rw * GMRES_MR_G + cc] * yk[cc];
+        yk[rw] = sacc / R[rw * GMRES_MR_G + rw];
+      }
+      for (int cc = 0; cc < jj; cc++) {
+        const double f = yk[cc];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const double2 vk = Vg[(size_t)cc * dim + at_use<EPE>(st.it[j])];
+          yy[j].x += f * vk.x;
+          yy[j].y += f * vk.y;
+        }
+      }
+      if (conv || its >= A.maxiter) break;
+      // restart: r = b - (I - alpha M) y
+      publish(yy);
+      double2 t3[EPT];
+      if (ST::NEEDS_SLOTS && !A.S.hasJ) apply_sweep<TRANS, false>(A.S, c, yy, t3);
+      else apply_sweep<TRANS, true>(A.S, c, yy, t3);
+      napp++;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) r[j] = make_double2(b[j].x - (yy[j].x - alpha * t3[j].x), b[j].y - (yy[j].y - alpha * t3[j].y));
+      team_sync<V::ONEWAVE>();  // every thread has read the scalars of this cycle before the next one overwrites them
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = yy[j];
+    return napp;
+  }
+
   template <bool TRANS>
   __device__ __forceinline__ int solve(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
     if constexpr (EPT == 1) {
-      if (A.use_gmres) return gmres<TRANS>(A, c, alpha, b, y);
+      if (A.use_gmres == 1) return gmres<TRANS>(A, c, alpha, b, y);
+    }
+    if constexpr (ICPB == 1) {
+      if (A.use_gmres == 2) return gmres_g<TRANS>(A, c, alpha, b, y);
     }
     return neumann<TRANS>(A, c, alpha, b, y);
   }
@@ -1522,7 +1670,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   constexpr int EPT = TM::EPT, ICPB = TM::ICPB;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem, A.nb, A.use_gmres != 0);
+  tm.init(S, smem, A.nb, A.use_gmres);
   const int dim = S.dim;
   double2 x[EPT];
 #pragma unroll
@@ -1717,7 +1865,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   constexpr int EPT = TM::EPT, ICPB = TM::ICPB;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem, A.nb, A.use_gmres != 0);
+  tm.init(S, smem, A.nb, A.use_gmres);
   team_sync<TM::V::ONEWAVE>();
   const int dim = S.dim;
   double2 xb[EPT], xn[EPT];  // adjoint state, primal state x_n (end of the step being reversed)

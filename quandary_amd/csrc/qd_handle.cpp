@@ -63,7 +63,7 @@ extern "C" void qd_destroy(qd_handle* h) {
   (void)hipSetDevice(h->device);
   for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_pen, &h->d_dpdm, &h->d_out4,
-                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash})
+                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
   if (h->d_oscs) (void)hipFree(h->d_oscs);
@@ -474,6 +474,10 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
   a.napply = d_napply;
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
   a.use_gmres = cfg.gmres;
+  if (cfg.gmres == 2) {
+    if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
+    a.kry = d_kry.p;
+  }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
@@ -549,6 +553,10 @@ int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, co
   a.coeff = d_coeff.p;
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
   a.use_gmres = cfg.gmres;
+  if (cfg.gmres == 2) {
+    if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
+    a.kry = d_kry.p;
+  }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev0, stream));
   QD_HIP(launch_adjoint(a, cfg, stream));

@@ -60,7 +60,7 @@ struct SweepArgs {
   int cs, nsub, nstages, ntime, nb;
   double dt, Tfinal;
   int stepper_ee, linsolve, maxiter;
-  int use_gmres;  // 1: in-kernel GMRES (one-element-per-thread variants whose Krylov basis fits in LDS), else Neumann
+  int use_gmres;  // 0: Neumann; 1: in-kernel GMRES, Krylov basis in LDS (one element per thread, small dim); 2: basis in global memory (kry)
   double abstol, reltol;
   // penalties (src/timestepper.cpp:256-480)
   double gamma_penalty, penalty_param, gamma_dpdm;
@@ -77,6 +77,7 @@ struct SweepArgs {
   const double* jbar;   // [nb][3]
   double* coeff;        // [nb][nsub][2Q]  (x^T dM/dp_k z, x^T dM/dq_k z)
   double* xbar0;        // [nb][2*dim] adjoint at t=0 (diagnostic) or nullptr
+  double* kry;          // [nb][GMRES_MR_G+1][2*dim] Krylov basis of the GMRES variant whose basis does not fit in LDS
   double* stash;        // [2][nb][2*dim] staging area of the several-elements-per-thread variants (adjoint state / midpoint state
                         // parked in L2/HBM while a linear solve runs, instead of compiler-chosen scratch spills)
 };
@@ -85,7 +86,7 @@ struct LaunchCfg {
   int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)
   int qubit;  // 1: all oscillators have two levels -> bit-trick stencil
   int block;  // threads per block (one block per initial condition)
-  int gmres;  // 1: Krylov storage is part of the LDS carve-up
+  int gmres;  // 0 Neumann, 1 GMRES with the Krylov basis in LDS, 2 GMRES with the basis in global memory
   size_t lds;
 };
 
@@ -103,6 +104,7 @@ hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* su
 hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false);
+size_t krylov_doubles(const DevSys& S, int nb);  // size of SweepArgs::kry for LaunchCfg::gmres == 2
 
 void set_error(const std::string& msg);
 

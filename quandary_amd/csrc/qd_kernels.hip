@@ -230,7 +230,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   // column layout (V8/V9): one wave per column of rho, N <= 64 lanes used
   auto colblock = [&](int v) { return 64 * ((S.N + ept[v] - 1) / ept[v]); };
   auto fits = [&](int v) {
-    if (colv[v]) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= maxb[v] && lds_bytes(S, colblock(v), true, false, false, 1, true) <= 160 * 1024;
+    if (colv[v]) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= maxb[v] && lds_bytes(S, colblock(v), true, false, 2, 1, true) <= 160 * 1024;
     return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v];
   };
   int var;
@@ -253,16 +253,21 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   c.var = var;
   c.block = colv[var] ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
   c.gmres = 0;
-  c.lds = lds_bytes(S, c.block, dbuf[var], false, false, icpb[var], colv[var]);
-  if (gm && ept[var] == 1) {
-    const size_t with = lds_bytes(S, c.block, dbuf[var], false, true, icpb[var]);
-    if (with <= 160 * 1024) {
+  c.lds = lds_bytes(S, c.block, dbuf[var], false, 0, icpb[var], colv[var]);
+  if (gm && icpb[var] == 1) {
+    const size_t in_lds = lds_bytes(S, c.block, dbuf[var], false, 1, icpb[var], colv[var]);
+    if (ept[var] == 1 && in_lds <= 160 * 1024) {  // Krylov basis in LDS
       c.gmres = 1;
-      c.lds = with;
+      c.lds = in_lds;
+    } else {  // Krylov basis in global memory
+      c.gmres = 2;
+      c.lds = lds_bytes(S, c.block, dbuf[var], false, 2, icpb[var], colv[var]);
     }
   }
   return c;
 }
+
+size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G + 1) * 2 * (size_t)S.dim; }
 
 // ---------------------------------------------------------------------------------------------
 // dispatch to the per-(Q, Lindblad, qubit) translation units (qd_inst.hip)
