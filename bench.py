@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "grad"])
     ap.add_argument("--linsolve", default=None, choices=[None, "neumann", "gmres"])
     ap.add_argument("--ntime", type=int, default=None, help="override the number of time steps of the workload")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="override a config entry of the workload, e.g. --set 'initialcondition=diagonal, 0, 1, 2, 3, 4'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = one full set of initial conditions per GPU (default); strong = split the set over the GPUs")
@@ -169,6 +171,9 @@ def main():
         over["linearsolver_type"] = args.linsolve
     if args.ntime:
         over["ntime"] = args.ntime
+    for kv in args.set:
+        k, _, v = kv.partition("=")
+        over[k.strip()] = v.strip()
     spec = workload_spec(args.workload, mode, over)
     weak = world > 1 and args.scaling == "weak"
     if not weak and spec.ninit % world:

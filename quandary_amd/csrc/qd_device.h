@@ -1230,7 +1230,9 @@ __device__ __forceinline__ void finalizeJ_diff(const DevTarget& tg, double re, d
 // ---------------------------------------------------------------------------------------------
 // the per-workgroup machinery shared by the forward, adjoint and apply kernels
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int VAR, bool QUBIT>
+// GM: the GMRES code paths are compiled in (separate kernel instantiations, so that the Neumann kernels do
+// not pay for them in registers and code size)
+template <int Q, bool LIND, int VAR, bool QUBIT, bool GM = false>
 struct Team {
   typedef Variant<VAR> V;
   static constexpr int EPT = V::EPT;    // slots per thread
@@ -1650,10 +1652,10 @@ struct Team {
 
   template <bool TRANS>
   __device__ __forceinline__ int solve(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
-    if constexpr (EPT == 1) {
+    if constexpr (GM && EPT == 1) {
       if (A.use_gmres == 1) return gmres<TRANS>(A, c, alpha, b, y);
     }
-    if constexpr (ICPB == 1) {
+    if constexpr (GM && ICPB == 1) {
       if (A.use_gmres == 2) return gmres_g<TRANS>(A, c, alpha, b, y);
     }
     return neumann<TRANS>(A, c, alpha, b, y);
@@ -1663,10 +1665,10 @@ struct Team {
 // ---------------------------------------------------------------------------------------------
 // forward sweep: TimeStepper::solveODE for every initial condition of the batch
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int VAR, bool QUBIT>
+template <int Q, bool LIND, int VAR, bool QUBIT, bool GM>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team<Q, LIND, VAR, QUBIT> TM;
+  typedef Team<Q, LIND, VAR, QUBIT, GM> TM;
   constexpr int EPT = TM::EPT, ICPB = TM::ICPB;
   const DevSys& S = A.S;
   TM tm;
@@ -1858,10 +1860,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
 // (primal states come from the stored trajectory for Lindblad AND Schroedinger: 288 GB of HBM make
 // the reference's backward recomputation of the Schroedinger primal unnecessary)
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int VAR, bool QUBIT>
+template <int Q, bool LIND, int VAR, bool QUBIT, bool GM>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team<Q, LIND, VAR, QUBIT> TM;
+  typedef Team<Q, LIND, VAR, QUBIT, GM> TM;
   constexpr int EPT = TM::EPT, ICPB = TM::ICPB;
   const DevSys& S = A.S;
   TM tm;

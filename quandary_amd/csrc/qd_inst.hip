@@ -20,14 +20,15 @@ constexpr int kQubitDim = kLind ? (1 << (2 * QD_Q)) : (1 << QD_Q);
 
 template <int VAR>
 constexpr bool variant_built() {
-  // V6/V7 (two initial conditions interleaved per workgroup) are not built: measured on MI355X they
-  // raise per-wave throughput (C2: 1.12 ms vs 1.50 ms per 1000 steps and initial condition) but the
-  // batches of this problem class never exceed the number of SIMDs (ninit <= dim), so the whole sweep
-  // is as slow as its slowest wave and one initial condition per wave wins (38.6M vs 26.7M units/s).
-  if (!kQubit) return VAR <= 4 || (kLind && VAR >= 8 && VAR <= 10);  // V8/V9: column layout, Lindblad only
+  // Built = what pick_config() can select.  Measured on MI355X and therefore NOT built: V6/V7 (two initial
+  // conditions interleaved per workgroup: higher per-wave throughput, but the batches of this problem
+  // class never exceed the number of SIMDs, so one initial condition per wave wins, C2 38.6M vs 26.7M
+  // units/s); V3 and V5 (1024-thread blocks: 128 VGPRs are not enough, 8-12x slower than V2 on C5); V8 and
+  // V10 (column layout with 4 / 6 columns per wave: 4.0M vs 4.85M units/s of V9 on C4).
+  if (!kQubit) return VAR <= 2 || VAR == 4 || (kLind && VAR == 9);
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
-  return VAR == 2 || VAR == 5;
+  return VAR == 2;
 }
 
 template <typename K>
@@ -40,7 +41,7 @@ static hipError_t set_lds(K kern, size_t bytes) {
 template <int VAR>
 static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (variant_built<VAR>()) {
-    auto kf = k_forward<QD_Q, kLind, VAR, kQubit>;
+    auto kf = cfg.gmres ? k_forward<QD_Q, kLind, VAR, kQubit, true> : k_forward<QD_Q, kLind, VAR, kQubit, false>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3((a.nb + Variant<VAR>::ICPB - 1) / Variant<VAR>::ICPB), dim3(cfg.block), cfg.lds, st, a);
@@ -52,7 +53,7 @@ static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (variant_built<VAR>()) {
-    auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit>;
+    auto kf = cfg.gmres ? k_adjoint<QD_Q, kLind, VAR, kQubit, true> : k_adjoint<QD_Q, kLind, VAR, kQubit, false>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3((a.nb + Variant<VAR>::ICPB - 1) / Variant<VAR>::ICPB), dim3(cfg.block), cfg.lds, st, a);

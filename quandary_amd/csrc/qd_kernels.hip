@@ -233,21 +233,18 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
     if (colv[v]) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= maxb[v] && lds_bytes(S, colblock(v), true, false, 2, 1, true) <= 160 * 1024;
     return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v];
   };
+  auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
+    if (!qubit) return v <= 2 || v == 4 || (S.lindblad && v == 9);
+    return dim <= 64 ? v == 0 : dim <= 256 ? v == 1 : v == 2;
+  };
   int var;
   if (dim <= 64) var = 0;
   else if (dim <= 256) var = 1;
-  else if (dim <= 1024) var = (qubit && nb < 512) ? 5 : 2;
+  else if (dim <= 1024) var = 2;
   else var = fits(QD_COL_DEFAULT) ? QD_COL_DEFAULT : 4;
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
-    if (v >= 0 && v < NVARIANTS && v != 6 && v != 7 && fits(v)) var = v;
-  }
-  if (!fits(var)) var = dim <= 64 ? 0 : dim <= 256 ? 1 : dim <= 1024 ? 2 : 4;
-  if (qubit) {  // the qubit translation units only build the variants that match their fixed dimension
-    const bool okv = dim <= 64 ? var == 0 : dim <= 256 ? var == 1 : (var == 2 || var == 5);
-    if (!okv) var = dim <= 64 ? 0 : dim <= 256 ? 1 : 2;
-  } else if (var == 5) {
-    var = 2;
+    if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
   }
   const int epe = ept[var] / icpb[var];
   c.var = var;
