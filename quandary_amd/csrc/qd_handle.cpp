@@ -70,6 +70,9 @@ extern "C" void qd_destroy(qd_handle* h) {
   if (h->d_carriers) (void)hipFree(h->d_carriers);
   if (h->d_pulses) (void)hipFree(h->d_pulses);
   if (h->d_napply) (void)hipFree(h->d_napply);
+  h->h_etable.release();
+  h->h_res.release();
+  h->h_params.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -285,7 +288,11 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     qd_destroy(h);
     return rc;
   }
-  h->etable_host.assign(h->etimes.size() * h->cs, 0.0);
+  if (h->h_etable.ensure(h->etimes.size() * h->cs) != QD_OK || h->h_params.ensure((size_t)h->ndesign) != QD_OK) {
+    qd_destroy(h);
+    return QD_ERR_NOMEM;
+  }
+  std::memset(h->h_etable.p, 0, sizeof(double) * h->etimes.size() * h->cs);
   *out = h;
   return QD_OK;
 }
@@ -301,7 +308,8 @@ extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
   QD_HIP(hipSetDevice(h->device));
   if (ndesign > 0) {
     std::memcpy(h->params.data(), alpha, sizeof(double) * ndesign);
-    QD_HIP(hipMemcpyAsync(h->d_params.p, h->params.data(), sizeof(double) * ndesign, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(h->h_params.p, alpha, sizeof(double) * ndesign);
+    QD_HIP(hipMemcpyAsync(h->d_params.p, h->h_params.p, sizeof(double) * ndesign, hipMemcpyHostToDevice, h->stream));
   }
   h->params_dirty = true;
   h->traj_valid = false;
@@ -314,8 +322,8 @@ int qd_handle::refresh_tables() {
   if (!params_dirty) return QD_OK;
   QD_HIP(launch_controls(dctl, d_params.p, d_sched_t.p, d_sched_h.p, (int)sched_t.size(), d_table.p, cs, stream));
   QD_HIP(launch_controls(dctl, d_params.p, d_etimes.p, d_ezero.p, (int)etimes.size(), d_etable.p, cs, stream));
-  QD_HIP(hipMemcpyAsync(etable_host.data(), d_etable.p, sizeof(double) * etable_host.size(), hipMemcpyDeviceToHost, stream));
-  QD_HIP(hipStreamSynchronize(stream));
+  // asynchronous: complete at the stream synchronisation that ends the sweep (forward_dev)
+  QD_HIP(hipMemcpyAsync(h_etable.p, d_etable.p, sizeof(double) * etimes.size() * cs, hipMemcpyDeviceToHost, stream));
   params_dirty = false;
   return QD_OK;
 }
@@ -325,7 +333,7 @@ double qd_handle::energy_penalty_host() const {
   double e = 0.0;
   for (size_t n = 0; n < etimes.size(); n++) {
     double pen = 0.0;
-    const double* row = etable_host.data() + n * cs;
+    const double* row = h_etable.p + n * cs;
     for (int k = 0; k < S.Q; k++) pen += (row[2 + k] * row[2 + k] + row[2 + S.Q + k] * row[2 + S.Q + k]) / tg.ntime;
     e += pen;
   }
@@ -484,9 +492,15 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
   QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4.p, stream));
-  unsigned long long nap = 0;
-  QD_HIP(hipMemcpyAsync(&nap, d_napply, sizeof nap, hipMemcpyDeviceToHost, stream));
+  // every result of the sweep in one pinned buffer, one synchronisation
+  if ((r = h_res.ensure((size_t)6 * nb + 1))) return r;
+  QD_HIP(hipMemcpyAsync(h_res.p, d_pen.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
+  QD_HIP(hipMemcpyAsync(h_res.p + nb, d_dpdm.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
+  if (tgp) QD_HIP(hipMemcpyAsync(h_res.p + 2 * (size_t)nb, d_out4.p, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost, stream));
+  QD_HIP(hipMemcpyAsync(h_res.p + 6 * (size_t)nb, d_napply, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
   QD_HIP(hipStreamSynchronize(stream));
+  unsigned long long nap = 0;
+  std::memcpy(&nap, h_res.p + 6 * (size_t)nb, sizeof nap);
   float ms = 0.f;
   QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
   last_fwd_ms = ms;
@@ -509,12 +523,11 @@ extern "C" int qd_forward(qd_handle* h, const double* x0, int nb, int store_traj
   if ((r = h->forward_dev(h->d_x0.p, nb, store_trajectory != 0, h->target_set ? &h->dtg : nullptr, &energy))) return r;
   if (out) {
     if (out->final_states) QD_HIP(hipMemcpy(out->final_states, h->d_xT.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (out->penalty_integral) QD_HIP(hipMemcpy(out->penalty_integral, h->d_pen.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
-    if (out->penalty_dpdm) QD_HIP(hipMemcpy(out->penalty_dpdm, h->d_dpdm.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    if (out->penalty_integral) std::memcpy(out->penalty_integral, h->res_pen(), sizeof(double) * nb);
+    if (out->penalty_dpdm) std::memcpy(out->penalty_dpdm, h->res_dpdm(), sizeof(double) * nb);
     if (out->energy_penalty) *out->energy_penalty = energy;
     if (h->target_set && (out->J_re || out->J_im || out->fid_re || out->fid_im)) {
-      std::vector<double> o4((size_t)4 * nb);
-      QD_HIP(hipMemcpy(o4.data(), h->d_out4.p, sizeof(double) * o4.size(), hipMemcpyDeviceToHost));
+      const double* o4 = h->res_out4();
       for (int b = 0; b < nb; b++) {
         if (out->J_re) out->J_re[b] = o4[4 * b];
         if (out->J_im) out->J_im[b] = o4[4 * b + 1];

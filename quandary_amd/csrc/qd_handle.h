@@ -39,6 +39,27 @@ struct DBuf {
   }
 };
 
+// growable PINNED host buffer: the target of the asynchronous result downloads (one stream
+// synchronisation per sweep instead of one blocking copy per result array)
+struct HBuf {
+  double* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return QD_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    QD_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(double) * (n > 0 ? n : 1), hipHostMallocDefault));
+    cap = n;
+    return QD_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 }  // namespace qd
 
 struct qd_handle {
@@ -66,7 +87,9 @@ struct qd_handle {
   int nstages = 1, nsub = 0, cs = 0;
   std::vector<double> sched_t, sched_h, etimes;  // host copies
   qd::DBuf d_sched_t, d_sched_h, d_etimes, d_ezero, d_table, d_etable, d_onerow, d_onetime;
-  std::vector<double> etable_host;
+  qd::HBuf h_etable;  // energy-penalty table rows, downloaded with the sweep results
+  qd::HBuf h_res;     // per-state results of the last forward sweep: [pen nb | dpdm nb | out4 4nb | napply]
+  qd::HBuf h_params;  // staging copy of the control parameters
   // target for in-loop / final objective terms
   bool target_set = false;
   qd::DevTarget dtg{};
@@ -89,4 +112,7 @@ struct qd_handle {
   // gradient from d_coeffsum (+ energy term ebar); writes host grad[ndesign]
   int gradient_from_coeffs(double ebar, double* grad);
   double energy_penalty_host() const;
+  const double* res_pen() const { return h_res.p; }
+  const double* res_dpdm() const { return h_res.p + last_nb; }
+  const double* res_out4() const { return h_res.p + 2 * (size_t)last_nb; }
 };

@@ -511,10 +511,7 @@ extern "C" int qd_optim_forward_local(qd_optim* o, const double* alpha, int stor
   if ((r = h->forward_dev(o->d_x0.p, nl, store, &o->tg, &energy))) return r;
   o->stored = store;
   o->forward_done = true;
-  std::vector<double> pen(nl), dpdm(nl), o4((size_t)4 * nl);
-  QD_HIP(hipMemcpy(pen.data(), h->d_pen.p, sizeof(double) * nl, hipMemcpyDeviceToHost));
-  QD_HIP(hipMemcpy(dpdm.data(), h->d_dpdm.p, sizeof(double) * nl, hipMemcpyDeviceToHost));
-  QD_HIP(hipMemcpy(o4.data(), h->d_out4.p, sizeof(double) * o4.size(), hipMemcpyDeviceToHost));
+  const double *pen = h->res_pen(), *dpdm = h->res_dpdm(), *o4 = h->res_out4();  // pinned, downloaded with the sweep
   for (int i = 0; i < QD_NSUMS; i++) partial[i] = 0.0;
   for (int i = 0; i < nl; i++) {  // src/optimproblem.cpp:258-279
     const double w = o->weights[o->first + i];
