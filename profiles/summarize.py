@@ -11,7 +11,9 @@ import sys
 
 
 def find(d, suffix):
-    return sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    """newest matching file only: gpurun merges every call's output into the same directory"""
+    fs = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
 
 
 def main():
