@@ -146,6 +146,37 @@ def test_other_steppers(stepper):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("stepper", ["IMR4", "EE"])
+def test_other_steppers_column_layout(stepper, monkeypatch):
+    """compositional / explicit steppers through the column-per-wave kernel (staging paths differ from IMR)"""
+    monkeypatch.setenv("QD_VAR", "9")
+    sp, h, orc = _pair(dict(nlevels=[3, 4], lindblad=True, jkl=0.01, detuned=True, target="pure", objective="Jfrobenius"),
+                       ntime=10, stepper=stepper, penalties=True)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
+def test_large_schroedinger_state(linsolve):
+    """Schroedinger with 1024 < dim <= 4096 (6^4 = 1296): the 8-elements-per-thread linear-map kernel (V4) with
+    explicit staging, Neumann and GMRES with the Krylov basis in global memory."""
+    sp, h, orc = _pair(dict(nlevels=[6, 6, 6, 6], lindblad=False, nessential=[2, 2, 2, 2], jkl=0.002, detuned=True,
+                            init="pure, 1, 0, 1, 0", target="pure", objective="Jmeasure"), ntime=8, nspline=6, linsolve=linsolve, penalties=True)
+    assert h.dim == 1296
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
 def test_forward_states_and_trajectory():
     sp, h, orc = _pair(dict(nlevels=[2, 2, 2], lindblad=True), ntime=30)
     opt = capi.Optim(h, sp)
