@@ -651,21 +651,25 @@ struct QubitStencil {
     for (int k = 0; k < Q; k++) {
       const unsigned a = (i0 >> (Q - 1 - k)) & 1;
       const double sqb = HOIST ? qb[k] : flip_if(c.q[k], a);
-      double br = xb[k].x, bi = xb[k].y;
-      double tr = sqb * xb[k].x, ti = sqb * xb[k].y;
-      if (LIND) {
+      if (!LIND) {
+        // Schroedinger: FMAs only, accumulated into two pairs (even / odd oscillators)
+        double& ar = (k & 1) ? gr : hr;
+        double& ai = (k & 1) ? gi : hi;
+        ar = fma(sqb, xb[k].x, ar);
+        ai = fma(sqb, xb[k].y, ai);
+        ar = fma(c.p[k], xb[k].y, ar);
+        ai = fma(-c.p[k], xb[k].x, ai);
+      } else {
+        // Lindblad (latency-bound single-wave kernels): independent product trees per oscillator, summed at
+        // the end - the FMA-only chain is two instructions shorter but serial, measured 6 % slower on C2
         const unsigned ap = (i0 >> (2 * Q - 1 - k)) & 1;
         const double sqk = HOIST ? qk[k] : flip_if(c.q[k], ap);
-        tr = fma(sqk, xk[k].x, tr);
-        ti = fma(sqk, xk[k].y, ti);
-        br -= xk[k].x;
-        bi -= xk[k].y;
+        double tr = fma(sqk, xk[k].x, sqb * xb[k].x), ti = fma(sqk, xk[k].y, sqb * xb[k].y);
+        tr = fma(c.p[k], xb[k].y - xk[k].y, tr);
+        ti = fma(-c.p[k], xb[k].x - xk[k].x, ti);
+        if (k & 1) { gr += tr; gi += ti; }
+        else { hr += tr; hi += ti; }
       }
-      tr = fma(c.p[k], bi, tr);
-      ti = fma(-c.p[k], br, ti);
-      if (k == 1) { gr = tr; gi = ti; }
-      else if (k & 1) { gr += tr; gi += ti; }
-      else { hr += tr; hi += ti; }
     }
     if (Q > 1) {
       hr += gr;
@@ -1029,11 +1033,18 @@ struct QubitSlotStencil {
         xk = at(sx, ak[k], j);
         sqk = qk[k];
       }
-      double tr = fma(sqk, xk.x, qb[k] * xb.x), ti = fma(sqk, xk.y, qb[k] * xb.y);
-      tr = fma(c.p[k], xb.y - xk.y, tr);
-      ti = fma(-c.p[k], xb.x - xk.x, ti);
-      if (k & 1) { gr += tr; gi += ti; }
-      else { hr += tr; hi += ti; }
+      // q (s_b x_b + s_k x_k) + p (x_b.y - x_k.y) etc., accumulated by FMAs only; two accumulator pairs
+      // (even / odd oscillators) keep four independent dependency chains
+      double& ar = (k & 1) ? gr : hr;
+      double& ai = (k & 1) ? gi : hi;
+      ar = fma(qb[k], xb.x, ar);
+      ai = fma(qb[k], xb.y, ai);
+      ar = fma(sqk, xk.x, ar);
+      ai = fma(sqk, xk.y, ai);
+      ar = fma(c.p[k], xb.y, ar);
+      ai = fma(-c.p[k], xb.x, ai);
+      ar = fma(-c.p[k], xk.y, ar);
+      ai = fma(c.p[k], xk.x, ai);
       // T1 off-diagonal: forward needs both digits 0 (neighbour has both set), transposed both 1
       const bool slot_ok = k >= 2 || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
       if (slot_ok) {
