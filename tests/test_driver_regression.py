@@ -74,11 +74,13 @@ def test_driver_cli_without_gpu():
     ("AxC_initEnsemble", ["rho*.dat", "optim_history.dat"]),
     ("AxC_initFile", ["rho*.dat", "optim_history.dat"]),
     ("pipulse", ["optim_history.dat", "rho*.dat", "population*.dat", "expected*.dat"]),
+    ("nlevels_4_4_4_4", ["population*.dat", "expected*.dat"]),  # 4x4x4x4 Schroedinger with Jkl, composite observables
 ])
 def test_simulation_cases(case, patterns, tmp_path):
     out = _run(case, str(tmp_path))
     _compare(case, out, [p for p in patterns if p != "optim_history.dat"], atol=5e-10)
-    _compare(case, out, ["optim_history.dat"], atol=1e-12)
+    if "optim_history.dat" in patterns:
+        _compare(case, out, ["optim_history.dat"], atol=1e-12)
     for f in ("params.dat", "control0.dat", "timing.dat"):
         assert os.path.exists(os.path.join(out, f))
 

@@ -100,6 +100,32 @@ def test_optimization_iteration0(case):
     orc.close()
 
 
+def test_nlevels_4_4_4_4_observables():
+    """Four 4-level oscillators with dipole-dipole coupling (dim 256 Schroedinger, the reference runs it
+    with its sparse-matrix solver + GMRES): per-oscillator and composite expected energies / populations."""
+    case = "nlevels_4_4_4_4"
+    sp = load_case(case)
+    assert sp.runtype == "simulation" and sp.dim == 256
+    orc = Oracle(sp)
+    _, traj, _ = orc.evalF(sp.params0, out_freq=sp.output_frequency)
+    dim = sp.dim
+    for k in range(4):
+        rows, _, d = golden_rows(case, f"expected{k}.iinit0000.dat")
+        mine = np.array([orc.expected_energy(k, traj[0][r]) for r in rows])
+        np.testing.assert_allclose(mine, d[:, 0], rtol=REF_RTOL, atol=1e-12)
+        rows, _, d = golden_rows(case, f"population{k}.iinit0000.dat")
+        mine = np.array([orc.population(k, traj[0][r]) for r in rows])
+        np.testing.assert_allclose(mine, d, rtol=REF_RTOL, atol=1e-12)
+    # composite system (MasterEq::population / expectedEnergy, src/mastereq.cpp:2897-2974): |psi_i|^2 and sum_i i |psi_i|^2
+    rows, _, d = golden_rows(case, "population_composite.iinit0000.dat")
+    pop = np.array([traj[0][r][:dim] ** 2 + traj[0][r][dim:] ** 2 for r in rows])
+    np.testing.assert_allclose(pop, d, rtol=REF_RTOL, atol=1e-12)
+    rows, _, d = golden_rows(case, "expected_composite.iinit0000.dat")
+    pop = np.array([traj[0][r][:dim] ** 2 + traj[0][r][dim:] ** 2 for r in rows])
+    np.testing.assert_allclose(pop @ np.arange(dim), d[:, 0], rtol=REF_RTOL, atol=1e-12)
+    orc.close()
+
+
 def test_axc_schroedinger_trajectory():
     case = "AxC_grad_schroedinger"
     sp = load_case(case)
