@@ -61,20 +61,28 @@ def _atoi(s):
         return 0
 
 
+def _split(s):
+    """std::getline(stream, token, ',') semantics (src/config.cpp:217-233): no token after a trailing comma"""
+    parts = s.split(",")
+    if parts and parts[-1] == "":
+        parts.pop()
+    return parts
+
+
 def _vec_str(cfg, key, default):
-    return [t for t in cfg.get(key, default).split(",")]
+    return _split(cfg.get(key, default))
 
 
 def _vec_double(cfg, key, default):
     if key not in cfg:
         return [default]
-    return [_atof(t) for t in cfg[key].split(",")]
+    return [_atof(t) for t in _split(cfg[key])]
 
 
 def _vec_int(cfg, key, default):
     if key not in cfg:
         return [default]
-    return [_atoi(t) for t in cfg[key].split(",")]
+    return [_atoi(t) for t in _split(cfg[key])]
 
 
 def _copy_last(v, n):
@@ -138,7 +146,9 @@ class MT19937:
 # --------------------------------------------------------------------------- #
 def gate_matrix(name, dim_ess, nosc, cfg_dir=".", filename=None):
     V = np.zeros((dim_ess, dim_ess), dtype=complex)
-    if name == "xgate":
+    if name == "none":  # dummy gate: applyGate leaves the (zero) target untouched (src/gate.cpp:3-7, :262)
+        pass
+    elif name == "xgate":
         V[0, 1] = V[1, 0] = 1.0
     elif name == "ygate":
         V[0, 1], V[1, 0] = -1j, 1j

@@ -314,13 +314,16 @@ __device__ __forceinline__ int at_use(int v) {
   return EPE > 1 ? opaque(v) : v;
 }
 
+// the digits of one index are packed into 32 bits: up to 256 / 64 / 32 / 16 levels for <= 4 / 5 / 6 / 7-8 oscillators
+constexpr int packed_digit_bits(int q) { return q <= 4 ? 8 : q == 5 ? 6 : q == 6 ? 5 : 4; }
+
 // ---------------------------------------------------------------------------------------------
 // general stencil (runtime level counts)
 // ---------------------------------------------------------------------------------------------
 template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct GenStencil {
   static constexpr bool NEEDS_SLOTS = false;  // apply() reads every neighbour from LDS
-  static constexpr int DB = (Q <= 4) ? 8 : 6;  // bits per packed digit (levels <= 255, or <= 63 for Q = 5)
+  static constexpr int DB = packed_digit_bits(Q);  // bits per packed digit
   int it[EPT];         // storage index (clamped to dim-1 for slots beyond the vector)
   bool valid[EPT];
   unsigned dbra[EPT];  // bra digits i_k
@@ -737,7 +740,7 @@ struct QubitStencil {
 template <int Q, int EPT>
 struct ColStencil {
   static constexpr bool NEEDS_SLOTS = true;  // apply() takes the thread's other elements of the vector being read
-  static constexpr int DB = (Q <= 4) ? 8 : 6;
+  static constexpr int DB = packed_digit_bits(Q);
   int it[EPT];
   bool valid[EPT];
   double dw[EPT], dd[EPT];

@@ -122,13 +122,16 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     delete h;
     return fail(QD_ERR_UNSUPPORTED, "qd_create: state dimension > 4096 needs the tiled large-system kernels (not built yet)");
   }
-  if (S.Q == 5 && S.maxn > 63) {
-    delete h;
-    return fail(QD_ERR_UNSUPPORTED, "qd_create: five oscillators are limited to 63 levels each (packed digits)");
+  {  // packed digits (qd_device.h: packed_digit_bits)
+    const int maxlev = S.Q <= 4 ? 256 : S.Q == 5 ? 64 : S.Q == 6 ? 32 : 16;
+    if (S.maxn > maxlev) {
+      delete h;
+      return fail(QD_ERR_UNSUPPORTED, "qd_create: too many levels per oscillator for this number of oscillators (packed digits: 256/64/32/16 levels for <=4/5/6/7-8 oscillators)");
+    }
   }
-  if (S.Q > 5) {
+  if (S.Q > 5 && S.lindblad) {
     delete h;
-    return fail(QD_ERR_UNSUPPORTED, "qd_create: the stencil kernels are instantiated for 1..5 oscillators (as the reference's matrix-free path)");
+    return fail(QD_ERR_UNSUPPORTED, "qd_create: Lindblad kernels are instantiated for 1..5 oscillators (as the reference's matrix-free path); Schroedinger for 1..8");
   }
   S.N = (int)N;
   S.dim = (int)dim;

@@ -5,7 +5,7 @@
 #include "qd_device.h"
 
 #if !defined(QD_Q) || !defined(QD_L) || !defined(QD_B)
-#error "compile with -DQD_Q=<1..5> -DQD_L=<0|1> -DQD_B=<0|1>"
+#error "compile with -DQD_Q=<1..8> -DQD_L=<0|1> -DQD_B=<0|1>"
 #endif
 
 namespace qd {

@@ -275,29 +275,32 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
   hipError_t inst_apply_##q##_##l##_##b(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
 #define QD_DECL_Q(l, b) QD_DECL(1, l, b) QD_DECL(2, l, b) QD_DECL(3, l, b) QD_DECL(4, l, b) QD_DECL(5, l, b)
 QD_DECL_Q(0, 0) QD_DECL_Q(1, 0) QD_DECL_Q(0, 1) QD_DECL_Q(1, 1)
+// Schroedinger only: 6..8 oscillators (beyond the reference's matrix-free templates, which stop at 5)
+QD_DECL(6, 0, 0) QD_DECL(7, 0, 0) QD_DECL(8, 0, 0) QD_DECL(6, 0, 1) QD_DECL(7, 0, 1) QD_DECL(8, 0, 1)
 
 typedef hipError_t (*sweep_fn)(const SweepArgs&, const LaunchCfg&, hipStream_t);
 typedef hipError_t (*apply_fn)(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
-#define QD_ROW(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b}
+#define QD_ROW(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b, nullptr, nullptr, nullptr}
+#define QD_ROW8(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b, base##6_##l##_##b, base##7_##l##_##b, base##8_##l##_##b}
 // index [qubit][lindblad][Q-1]
-static const sweep_fn fwd_tab[2][2][5] = {{QD_ROW(inst_forward_, 0, 0), QD_ROW(inst_forward_, 1, 0)},
-                                          {QD_ROW(inst_forward_, 0, 1), QD_ROW(inst_forward_, 1, 1)}};
-static const sweep_fn adj_tab[2][2][5] = {{QD_ROW(inst_adjoint_, 0, 0), QD_ROW(inst_adjoint_, 1, 0)},
-                                          {QD_ROW(inst_adjoint_, 0, 1), QD_ROW(inst_adjoint_, 1, 1)}};
-static const apply_fn app_tab[2][2][5] = {{QD_ROW(inst_apply_, 0, 0), QD_ROW(inst_apply_, 1, 0)},
-                                          {QD_ROW(inst_apply_, 0, 1), QD_ROW(inst_apply_, 1, 1)}};
+static const sweep_fn fwd_tab[2][2][8] = {{QD_ROW8(inst_forward_, 0, 0), QD_ROW(inst_forward_, 1, 0)},
+                                          {QD_ROW8(inst_forward_, 0, 1), QD_ROW(inst_forward_, 1, 1)}};
+static const sweep_fn adj_tab[2][2][8] = {{QD_ROW8(inst_adjoint_, 0, 0), QD_ROW(inst_adjoint_, 1, 0)},
+                                          {QD_ROW8(inst_adjoint_, 0, 1), QD_ROW(inst_adjoint_, 1, 1)}};
+static const apply_fn app_tab[2][2][8] = {{QD_ROW8(inst_apply_, 0, 0), QD_ROW(inst_apply_, 1, 0)},
+                                          {QD_ROW8(inst_apply_, 0, 1), QD_ROW(inst_apply_, 1, 1)}};
 
 hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (a.S.Q < 1 || a.S.Q > 5) return hipErrorInvalidValue;
+  if (a.S.Q < 1 || a.S.Q > 8 || !fwd_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;
   return fwd_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
 }
 hipError_t launch_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (a.S.Q < 1 || a.S.Q > 5) return hipErrorInvalidValue;
+  if (a.S.Q < 1 || a.S.Q > 8 || !adj_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;
   return adj_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
 }
 hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                         const LaunchCfg& cfg, hipStream_t st) {
-  if (S.Q < 1 || S.Q > 5) return hipErrorInvalidValue;
+  if (S.Q < 1 || S.Q > 8 || !app_tab[cfg.qubit ? 1 : 0][S.lindblad ? 1 : 0][S.Q - 1]) return hipErrorInvalidValue;
   return app_tab[cfg.qubit ? 1 : 0][S.lindblad ? 1 : 0][S.Q - 1](S, ctlrow, transpose, x, y, nb, cfg, st);
 }
 

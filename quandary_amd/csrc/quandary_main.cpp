@@ -103,7 +103,8 @@ static void gate_matrix(const strvec& tgt, int de, int Q, const std::string& dir
   auto I = [&](int r, int c) -> double& { return im[(size_t)r * de + c]; };
   const std::string& g = tgt[1];
   auto need = [&](int d) { if (de != d) die("gate '" + g + "' needs an essential dimension of " + std::to_string(d)); };
-  if (g == "xgate") { need(2); R(0, 1) = R(1, 0) = 1.0; }
+  if (g == "none") {  // dummy gate (src/gate.cpp:3-7): applyGate leaves the zero target untouched
+  } else if (g == "xgate") { need(2); R(0, 1) = R(1, 0) = 1.0; }
   else if (g == "ygate") { need(2); I(0, 1) = -1.0; I(1, 0) = 1.0; }
   else if (g == "zgate") { need(2); I(0, 0) = 1.0; I(1, 1) = -1.0; }  // as the reference fills it (src/gate.cpp:331-332)
   else if (g == "hadamard") { need(2); const double v = 1. / sqrt(2.); R(0, 0) = R(0, 1) = R(1, 0) = v; R(1, 1) = -v; }

@@ -75,6 +75,7 @@ def test_driver_cli_without_gpu():
     ("AxC_initFile", ["rho*.dat", "optim_history.dat"]),
     ("pipulse", ["optim_history.dat", "rho*.dat", "population*.dat", "expected*.dat"]),
     ("nlevels_4_4_4_4", ["population*.dat", "expected*.dat"]),  # 4x4x4x4 Schroedinger with Jkl, composite observables
+    ("spinchain_N8", ["population*.dat"]),  # eight coupled qubits: more oscillators than the reference's matrix-free path
 ])
 def test_simulation_cases(case, patterns, tmp_path):
     out = _run(case, str(tmp_path))

@@ -126,6 +126,21 @@ def test_nlevels_4_4_4_4_observables():
     orc.close()
 
 
+def test_spinchain_N8_populations():
+    """Eight coupled qubits (dim 256 Schroedinger, nearest-neighbour Jkl): beyond the five oscillators of the
+    reference's matrix-free templates (it runs this case with its sparse-matrix solver)."""
+    case = "spinchain_N8"
+    sp = load_case(case)
+    assert sp.runtype == "simulation" and sp.dim == 256
+    orc = Oracle(sp)
+    _, traj, _ = orc.evalF(sp.params0, out_freq=sp.output_frequency)
+    for k in range(8):
+        rows, _, d = golden_rows(case, f"population{k}.iinit0000.dat")
+        mine = np.array([orc.population(k, traj[0][r]) for r in rows])
+        np.testing.assert_allclose(mine, d, rtol=REF_RTOL, atol=1e-12)
+    orc.close()
+
+
 def test_axc_schroedinger_trajectory():
     case = "AxC_grad_schroedinger"
     sp = load_case(case)
