@@ -47,6 +47,8 @@ def _cpu_worker(args):
     from quandary_amd import config
 
     sp = config.build_spec(cfg)
+    from quandary_amd.workloads import attach_synthetic_hamiltonian
+    attach_synthetic_hamiltonian(sp)
     orc = Oracle(sp)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -103,6 +105,13 @@ def flops_per_apply(spec):
     Q = sy.nosc
     lind = sy.lindblad_type != 0
     n = [sy.nlevels[k] for k in range(Q)]
+    if getattr(spec, "hamiltonian", None) is not None:
+        # dense operator: one (Schroedinger) or two (Lindblad) complex dot products of length N per element + dissipators
+        N = int(np.prod(n))
+        per = (16.0 if lind else 8.0) * N
+        if lind:
+            per += 4.0 + sum(4.0 * ((n[k] - 1.0) / n[k]) ** 2 for k in range(Q) if sy.lindblad_type in (1, 3) and sy.decay_time[k] > 0)
+        return per * spec.dim
     per = 6.0
     for k in range(Q):
         frac = (n[k] - 1.0) / n[k]
@@ -123,7 +132,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "q4", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "q4", "c4", "c5", "d4"])
     ap.add_argument("--mode", default="fwd", choices=["fwd", "grad"])
     ap.add_argument("--linsolve", default=None, choices=[None, "neumann", "gmres"])
     ap.add_argument("--ntime", type=int, default=None, help="override the number of time steps of the workload")

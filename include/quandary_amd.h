@@ -177,6 +177,16 @@ int qd_dim_rho(const qd_handle* h);    /* N                                    *
 int qd_dim_ess(const qd_handle* h);    /* prod nessential                      */
 int qd_ndesign(const qd_handle* h);    /* number of control parameters         */
 
+/* User-supplied Hamiltonians, the reference's `hamiltonian_file_Hsys` / `hamiltonian_file_Hc` model
+ * (src/hamiltonianfilereader.cpp, applied by applyRHS_sparsemat src/mastereq.cpp:743-967): dense complex
+ * N x N matrices (N = qd_dim_rho), row-major, in rad/ns.  hc_re / hc_im hold nosc matrices back to back
+ * (NULL = no control Hamiltonians, the reference's "none").  They REPLACE the standard Hamiltonian model of
+ * the qd_system description - detuning, Kerr terms, dipole coupling, ladder-operator controls:
+ *     H(t) = Hsys + sum_k p_k(t) Re(Hc_k) + i q_k(t) Im(Hc_k),
+ * the T1/T2 dissipators of qd_system stay.  Supported for state dimensions up to 1024.  Call before the
+ * first sweep. */
+int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const double* hsys_im, const double* hc_re, const double* hc_im);
+
 int qd_set_params(qd_handle* h, const double* alpha, int ndesign);
 /* p_k(t), q_k(t) for every oscillator at nt times; pq is [nt][nosc][2] */
 int qd_eval_controls(qd_handle* h, const double* times, int nt, double* pq);

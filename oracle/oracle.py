@@ -37,6 +37,7 @@ def load():
     lib.qo_destroy.restype = None
     for f in ("qo_dim", "qo_dim_rho", "qo_dim_ess", "qo_ndesign"):
         getattr(lib, f).argtypes = [vp]
+    lib.qo_set_hamiltonian.argtypes = [vp, capi.c_dp, capi.c_dp, capi.c_dp, capi.c_dp]
     lib.qo_set_params.argtypes = [vp, capi.c_dp, C.c_int]
     lib.qo_eval_controls.argtypes = [vp, capi.c_dp, C.c_int, capi.c_dp]
     lib.qo_apply_rhs.argtypes = [vp, C.c_double, C.c_int, capi.c_dp, capi.c_dp, C.c_int]
@@ -87,6 +88,21 @@ class Oracle:
         self.dim_ess = self.lib.qo_dim_ess(self._c)
         self.ndesign = self.lib.qo_ndesign(self._c)
         self._o = C.c_void_p()
+        ham = getattr(spec, "hamiltonian", None)
+        if ham is not None:
+            self.set_hamiltonian(*ham)
+
+    def set_hamiltonian(self, hsys, hc=None):
+        n = self.dim_rho
+        hsys = np.asarray(hsys, dtype=complex).reshape(n, n)
+        sr, si = np.ascontiguousarray(hsys.real), np.ascontiguousarray(hsys.imag)
+        if hc is not None:
+            hc = np.asarray(hc, dtype=complex).reshape(self.spec.system.nosc, n, n)
+            cr, ci = np.ascontiguousarray(hc.real), np.ascontiguousarray(hc.imag)
+            rc = self.lib.qo_set_hamiltonian(self._c, capi.dptr(sr), capi.dptr(si), capi.dptr(cr), capi.dptr(ci))
+        else:
+            rc = self.lib.qo_set_hamiltonian(self._c, capi.dptr(sr), capi.dptr(si), None, None)
+        _check(self.lib, rc, "qo_set_hamiltonian")
 
     def close(self):
         if self._o:

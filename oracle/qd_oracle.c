@@ -76,6 +76,12 @@ typedef struct qo_ctx {
   long n_apply, n_steps;
   /* control evaluated by assemble_RHS */
   double p[QO_MAXQ], q[QO_MAXQ], cosj[QD_MAX_PAIRS], sinj[QD_MAX_PAIRS];
+  /* user-supplied dense Hamiltonians (hamiltonian_file_Hsys / _Hc; src/hamiltonianfilereader.cpp,
+   * applyRHS_sparsemat src/mastereq.cpp:743-967): N x N row-major, replace the standard Hamiltonian model */
+  int dense;
+  double *hs_re, *hs_im; /* Hsys */
+  double *hc_re, *hc_im; /* [Q][N*N] */
+  double *g_re, *g_im;   /* scratch: G(t) = -i H(t) */
 } qo_ctx;
 
 static char qo_err[512];
@@ -315,6 +321,55 @@ static int assemble_rhs(qo_ctx* c, double t) {
   return 0;
 }
 
+/* User-Hamiltonian model.  Reference (applyRHS_sparsemat, src/mastereq.cpp:760-795): uout = Re u - Im v,
+ * vout = Im u + Re v with Re = Ad + sum_k q_k Ac_k, Im = Bd + sum_k p_k Bc_k and, from the file reader
+ * (src/hamiltonianfilereader.cpp:77-84, :170-176), Ad = Im(Hsys), Bd = -Re(Hsys), Ac = Im(Hc), Bc = -Re(Hc),
+ * lifted to I (x) X - X^T (x) I for Lindblad.  In Hilbert space that is y = G psi (Schroedinger) or
+ * y = G rho - rho G (Lindblad) with G = -i H(t); the transposed real operator (:836-880) is the same with G^H.
+ * y += ... (the dissipators were accumulated by the caller). */
+static void dense_build_G(qo_ctx* c) {
+  const int N = c->s.N, Q = c->s.Q, nn = N * N;
+  for (int e = 0; e < nn; e++) {
+    double re = c->hs_im[e], im = -c->hs_re[e];
+    for (int k = 0; k < Q; k++) {
+      re += c->q[k] * c->hc_im[(size_t)k * nn + e];
+      im -= c->p[k] * c->hc_re[(size_t)k * nn + e];
+    }
+    c->g_re[e] = re;
+    c->g_im[e] = im;
+  }
+}
+
+/* y(I,I') += sum_m Gt(I,m) x(m,I') - x(I,m) Gt(m,I'),  Gt = G (gre, gim) or its conjugate transpose */
+static void dense_comm(const osys* s, const double* gre, const double* gim, int herm, const double* x, double* y) {
+  const int N = s->N, dim = s->dim, ncol = s->lindblad ? N : 1;
+  for (int Ip = 0; Ip < ncol; Ip++)
+    for (int I = 0; I < N; I++) {
+      double ar = 0.0, ai = 0.0;
+      for (int m = 0; m < N; m++) {
+        double gr = herm ? gre[m * N + I] : gre[I * N + m], gi = herm ? -gim[m * N + I] : gim[I * N + m];
+        const int e = s->lindblad ? Ip * N + m : m;
+        ar += gr * x[e] - gi * x[e + dim];
+        ai += gr * x[e + dim] + gi * x[e];
+        if (s->lindblad) {
+          gr = herm ? gre[Ip * N + m] : gre[m * N + Ip];
+          gi = herm ? -gim[Ip * N + m] : gim[m * N + Ip];
+          const int f = m * N + I;
+          ar -= x[f] * gr - x[f + dim] * gi;
+          ai -= x[f] * gi + x[f + dim] * gr;
+        }
+      }
+      const int it = s->lindblad ? Ip * N + I : I;
+      y[it] += ar;
+      y[it + dim] += ai;
+    }
+}
+
+static void dense_commutator(qo_ctx* c, int transpose, const double* x, double* y) {
+  dense_build_G(c);
+  dense_comm(&c->s, c->g_re, c->g_im, transpose, x, y);
+}
+
 /* y = M x or M^T x with the controls/cos/sin currently held in the context */
 static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
   const osys* s = &c->s;
@@ -330,20 +385,23 @@ static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
     stp[k] = N * s->post[k];
   }
   c->n_apply++;
+  const int dense = c->dense; /* user Hamiltonians: only the dissipators come from the standard model */
   for (int it = 0; it < dim; it++) {
     const double xre = x[it], xim = x[it + dim];
     /* diagonal: mastereq.hpp:316-433, mastereq.cpp:1526-1551 / :1650-1675 */
     double hd = 0.0, hdp = 0.0, dd = 0.0;
     int pair = 0;
-    for (int k = 0; k < Q; k++) {
+    for (int k = 0; k < Q && !dense; k++) {
       hd += s->detune[k] * i[k] - s->xi[k] / 2.0 * i[k] * (i[k] - 1);
       for (int l = k + 1; l < Q; l++) hd -= s->xikl[pair++] * i[k] * i[l];
     }
     if (s->lindblad) {
       pair = 0;
       for (int k = 0; k < Q; k++) {
-        hdp += s->detune[k] * ip[k] - s->xi[k] / 2.0 * ip[k] * (ip[k] - 1);
-        for (int l = k + 1; l < Q; l++) hdp -= s->xikl[pair++] * ip[k] * ip[l];
+        if (!dense) {
+          hdp += s->detune[k] * ip[k] - s->xi[k] / 2.0 * ip[k] * (ip[k] - 1);
+          for (int l = k + 1; l < Q; l++) hdp -= s->xikl[pair++] * ip[k] * ip[l];
+        }
         dd += s->g2[k] * (i[k] * ip[k] - 0.5 * (i[k] * i[k] + ip[k] * ip[k])) - s->g1[k] / 2.0 * (i[k] + ip[k]);
       }
     }
@@ -361,7 +419,7 @@ static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
     }
     /* dipole-dipole coupling: mastereq.hpp:632-741 */
     pair = 0;
-    for (int k = 0; k < Q; k++)
+    for (int k = 0; k < Q && !dense; k++)
       for (int l = k + 1; l < Q; l++, pair++) {
         const double Jij = s->J[pair];
         if (!(fabs(Jij) > 1e-10)) continue;
@@ -436,7 +494,7 @@ static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
       }
     }
     /* control: mastereq.hpp:818-912 */
-    for (int k = 0; k < Q; k++) {
+    for (int k = 0; k < Q && !dense; k++) {
       const double pt = c->p[k], qt = c->q[k];
       const int n = s->n[k], npk = np[k], a = i[k], ap = ip[k], st = s->post[k], stq = stp[k];
       if (!transpose) {
@@ -501,6 +559,7 @@ static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
       }
     }
   }
+  if (dense) dense_commutator(c, transpose, x, y);
 }
 
 /* compute_dRHS_dParams_matfree, src/mastereq.cpp:970-1276 + dRHSdp_getcoeffs (mastereq.hpp:553-604).
@@ -508,6 +567,24 @@ static void apply_rhs(qo_ctx* c, int transpose, const double* x, double* y) {
 static void drhs_dparams(qo_ctx* c, double t, const double* x, const double* xbar, double alpha, double* grad) {
   const osys* s = &c->s;
   const int Q = s->Q, N = s->N, dim = s->dim;
+  if (c->dense) { /* compute_dRHS_dParams_sparsemat, src/mastereq.cpp:925-968: qbar = xbar.(Ac x), pbar = vbar.(Bc u) - ubar.(Bc v) */
+    const int nn = N * N;
+    double* w = (double*)calloc((size_t)2 * dim, sizeof(double));
+    double* zero = (double*)calloc((size_t)nn, sizeof(double));
+    for (int k = 0; k < Q; k++) {
+      memset(w, 0, sizeof(double) * 2 * dim);
+      dense_comm(s, c->hc_im + (size_t)k * nn, zero, 0, x, w); /* A = [Im(Hc_k), x] */
+      double qbar = 0.0, pbar = 0.0;
+      for (int e = 0; e < dim; e++) qbar += w[e] * xbar[e] + w[e + dim] * xbar[e + dim];
+      memset(w, 0, sizeof(double) * 2 * dim);
+      dense_comm(s, c->hc_re + (size_t)k * nn, zero, 0, x, w); /* B = [Re(Hc_k), x];  dM/dp x = -i B */
+      for (int e = 0; e < dim; e++) pbar += w[e + dim] * xbar[e] - w[e] * xbar[e + dim];
+      eval_control_diff(c, k, t, grad + c->osc[k].offset, alpha * pbar, alpha * qbar);
+    }
+    free(w);
+    free(zero);
+    return;
+  }
   const double* sq = s->sq;
   double cp[QO_MAXQ], cq[QO_MAXQ];
   int i[QO_MAXQ], ip[QO_MAXQ], np[QO_MAXQ];
@@ -1509,7 +1586,29 @@ void qo_destroy(qo_ctx* c) {
   free(c->params);
   free(c->rhs); free(c->stage); free(c->stage_adj); free(c->tmp); free(c->err); free(c->aux);
   free(c->gm_V); free(c->gm_H); free(c->gm_cs); free(c->gm_sn); free(c->gm_g); free(c->gm_y);
+  free(c->hs_re); free(c->hs_im); free(c->hc_re); free(c->hc_im); free(c->g_re); free(c->g_im);
   free(c);
+}
+
+/* hamiltonian_file_Hsys / hamiltonian_file_Hc: dense N x N row-major matrices (hc_*: Q of them, or NULL) */
+int qo_set_hamiltonian(qo_ctx* c, const double* hsys_re, const double* hsys_im, const double* hc_re, const double* hc_im) {
+  if (!c || !hsys_re || !hsys_im) return fail("qo_set_hamiltonian: null argument");
+  const size_t nn = (size_t)c->s.N * c->s.N, Q = (size_t)c->s.Q;
+  free(c->hs_re); free(c->hs_im); free(c->hc_re); free(c->hc_im); free(c->g_re); free(c->g_im);
+  c->hs_re = (double*)malloc(sizeof(double) * nn);
+  c->hs_im = (double*)malloc(sizeof(double) * nn);
+  c->hc_re = (double*)calloc(Q * nn, sizeof(double));
+  c->hc_im = (double*)calloc(Q * nn, sizeof(double));
+  c->g_re = (double*)malloc(sizeof(double) * nn);
+  c->g_im = (double*)malloc(sizeof(double) * nn);
+  memcpy(c->hs_re, hsys_re, sizeof(double) * nn);
+  memcpy(c->hs_im, hsys_im, sizeof(double) * nn);
+  if (hc_re && hc_im) {
+    memcpy(c->hc_re, hc_re, sizeof(double) * Q * nn);
+    memcpy(c->hc_im, hc_im, sizeof(double) * Q * nn);
+  }
+  c->dense = 1;
+  return 0;
 }
 
 int qo_create(const qd_system* sys, const qd_controls* ctl, const qd_time* tg, const qd_solver* sol, qo_ctx** out) {
@@ -1626,6 +1725,25 @@ int qo_drhs_coeffs(qo_ctx* c, const double* z, const double* xbar, double* coeff
   /* reuse drhs_dparams through a unit "gradient": evaluate the coefficients directly */
   const osys* s = &c->s;
   const int Q = s->Q, N = s->N, dim = s->dim;
+  if (c->dense) {
+    const int nn = N * N;
+    double* w = (double*)calloc((size_t)2 * dim, sizeof(double));
+    double* zero = (double*)calloc((size_t)nn, sizeof(double));
+    for (int k = 0; k < Q; k++) {
+      double qbar = 0.0, pbar = 0.0;
+      memset(w, 0, sizeof(double) * 2 * dim);
+      dense_comm(s, c->hc_im + (size_t)k * nn, zero, 0, z, w);
+      for (int e = 0; e < dim; e++) qbar += w[e] * xbar[e] + w[e + dim] * xbar[e + dim];
+      memset(w, 0, sizeof(double) * 2 * dim);
+      dense_comm(s, c->hc_re + (size_t)k * nn, zero, 0, z, w);
+      for (int e = 0; e < dim; e++) pbar += w[e + dim] * xbar[e] - w[e] * xbar[e + dim];
+      coeff[2 * k] = pbar;
+      coeff[2 * k + 1] = qbar;
+    }
+    free(w);
+    free(zero);
+    return 0;
+  }
   const double* sq = s->sq;
   int i[QO_MAXQ], ip[QO_MAXQ], np[QO_MAXQ];
   for (int k = 0; k < Q; k++) {

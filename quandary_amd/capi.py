@@ -169,7 +169,7 @@ def iptr(a):
 # Every symbol include/quandary_amd.h declares; tests check the library exports all of them.
 EXPORTS = [
     "qd_last_error", "qd_version", "qd_device_count", "qd_create", "qd_destroy", "qd_dim", "qd_dim_rho",
-    "qd_dim_ess", "qd_ndesign", "qd_set_params", "qd_eval_controls", "qd_apply_rhs", "qd_get_state",
+    "qd_dim_ess", "qd_ndesign", "qd_set_hamiltonian", "qd_set_params", "qd_eval_controls", "qd_apply_rhs", "qd_get_state",
     "qd_set_target", "qd_set_penalty", "qd_forward", "qd_adjoint", "qd_last_mean_applies",
     "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
@@ -204,6 +204,7 @@ def load_library(path=None):
     lib.qd_destroy.restype = None
     for f in ("qd_dim", "qd_dim_rho", "qd_dim_ess", "qd_ndesign"):
         getattr(lib, f).argtypes = [vp]
+    lib.qd_set_hamiltonian.argtypes = [vp, c_dp, c_dp, c_dp, c_dp]
     lib.qd_set_params.argtypes = [vp, c_dp, C.c_int]
     lib.qd_eval_controls.argtypes = [vp, c_dp, C.c_int, c_dp]
     lib.qd_apply_rhs.argtypes = [vp, C.c_double, C.c_int, c_dp, c_dp, C.c_int]
@@ -262,6 +263,22 @@ class Handle:
         self.dim_ess = self.lib.qd_dim_ess(self._h)
         self.ndesign = self.lib.qd_ndesign(self._h)
         self._keep = []
+        ham = getattr(spec, "hamiltonian", None)  # (Hsys, Hc) complex arrays from hamiltonian_file_Hsys / _Hc
+        if ham is not None:
+            self.set_hamiltonian(*ham)
+
+    def set_hamiltonian(self, hsys, hc=None):
+        """User-supplied Hamiltonians: hsys complex [N, N], hc complex [nosc, N, N] or None (rad/ns)."""
+        n = self.dim_rho
+        hsys = np.asarray(hsys, dtype=complex).reshape(n, n)
+        sr, si = np.ascontiguousarray(hsys.real), np.ascontiguousarray(hsys.imag)
+        if hc is not None:
+            hc = np.asarray(hc, dtype=complex).reshape(self.spec.system.nosc, n, n)
+            cr, ci = np.ascontiguousarray(hc.real), np.ascontiguousarray(hc.imag)
+            rc = self.lib.qd_set_hamiltonian(self._h, dptr(sr), dptr(si), dptr(cr), dptr(ci))
+        else:
+            rc = self.lib.qd_set_hamiltonian(self._h, dptr(sr), dptr(si), None, None)
+        _check(self.lib, rc, "qd_set_hamiltonian")
 
     def close(self):
         if self._h:

@@ -475,7 +475,34 @@ def build_spec(cfg, cfg_dir="."):
     sp.ninit = ninit
     sp.output_frequency = _atoi(cfg.get("output_frequency", "1"))
     sp.outputs = [_vec_str(cfg, f"output{i}", "none") for i in range(Q)]
+    # user-supplied Hamiltonians (src/main.cpp:309-316, src/hamiltonianfilereader.cpp)
+    fsys, fc = cfg.get("hamiltonian_file_Hsys", "none"), cfg.get("hamiltonian_file_Hc", "none")
+    sp.hamiltonian = None
+    if fsys != "none" or fc != "none":
+        sp.hamiltonian = read_hamiltonian_files(None if fsys == "none" else os.path.join(cfg_dir, fsys),
+                                                None if fc == "none" else os.path.join(cfg_dir, fc), N, Q)
     return sp
+
+
+def read_hamiltonian_files(path_sys, path_c, N, Q):
+    """`row col real imag` lines for Hsys, `oscillator row col real imag` lines for Hc; '#' comments.
+    Returns (Hsys [N,N] complex, Hc [Q,N,N] complex or None)."""
+    hsys = np.zeros((N, N), dtype=complex)
+    if path_sys:
+        for line in open(path_sys):
+            t = line.split()
+            if not t or line.startswith("#") or len(t) < 4:
+                continue
+            hsys[int(t[0]), int(t[1])] = float(t[2]) + 1j * float(t[3])
+    hc = None
+    if path_c:
+        hc = np.zeros((Q, N, N), dtype=complex)
+        for line in open(path_c):
+            t = line.split()
+            if not t or line.startswith("#") or len(t) < 5:
+                continue
+            hc[int(t[0]), int(t[1]), int(t[2])] += float(t[3]) + 1j * float(t[4])
+    return hsys, hc
 
 
 def load(path):

@@ -35,10 +35,11 @@ namespace qd {
 // COL    column-per-wave layout (ColStencil)
 // LEAN   throughput regime: no register-carried prefetches, the vectors that are idle during a linear
 //        solve are parked in L2/HBM explicitly (SweepArgs::stash) instead of being spilled by the compiler
-template <int EPT_, int MAXB_, bool DBUF_, bool ONEWAVE_, int ICPB_ = 1, bool COL_ = false, bool LEAN_ = false>
+// DENSE  user-supplied dense Hamiltonians (DenseStencil) instead of the matrix-free stencil
+template <int EPT_, int MAXB_, bool DBUF_, bool ONEWAVE_, int ICPB_ = 1, bool COL_ = false, bool LEAN_ = false, bool DENSE_ = false>
 struct VariantDef {
   static constexpr int EPT = EPT_, MAXB = MAXB_, ICPB = ICPB_, FENCE = 1;
-  static constexpr bool DBUF = DBUF_, ONEWAVE = ONEWAVE_, BLDS = false, COL = COL_, LEAN = LEAN_;
+  static constexpr bool DBUF = DBUF_, ONEWAVE = ONEWAVE_, BLDS = false, COL = COL_, LEAN = LEAN_, DENSE = DENSE_;
 };
 template <int VAR> struct Variant;
 template <> struct Variant<0> : VariantDef<1, 64, false, true> {};     // dim <= 64: one wave, no barriers
@@ -58,7 +59,11 @@ template <> struct Variant<7> : VariantDef<2, 256, true, false, 2> {};
 template <> struct Variant<8> : VariantDef<4, 1024, true, false, 1, true, true> {};
 template <> struct Variant<9> : VariantDef<8, 512, true, false, 1, true, true> {};
 template <> struct Variant<10> : VariantDef<6, 640, true, false, 1, true, true> {};
-constexpr int NVARIANTS = 11;
+// V11-V13: the linear-map variants V0-V2 with the dense user-Hamiltonian operator (hamiltonian_file_Hsys / _Hc)
+template <> struct Variant<11> : VariantDef<1, 64, false, true, 1, false, false, true> {};
+template <> struct Variant<12> : VariantDef<1, 256, true, false, 1, false, false, true> {};
+template <> struct Variant<13> : VariantDef<4, 256, true, false, 1, false, false, true> {};
+constexpr int NVARIANTS = 14;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 
@@ -187,6 +192,7 @@ template <int Q>
 struct StepC {
   double h, p[Q], q[Q];
   double cs[Q * (Q - 1) / 2 + 1], sn[Q * (Q - 1) / 2 + 1];
+  const double2* g;  // user-Hamiltonian path: G(t) = -i H(t) of this sub-step, N x N row-major (null otherwise)
 };
 
 template <int Q>
@@ -1092,14 +1098,99 @@ struct QubitSlotStencil {
   __device__ __forceinline__ bool is_guard(const DevSys&, int) const { return false; }
 };
 
-template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false>
+
+// ---------------------------------------------------------------------------------------------
+// dense operator (user-supplied Hamiltonians; the reference serves them with its sparse-matrix solver:
+// src/hamiltonianfilereader.cpp, applyRHS_sparsemat src/mastereq.cpp:743-967).  In Hilbert space
+//   G(t) = -i H(t),  H(t) = Hsys + sum_k p_k(t) Re(Hc_k) + i q_k(t) Im(Hc_k)
+//   Schroedinger: y = G psi          Lindblad: y = G rho - rho G + (T1/T2 dissipators of the standard model)
+// and the transposed real operator is the same expression with G^H.  G(t) of every sub-step is tabulated
+// once per parameter update (k_gmat, shared by all initial conditions, read through L2); the
+// dissipators reuse the general stencil's digit tables.
+// ---------------------------------------------------------------------------------------------
+template <int Q, bool LIND, int EPT, int EPE = EPT>
+struct DenseStencil : GenStencil<Q, LIND, EPT, EPE> {
+  typedef GenStencil<Q, LIND, EPT, EPE> Base;
+  using Base::it;
+  using Base::dbra;
+  using Base::dket;
+  using Base::dd;
+  using Base::ofs;
+  using Base::dig;
+
+  __device__ __forceinline__ static double2 cmul_acc(double2 acc, double2 a, double2 b) {  // acc + a b
+    acc.x = fma(a.x, b.x, fma(-a.y, b.y, acc.x));
+    acc.y = fma(a.x, b.y, fma(a.y, b.x, acc.y));
+    return acc;
+  }
+
+  // sum_m Gt(I,m) x(m,I') - x(I,m) Gt(m,I')  with Gt = G or G^H
+  template <bool TRANS, typename GET>
+  __device__ __forceinline__ double2 commutator(const DevSys& S, const double2* __restrict__ sx, int I, int Ip, GET g) const {
+    const int N = S.N;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int m = 0; m < N; m++) {
+      double2 gl = TRANS ? g(m, I) : g(I, m);
+      if (TRANS) gl.y = -gl.y;
+      acc = cmul_acc(acc, gl, LIND ? sx[Ip * N + m] : sx[m]);
+      if (LIND) {
+        double2 gr = TRANS ? g(Ip, m) : g(m, Ip);
+        if (TRANS) gr.y = -gr.y;
+        gr.x = -gr.x;
+        gr.y = -gr.y;
+        acc = cmul_acc(acc, sx[m * N + I], gr);
+      }
+    }
+    return acc;
+  }
+
+  // gradient contraction: A = [Im(Hc_k), z], B = [Re(Hc_k), z]  (the control part of M z is q A - i p B)
+  __device__ __forceinline__ void ladder(const DevSys& S, const Lds&, const double2* __restrict__ sx, int k, int j, double2& A,
+                                         double2& B) const {
+    const int N = S.N, i0 = opaque(it[j]);
+    const int I = LIND ? i0 % N : i0, Ip = LIND ? i0 / N : 0;
+    const double* hr = S.hcr + (size_t)k * N * N;
+    const double* hi = S.hci + (size_t)k * N * N;
+    A = commutator<false>(S, sx, I, Ip, [&](int r, int c) { return make_double2(hi[r * N + c], 0.0); });
+    B = commutator<false>(S, sx, I, Ip, [&](int r, int c) { return make_double2(hr[r * N + c], 0.0); });
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                           const double2 xs) const {
+    const int N = S.N, i0 = opaque(it[j]), top = S.dim - 1;
+    const int I = LIND ? i0 % N : i0, Ip = LIND ? i0 / N : 0;
+    const double2* __restrict__ G = c.g;
+    double2 y = commutator<TRANS>(S, sx, I, Ip, [&](int r, int cc) { return G[r * N + cc]; });
+    if (LIND) {
+      y.x = fma(dd[j], xs.x, y.x);
+      y.y = fma(dd[j], xs.y, y.y);
+      const unsigned db = opaque(dbra[j]), dk = opaque(dket[j]);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const double g1 = S.g1off[k];
+        if (g1 == 0.0) continue;
+        const int a = dig(db, k), ap = dig(dk, k), st = S.post[k] * (N + 1);
+        const double l1 = g1 * (TRANS ? L.tdn[ofs[k] + a] * L.tdn[ofs[k] + ap] : L.tup[ofs[k] + a] * L.tup[ofs[k] + ap]);
+        const double2 xn = sx[TRANS ? max(i0 - st, 0) : min(i0 + st, top)];
+        y.x = fma(l1, xn.x, y.x);
+        y.y = fma(l1, xn.y, y.y);
+      }
+    }
+    return y;
+  }
+};
+
+template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false, bool DENSE = false>
 struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, bool LIND, int EPT, int EPE>
-struct StencilSel<Q, LIND, EPT, EPE, true, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
+struct StencilSel<Q, LIND, EPT, EPE, true, false, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, int EPT, int EPE>
-struct StencilSel<Q, true, EPT, EPE, false, true> { typedef ColStencil<Q, EPT> type; };
+struct StencilSel<Q, true, EPT, EPE, false, true, false> { typedef ColStencil<Q, EPT> type; };
 template <int Q>
-struct StencilSel<Q, true, 4, 4, true, false> { typedef QubitSlotStencil<Q> type; };
+struct StencilSel<Q, true, 4, 4, true, false, false> { typedef QubitSlotStencil<Q> type; };
+template <int Q, bool LIND, int EPT, int EPE>
+struct StencilSel<Q, LIND, EPT, EPE, false, false, true> { typedef DenseStencil<Q, LIND, EPT, EPE> type; };
 
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
 template <int Q, bool LIND, int EPT, int EPE>
@@ -1110,6 +1201,8 @@ template <int Q, int EPT>
 __device__ __forceinline__ bool slot_valid(const ColStencil<Q, EPT>& st, int j) { return st.valid[j]; }
 template <int Q>
 __device__ __forceinline__ bool slot_valid(const QubitSlotStencil<Q>& st, int j) { return st.valid[j]; }
+template <int Q, bool LIND, int EPT, int EPE>
+__device__ __forceinline__ bool slot_valid(const DenseStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)
@@ -1252,7 +1345,7 @@ struct Team {
   static constexpr int EPT = V::EPT;    // slots per thread
   static constexpr int ICPB = V::ICPB;  // initial conditions per workgroup (interleaved in the same threads)
   static constexpr int EPE = EPT / ICPB;  // elements per thread of ONE initial condition
-  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL>::type ST;
+  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL, V::DENSE>::type ST;
   ST st;
   Lds L;
   int cur;      // which LDS buffer holds the vector that may be stencil-read
@@ -1731,6 +1824,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
       load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
       scalarize<Q>(c, jpairs);
     }
+    c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     tm.st.prep(c);
     if (traj) {
 #pragma unroll
@@ -2003,6 +2097,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     if (!CARRY) scalarize<Q>(c, jpairs);
+    c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     tm.st.prep(c);
     double cf[2 * Q * ICPB];
 #pragma unroll
@@ -2037,6 +2132,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       store_coeffs();
       StepC<Q> c1;
       load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
+      c1.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
       tm.st.prep(c1);
       tm.publish(xb);
       double2 t[EPT];
@@ -2157,6 +2253,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_apply(const DevSys S, co
   tm.publish(x);
   StepC<Q> c;
   load_step<Q>(ctlrow, c, S.npairs > 0);
+  c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) : nullptr;  // one-row table for the test hook
   tm.st.prep(c);
   if (transpose) tm.template apply_all<true>(S, c, x, y);
   else tm.template apply_all<false>(S, c, x, y);

@@ -63,7 +63,7 @@ extern "C" void qd_destroy(qd_handle* h) {
   (void)hipSetDevice(h->device);
   for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_pen, &h->d_dpdm, &h->d_out4,
-                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry})
+                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
   if (h->d_oscs) (void)hipFree(h->d_oscs);
@@ -305,6 +305,39 @@ extern "C" int qd_dim_rho(const qd_handle* h) { return h ? h->S.N : QD_ERR_INVAL
 extern "C" int qd_dim_ess(const qd_handle* h) { return h ? h->dim_ess : QD_ERR_INVALID; }
 extern "C" int qd_ndesign(const qd_handle* h) { return h ? h->ndesign : QD_ERR_INVALID; }
 
+extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const double* hsys_im, const double* hc_re, const double* hc_im) {
+  if (!h || !hsys_re || !hsys_im) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: null system Hamiltonian");
+  if ((hc_re == nullptr) != (hc_im == nullptr)) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: give both parts of the control Hamiltonians or neither");
+  if (h->S.dim > 1024) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: user Hamiltonians are supported for state dimensions up to 1024");
+  QD_HIP(hipSetDevice(h->device));
+  const size_t nn = (size_t)h->S.N * h->S.N;
+  if ((double)h->sched_t.size() * (double)nn * 16.0 > 16e9)
+    return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: the table of G(t) would exceed 16 GB (time steps x N^2)");
+  // G0 = -i Hsys = Im(Hsys) - i Re(Hsys): Ad = Im(Hsys), Bd = -Re(Hsys) (src/hamiltonianfilereader.cpp:77-84)
+  std::vector<double> g0(2 * nn), cr((size_t)h->S.Q * nn, 0.0), ci((size_t)h->S.Q * nn, 0.0);
+  for (size_t e = 0; e < nn; e++) {
+    g0[2 * e] = hsys_im[e];
+    g0[2 * e + 1] = -hsys_re[e];
+  }
+  if (hc_re) {
+    std::copy(hc_re, hc_re + cr.size(), cr.begin());
+    std::copy(hc_im, hc_im + ci.size(), ci.begin());
+  }
+  int r;
+  if ((r = h->d_g0.ensure(g0.size())) || (r = h->d_hcr.ensure(cr.size())) || (r = h->d_hci.ensure(ci.size()))) return r;
+  QD_HIP(hipMemcpy(h->d_g0.p, g0.data(), sizeof(double) * g0.size(), hipMemcpyHostToDevice));
+  QD_HIP(hipMemcpy(h->d_hcr.p, cr.data(), sizeof(double) * cr.size(), hipMemcpyHostToDevice));
+  QD_HIP(hipMemcpy(h->d_hci.p, ci.data(), sizeof(double) * ci.size(), hipMemcpyHostToDevice));
+  h->S.dense = 1;
+  h->S.hcr = h->d_hcr.p;
+  h->S.hci = h->d_hci.p;
+  h->S.gtab = nullptr;
+  h->S.hasJ = 0;  // the file model replaces the standard one including the dipole-dipole terms (src/mastereq.cpp:273-284)
+  h->params_dirty = true;
+  h->traj_valid = false;
+  return QD_OK;
+}
+
 extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
   if (!h || (!alpha && ndesign > 0)) return fail(QD_ERR_INVALID, "qd_set_params: null argument");
   if (ndesign != h->ndesign) return fail(QD_ERR_INVALID, "qd_set_params: ndesign mismatch");
@@ -324,6 +357,13 @@ extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
 int qd_handle::refresh_tables() {
   if (!params_dirty) return QD_OK;
   QD_HIP(launch_controls(dctl, d_params.p, d_sched_t.p, d_sched_h.p, (int)sched_t.size(), d_table.p, cs, stream));
+  if (S.dense) {  // G(t) = -i H(t) for every table row, shared by all initial conditions
+    const size_t nn = (size_t)S.N * S.N;
+    int r;
+    if ((r = d_gtab.ensure(sched_t.size() * nn * 2))) return r;
+    S.gtab = d_gtab.p;
+    QD_HIP(launch_gmat(S, d_g0.p, d_table.p, cs, (int)sched_t.size(), d_gtab.p, stream));
+  }
   QD_HIP(launch_controls(dctl, d_params.p, d_etimes.p, d_ezero.p, (int)etimes.size(), d_etable.p, cs, stream));
   // asynchronous: complete at the stream synchronisation that ends the sweep (forward_dev)
   QD_HIP(hipMemcpyAsync(h_etable.p, d_etable.p, sizeof(double) * etimes.size() * cs, hipMemcpyDeviceToHost, stream));
@@ -369,8 +409,8 @@ extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, doubl
 }
 
 static int check_cfg(const LaunchCfg& cfg) {
-  static const int maxb[11] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640};
-  if (cfg.var < 0 || cfg.var > 10 || cfg.block > maxb[cfg.var])
+  static const int maxb[14] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640, 64, 256, 256};
+  if (cfg.var < 0 || cfg.var > 13 || cfg.block > maxb[cfg.var])
     return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
   if (cfg.lds > 160 * 1024) return fail(QD_ERR_UNSUPPORTED, "state does not fit the 160 KiB LDS of one CU");
   return QD_OK;
@@ -389,7 +429,13 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
   QD_HIP(hipMemcpyAsync(h->d_x0.p, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   LaunchCfg cfg = pick_config(h->S, nb);
   if ((r = check_cfg(cfg))) return r;
-  QD_HIP(launch_apply(h->S, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
+  qd::DevSys Sone = h->S;
+  if (h->S.dense) {
+    if ((r = h->d_gone.ensure((size_t)2 * h->S.N * h->S.N))) return r;
+    QD_HIP(launch_gmat(h->S, h->d_g0.p, h->d_onerow.p, h->cs, 1, h->d_gone.p, h->stream));
+    Sone.gtab = h->d_gone.p;
+  }
+  QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
   return QD_OK;

@@ -97,6 +97,7 @@ struct qd_handle {
   int target_nb = 0;
   // sweep buffers
   qd::DBuf d_x0, d_xT, d_traj, d_pen, d_dpdm, d_out4, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
+  qd::DBuf d_g0, d_hcr, d_hci, d_gtab, d_gone;  // dense user-Hamiltonian path (qd_set_hamiltonian)
   unsigned long long* d_napply = nullptr;
   int last_nb = 0;
   bool traj_valid = false;

@@ -5,7 +5,7 @@
 #include "qd_device.h"
 
 #if !defined(QD_Q) || !defined(QD_L) || !defined(QD_B)
-#error "compile with -DQD_Q=<1..8> -DQD_L=<0|1> -DQD_B=<0|1>"
+#error "compile with -DQD_Q=<1..8> -DQD_L=<0|1> -DQD_B=<0 general|1 qubit|2 dense>"
 #endif
 
 namespace qd {
@@ -13,7 +13,8 @@ namespace qd {
 #define QD_CAT4(a, q, l, b) a##q##_##l##_##b
 #define QD_NAME(base, q, l, b) QD_CAT4(base, q, l, b)
 
-constexpr bool kQubit = (QD_B != 0);
+constexpr bool kQubit = (QD_B == 1);
+constexpr bool kDense = (QD_B == 2);  // user-supplied dense Hamiltonians (DenseStencil)
 constexpr bool kLind = (QD_L != 0);
 // all-qubit systems have a fixed dimension, so only the matching variants are built
 constexpr int kQubitDim = kLind ? (1 << (2 * QD_Q)) : (1 << QD_Q);
@@ -25,6 +26,7 @@ constexpr bool variant_built() {
   // class never exceed the number of SIMDs, so one initial condition per wave wins, C2 38.6M vs 26.7M
   // units/s); V3 and V5 (1024-thread blocks: 128 VGPRs are not enough, 8-12x slower than V2 on C5); V8 and
   // V10 (column layout with 4 / 6 columns per wave: 4.0M vs 4.85M units/s of V9 on C4).
+  if (kDense) return VAR >= 11 && VAR <= 13;
   if (!kQubit) return VAR <= 2 || VAR == 4 || (kLind && VAR == 9);
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
@@ -89,6 +91,9 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
     case 8: return FN<8>(__VA_ARGS__);       \
     case 9: return FN<9>(__VA_ARGS__);       \
     case 10: return FN<10>(__VA_ARGS__);     \
+    case 11: return FN<11>(__VA_ARGS__);     \
+    case 12: return FN<12>(__VA_ARGS__);     \
+    case 13: return FN<13>(__VA_ARGS__);     \
     default: return hipErrorInvalidValue;    \
   }
 

@@ -23,6 +23,11 @@ struct DevSys {
   double detune[QD_MAX_OSC], xi[QD_MAX_OSC], g1[QD_MAX_OSC], g2[QD_MAX_OSC];
   double g1off[QD_MAX_OSC];  // gamma_1 of the off-diagonal decay term: 0 unless |gamma_1| > 1e-12 (mastereq.hpp:759)
   double xikl[QD_MAX_PAIRS], J[QD_MAX_PAIRS];
+  // user-supplied dense Hamiltonians (qd_set_hamiltonian); the standard Hamiltonian model is then unused
+  int dense, pad1;
+  const double* hcr;   // [Q][N*N] Re(Hc_k), row-major
+  const double* hci;   // [Q][N*N] Im(Hc_k)
+  const double* gtab;  // [rows][N*N] interleaved complex: G(t_row) = -i H(t_row), one row per control-table row
 };
 
 // Control parameterisation on the device (src/oscillator.cpp:45-132, src/controlbasis.cpp:20-32,219-225)
@@ -84,7 +89,7 @@ struct SweepArgs {
 
 struct LaunchCfg {
   int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)
-  int qubit;  // 1: all oscillators have two levels -> bit-trick stencil
+  int qubit;  // stencil family: 0 general (runtime level counts), 1 all-qubit bit tricks, 2 dense user Hamiltonians
   int block;  // threads per block (one block per initial condition)
   int gmres;  // 0 Neumann, 1 GMRES with the Krylov basis in LDS, 2 GMRES with the basis in global memory
   size_t lds;
@@ -97,6 +102,7 @@ hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, co
                         const LaunchCfg& cfg, hipStream_t st);
 hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
 hipError_t launch_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
+hipError_t launch_gmat(const DevSys& S, const double* g0, const double* table, int cs, int nrows, double* gtab, hipStream_t st);
 hipError_t launch_objective(const DevSys& S, const DevTarget& tg, const double* x, int nb, double* out4, hipStream_t st);
 hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, const double* rbar_ibar, int nb, double* xbar,
                        hipStream_t st);

@@ -210,6 +210,27 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// dense user-Hamiltonian path: G(t_row) = -i Hsys + sum_k q_k Im(Hc_k) - i p_k Re(Hc_k) for every row of
+// the control table (Re = Ad + sum q_k Ac_k, Im = Bd + sum p_k Bc_k with Ac = Im(Hc), Bc = -Re(Hc):
+// src/mastereq.cpp:760-795, src/hamiltonianfilereader.cpp:77-84,170-176)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gmat(const DevSys S, const double* __restrict__ g0, const double* __restrict__ table, int cs, int nrows,
+                       double* __restrict__ gtab) {
+  const int nn = S.N * S.N;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)nrows * nn) return;
+  const int row = (int)(e / nn), el = (int)(e % nn);
+  const double* r = table + (size_t)row * cs;
+  double re = g0[2 * el], im = g0[2 * el + 1];
+  for (int k = 0; k < S.Q; k++) {
+    re = fma(r[2 + S.Q + k], S.hci[(size_t)k * nn + el], re);
+    im = fma(-r[2 + k], S.hcr[(size_t)k * nn + el], im);
+  }
+  gtab[2 * e] = re;
+  gtab[2 * e + 1] = im;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 // Variant choice.  One workgroup per initial condition.  Few initial conditions (latency regime):
@@ -217,15 +238,16 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 // regime): more elements per thread so that several workgroups share a CU.
 constexpr int QD_COL_DEFAULT = 9;
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
-  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2, 4, 8, 6}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1};
-  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640};
-  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true, true, true, true};
-  static const bool colv[NVARIANTS] = {false, false, false, false, false, false, false, false, true, true, true};
+  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2, 4, 8, 6, 1, 1, 4}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1};
+  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640, 64, 256, 256};
+  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true, true, true, true, false, true, true};
+  static const bool colv[NVARIANTS] = {false, false, false, false, false, false, false, false, true, true, true, false, false, false};
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
-  c.qubit = qubit ? 1 : 0;
+  if (S.dense) qubit = false;
+  c.qubit = S.dense ? 2 : qubit ? 1 : 0;
   const bool gm = want_gmres && !getenv("QD_FORCE_NEUMANN");
   // column layout (V8/V9): one wave per column of rho, N <= 64 lanes used
   auto colblock = [&](int v) { return 64 * ((S.N + ept[v] - 1) / ept[v]); };
@@ -234,6 +256,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
     return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v];
   };
   auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
+    if (S.dense) return v >= 11 && v <= 13;
     if (!qubit) return v <= 2 || v == 4 || (S.lindblad && v == 9);
     return dim <= 64 ? v == 0 : dim <= 256 ? v == 1 : v == 2;
   };
@@ -242,6 +265,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   else if (dim <= 256) var = 1;
   else if (dim <= 1024) var = 2;
   else var = fits(QD_COL_DEFAULT) ? QD_COL_DEFAULT : 4;
+  if (S.dense) var = dim <= 64 ? 11 : dim <= 256 ? 12 : 13;  // qd_set_hamiltonian limits dim to 1024
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
@@ -277,31 +301,36 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 QD_DECL_Q(0, 0) QD_DECL_Q(1, 0) QD_DECL_Q(0, 1) QD_DECL_Q(1, 1)
 // Schroedinger only: 6..8 oscillators (beyond the reference's matrix-free templates, which stop at 5)
 QD_DECL(6, 0, 0) QD_DECL(7, 0, 0) QD_DECL(8, 0, 0) QD_DECL(6, 0, 1) QD_DECL(7, 0, 1) QD_DECL(8, 0, 1)
+// dense user-Hamiltonian operator
+QD_DECL_Q(0, 2) QD_DECL_Q(1, 2)
 
 typedef hipError_t (*sweep_fn)(const SweepArgs&, const LaunchCfg&, hipStream_t);
 typedef hipError_t (*apply_fn)(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);
 #define QD_ROW(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b, nullptr, nullptr, nullptr}
 #define QD_ROW8(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b, base##6_##l##_##b, base##7_##l##_##b, base##8_##l##_##b}
 // index [qubit][lindblad][Q-1]
-static const sweep_fn fwd_tab[2][2][8] = {{QD_ROW8(inst_forward_, 0, 0), QD_ROW(inst_forward_, 1, 0)},
-                                          {QD_ROW8(inst_forward_, 0, 1), QD_ROW(inst_forward_, 1, 1)}};
-static const sweep_fn adj_tab[2][2][8] = {{QD_ROW8(inst_adjoint_, 0, 0), QD_ROW(inst_adjoint_, 1, 0)},
-                                          {QD_ROW8(inst_adjoint_, 0, 1), QD_ROW(inst_adjoint_, 1, 1)}};
-static const apply_fn app_tab[2][2][8] = {{QD_ROW8(inst_apply_, 0, 0), QD_ROW(inst_apply_, 1, 0)},
-                                          {QD_ROW8(inst_apply_, 0, 1), QD_ROW(inst_apply_, 1, 1)}};
+static const sweep_fn fwd_tab[3][2][8] = {{QD_ROW8(inst_forward_, 0, 0), QD_ROW(inst_forward_, 1, 0)},
+                                          {QD_ROW8(inst_forward_, 0, 1), QD_ROW(inst_forward_, 1, 1)},
+                                          {QD_ROW(inst_forward_, 0, 2), QD_ROW(inst_forward_, 1, 2)}};
+static const sweep_fn adj_tab[3][2][8] = {{QD_ROW8(inst_adjoint_, 0, 0), QD_ROW(inst_adjoint_, 1, 0)},
+                                          {QD_ROW8(inst_adjoint_, 0, 1), QD_ROW(inst_adjoint_, 1, 1)},
+                                          {QD_ROW(inst_adjoint_, 0, 2), QD_ROW(inst_adjoint_, 1, 2)}};
+static const apply_fn app_tab[3][2][8] = {{QD_ROW8(inst_apply_, 0, 0), QD_ROW(inst_apply_, 1, 0)},
+                                          {QD_ROW8(inst_apply_, 0, 1), QD_ROW(inst_apply_, 1, 1)},
+                                          {QD_ROW(inst_apply_, 0, 2), QD_ROW(inst_apply_, 1, 2)}};
 
 hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (a.S.Q < 1 || a.S.Q > 8 || !fwd_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;
-  return fwd_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
+  if (a.S.Q < 1 || a.S.Q > 8 || !fwd_tab[cfg.qubit][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;
+  return fwd_tab[cfg.qubit][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
 }
 hipError_t launch_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (a.S.Q < 1 || a.S.Q > 8 || !adj_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;
-  return adj_tab[cfg.qubit ? 1 : 0][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
+  if (a.S.Q < 1 || a.S.Q > 8 || !adj_tab[cfg.qubit][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;
+  return adj_tab[cfg.qubit][a.S.lindblad ? 1 : 0][a.S.Q - 1](a, cfg, st);
 }
 hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                         const LaunchCfg& cfg, hipStream_t st) {
-  if (S.Q < 1 || S.Q > 8 || !app_tab[cfg.qubit ? 1 : 0][S.lindblad ? 1 : 0][S.Q - 1]) return hipErrorInvalidValue;
-  return app_tab[cfg.qubit ? 1 : 0][S.lindblad ? 1 : 0][S.Q - 1](S, ctlrow, transpose, x, y, nb, cfg, st);
+  if (S.Q < 1 || S.Q > 8 || !app_tab[cfg.qubit][S.lindblad ? 1 : 0][S.Q - 1]) return hipErrorInvalidValue;
+  return app_tab[cfg.qubit][S.lindblad ? 1 : 0][S.Q - 1](S, ctlrow, transpose, x, y, nb, cfg, st);
 }
 
 hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
@@ -309,6 +338,13 @@ hipError_t launch_controls(const DevCtlDesc& d, const double* params, const doub
   const int total = nrows * d.Q;
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(k_controls, dim3((total + 127) / 128), dim3(128), 0, st, d, params, times, hs, nrows, table, cs);
+  return hipGetLastError();
+}
+
+hipError_t launch_gmat(const DevSys& S, const double* g0, const double* table, int cs, int nrows, double* gtab, hipStream_t st) {
+  const size_t total = (size_t)nrows * S.N * S.N;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gmat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, g0, table, cs, nrows, gtab);
   return hipGetLastError();
 }
 

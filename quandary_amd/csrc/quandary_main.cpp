@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <random>
 #include <sstream>
@@ -643,6 +644,43 @@ int main(int argc, char** argv) {
   qd_handle* h = nullptr;
   QDCHK(qd_create(&P.sys, &P.ctl, &P.tg, &P.sol, P.cfg.integer("device", 0), &h));
   if (qd_ndesign(h) != (int)P.params0.size()) die("internal: parameter count mismatch");
+  {  // user-supplied Hamiltonians (src/main.cpp:309-316, src/hamiltonianfilereader.cpp)
+    const std::string fsys = P.cfg.str("hamiltonian_file_Hsys", "none"), fc = P.cfg.str("hamiltonian_file_Hc", "none");
+    if (fsys != "none" || fc != "none") {
+      const int N = qd_dim_rho(h);
+      const size_t nn = (size_t)N * N;
+      std::vector<double> sre(nn, 0.0), sim(nn, 0.0), cre((size_t)P.Q * nn, 0.0), cim((size_t)P.Q * nn, 0.0);
+      auto each_line = [&](const std::string& fn, int nfields, const std::function<void(const std::vector<double>&)>& fnc) {
+        std::ifstream f(P.cfgdir + fn);
+        if (!f.is_open()) die("Could not open '" + fn + "'");
+        std::string line;
+        while (std::getline(f, line)) {
+          if (line.empty() || line[0] == '#') continue;
+          std::istringstream iss(line);
+          std::vector<double> v;
+          double x;
+          while ((int)v.size() < nfields && (iss >> x)) v.push_back(x);
+          if ((int)v.size() == nfields) fnc(v);
+        }
+      };
+      if (fsys != "none")
+        each_line(fsys, 4, [&](const std::vector<double>& v) {  // row col real imag
+          const size_t e = (size_t)v[0] * N + (size_t)v[1];
+          if (v[0] < 0 || v[0] >= N || v[1] < 0 || v[1] >= N) die("hamiltonian_file_Hsys: index out of range");
+          sre[e] = v[2];
+          sim[e] = v[3];
+        });
+      if (fc != "none")
+        each_line(fc, 5, [&](const std::vector<double>& v) {  // oscillator row col real imag
+          if (v[0] < 0 || v[0] >= P.Q || v[1] < 0 || v[1] >= N || v[2] < 0 || v[2] >= N) die("hamiltonian_file_Hc: index out of range");
+          const size_t e = (size_t)v[0] * nn + (size_t)v[1] * N + (size_t)v[2];
+          cre[e] += v[3];
+          cim[e] += v[4];
+        });
+      QDCHK(qd_set_hamiltonian(h, sre.data(), sim.data(), fc != "none" ? cre.data() : nullptr, fc != "none" ? cim.data() : nullptr));
+      if (!quiet) printf("# Hamiltonian model read from files.\n");
+    }
+  }
   qd_optim* o = nullptr;
   QDCHK(qd_optim_create(h, &P.obj, 0, 1, &o));
   if (!quiet) {

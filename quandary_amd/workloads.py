@@ -42,6 +42,20 @@ def _axc(ntime, linsolve="neumann", init="basis", runtype="simulation"):
     ]) + "\n"
 
 
+def random_hamiltonians(n, nosc, seed=1234):
+    """Synthetic user Hamiltonians for the dense-operator path: random Hermitian Hsys and Hc_k (rad/ns)."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    hsys = 0.3 * (a + a.conj().T)
+    hc = []
+    for _ in range(nosc):
+        b = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        hc.append(0.5 * (b + b.conj().T))
+    return hsys, np.array(hc)
+
+
 WORKLOADS = {
     # name: (description, config text factory(mode))
     "c1": ("C1 2x2 Schroedinger CNOT, 4 basis states (config_template.cfg shape)",
@@ -56,6 +70,9 @@ WORKLOADS = {
            lambda mode: _axc(2500 if mode == "simulation" else 500, runtype=mode)),
     "c5": ("C5 2^5 Lindblad (dim 1024), 1024 basis initial conditions, ntime 1000, fp64 stencil path",
            lambda mode: _qubits(5, True, 1000, 0.01, 30, runtype=mode)),
+    # dense user-Hamiltonian operator (hamiltonian_file_Hsys / _Hc of the reference): random Hermitian 16 x 16
+    "d4": ("D4 2^4 Lindblad with user-supplied dense Hamiltonians (dim 256), 256 basis initial conditions, ntime 1000",
+           lambda mode: _qubits(4, True, 1000, 0.002, 30, runtype=mode) + "synthetic_hamiltonian_seed = 1234\n"),
 }
 
 
@@ -65,5 +82,16 @@ def workload_spec(name, mode="simulation", overrides=None):
     if overrides:
         cfg.update({k: str(v) for k, v in overrides.items()})
     sp = config.build_spec(cfg)
+    attach_synthetic_hamiltonian(sp)
     sp.description = desc
     return sp
+
+
+def attach_synthetic_hamiltonian(sp):
+    """workloads carrying `synthetic_hamiltonian_seed` use generated Hamiltonians instead of files"""
+    seed = sp.cfg.get("synthetic_hamiltonian_seed")
+    if seed is not None:
+        n = 1
+        for k in range(sp.system.nosc):
+            n *= sp.system.nlevels[k]
+        sp.hamiltonian = random_hamiltonians(n, sp.system.nosc, int(seed))

@@ -14,7 +14,8 @@ import sys
 REF = "/root/reference/tests/regression"
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = ["AxC", "AxC_grad_initBasis0", "AxC_grad_schroedinger", "AxC_initDiag0", "AxC_initEnsemble", "AxC_initFile",
-         "cnot", "pipulse", "xgate", "xgate_sparsemat", "state-to-state_spline0", "nlevels_4_4_4_4", "spinchain_N8"]
+         "cnot", "pipulse", "xgate", "xgate_sparsemat", "state-to-state_spline0", "nlevels_4_4_4_4", "spinchain_N8",
+         "hamiltonian-reader", "hamiltonian-reader-lindblad"]
 MAX_BYTES = 120_000
 
 

@@ -76,6 +76,8 @@ def test_driver_cli_without_gpu():
     ("pipulse", ["optim_history.dat", "rho*.dat", "population*.dat", "expected*.dat"]),
     ("nlevels_4_4_4_4", ["population*.dat", "expected*.dat"]),  # 4x4x4x4 Schroedinger with Jkl, composite observables
     ("spinchain_N8", ["population*.dat"]),  # eight coupled qubits: more oscillators than the reference's matrix-free path
+    ("hamiltonian-reader", ["population*.dat", "expected*.dat"]),          # dense user Hamiltonians from files, Schroedinger
+    ("hamiltonian-reader-lindblad", ["population*.dat"]),                   # ... with T1/T2 dissipators
 ])
 def test_simulation_cases(case, patterns, tmp_path):
     out = _run(case, str(tmp_path))

@@ -177,6 +177,69 @@ def test_large_schroedinger_state(linsolve):
     opt.close(); h.close(); orc.close()
 
 
+def _random_hamiltonians(n, nosc, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    hsys = 0.3 * (a + a.conj().T)
+    hc = []
+    for _ in range(nosc):
+        b = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        hc.append(0.5 * (b + b.conj().T))
+    return hsys, np.array(hc)
+
+
+DENSE_SHAPES = [
+    pytest.param(dict(nlevels=[2, 2], lindblad=False), id="dense-2x2-schroedinger"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=True), id="dense-2x2-lindblad"),
+    pytest.param(dict(nlevels=[3, 4], lindblad=True, nessential=[2, 3], target="pure", objective="Jfrobenius"), id="dense-3x4-lindblad-guard"),  # dim 144
+    pytest.param(dict(nlevels=[4, 6], lindblad=True, target="pure", objective="Jmeasure", init="diagonal, 0"), id="dense-4x6-lindblad"),  # dim 576, 4 el/thread
+    pytest.param(dict(nlevels=[10, 12], lindblad=False, target="pure", objective="Jmeasure", init="pure, 1, 2"), id="dense-120-schroedinger"),
+]
+
+
+@pytest.mark.parametrize("kw", DENSE_SHAPES)
+@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
+def test_user_hamiltonian_operator_vs_oracle(kw, linsolve):
+    """qd_set_hamiltonian (dense Hsys / Hc_k instead of the standard model): operator, transpose, objective
+    and gradient against the oracle's restatement of the reference's sparse-matrix formulas."""
+    sp = synthetic_spec(**{**kw, "ntime": 12, "penalties": True, "linsolve": linsolve, "dt": 0.004})
+    n = int(np.prod(kw["nlevels"]))
+    sp.hamiltonian = _random_hamiltonians(n, len(kw["nlevels"]), 11)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    rng = np.random.default_rng(5)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    x = rng.standard_normal((2, 2 * h.dim))
+    t = 0.37 * sp.time.ntime * sp.time.dt
+    for tr in (False, True):
+        yo = orc.apply_rhs(t, x, transpose=tr)
+        np.testing.assert_allclose(h.apply_rhs(t, x, transpose=tr), yo, rtol=1e-12, atol=1e-12 * np.abs(yo).max())
+    y = rng.standard_normal((2, 2 * h.dim))
+    assert np.sum(h.apply_rhs(t, x) * y) == pytest.approx(np.sum(x * h.apply_rhs(t, y, transpose=True)), rel=1e-11)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
+def test_user_hamiltonian_gradient_vs_finite_differences():
+    sp = synthetic_spec(nlevels=[2, 3], lindblad=True, ntime=10, nspline=5, penalties=True, target="pure", objective="Jfrobenius", dt=0.01)
+    sp.hamiltonian = _random_hamiltonians(6, 2, 3)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    a0 = np.array(sp.params0)
+    _, g = opt.evalGradF(a0)
+    rng = np.random.default_rng(2)
+    for i in rng.choice(len(a0), 6, replace=False):
+        e = np.zeros_like(a0); e[i] = 1e-6
+        fd = (opt.evalF(a0 + e)["objective"] - opt.evalF(a0 - e)["objective"]) / 2e-6
+        assert g[i] == pytest.approx(fd, rel=2e-5, abs=1e-9)
+    opt.close(); h.close()
+
+
 def test_forward_states_and_trajectory():
     sp, h, orc = _pair(dict(nlevels=[2, 2, 2], lindblad=True), ntime=30)
     opt = capi.Optim(h, sp)

@@ -141,6 +141,31 @@ def test_spinchain_N8_populations():
     orc.close()
 
 
+@pytest.mark.parametrize("case", ["hamiltonian-reader", "hamiltonian-reader-lindblad"])
+def test_user_hamiltonian_files(case):
+    """hamiltonian_file_Hsys / hamiltonian_file_Hc (dense user Hamiltonians; the reference's sparse-matrix
+    path): every expected*/population* file of the two reference cases."""
+    sp = load_case(case)
+    assert sp.runtype == "simulation" and sp.hamiltonian is not None
+    orc = Oracle(sp)
+    _, traj, _ = orc.evalF(sp.params0, out_freq=sp.output_frequency)
+    ids = [orc.initial_state(i)[1] for i in range(orc.ninit)]
+    files = sorted(glob.glob(os.path.join(GOLDEN, case, "base", "*.dat")))
+    assert files
+    for f in files:
+        name = os.path.basename(f)
+        k = int(name.split(".")[0][-1])
+        ii = ids.index(int(name.split("iinit")[1][:4]))
+        rows, _, d = golden_rows(case, name)
+        if name.startswith("expected"):
+            mine = np.array([orc.expected_energy(k, traj[ii][r]) for r in rows])
+            np.testing.assert_allclose(mine, d[:, 0], rtol=REF_RTOL, atol=1e-12, err_msg=name)
+        else:
+            mine = np.array([orc.population(k, traj[ii][r]) for r in rows])
+            np.testing.assert_allclose(mine, d, rtol=REF_RTOL, atol=1e-12, err_msg=name)
+    orc.close()
+
+
 def test_axc_schroedinger_trajectory():
     case = "AxC_grad_schroedinger"
     sp = load_case(case)
