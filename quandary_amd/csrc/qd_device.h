@@ -246,6 +246,7 @@ struct Lds {
   double* tdn;      //                  tdn[ofs_k + a] = sqrt(a)
   double* red;      // reduction scratch, two slots of NRED * nwaves
   double2* bvec;    // BLDS variants: right-hand side of the linear solve
+  double2* gmat;    // dense operator: G(t) = -i H(t) of the current sub-step, N x N row-major
   double2* coltab;  // column stencil: coltab[c * Q + k] = (sqrt(i'_k + 1) or 0 at the top level, sqrt(i'_k)) of column c
   double2* kry;     // GMRES: Krylov basis, (GMRES_MR + 1) vectors of dim
   double* ksc;      // GMRES: wave-uniform scalars (Hessenberg column, rotations, rhs, R, solution)
@@ -258,7 +259,7 @@ __host__ __device__ inline int table_len(const DevSys& S) {
 // krylov: 0 = Neumann only, 1 = GMRES with the Krylov basis in LDS, 2 = GMRES with the basis in global
 // memory (only the small Hessenberg problem lives in LDS)
 __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool dbuf, bool blds, int krylov = 0, int icpb = 1,
-                                     bool col = false) {
+                                     bool col = false, bool dense = false) {
   Lds l;
   l.buf0 = reinterpret_cast<double2*>(smem);
   l.bstride = dbuf ? S.dim * icpb : 0;
@@ -280,11 +281,17 @@ __device__ __forceinline__ Lds carve(unsigned char* smem, const DevSys& S, bool 
     l.kry = reinterpret_cast<double2*>(p);
     p += 2 * (size_t)(GMRES_MR + 1) * S.dim;
   }
-  if (krylov) l.ksc = p;
+  if (krylov) {
+    l.ksc = p;
+    p += krylov == 1 ? GMRES_NSC : gmres_nsc(GMRES_MR_G);
+  }
+  l.gmat = nullptr;
+  if (dense) l.gmat = reinterpret_cast<double2*>(p + (reinterpret_cast<size_t>(p) & 8 ? 1 : 0));  // 16-byte aligned
   return l;
 }
-static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, int krylov = 0, int icpb = 1, bool col = false) {
-  return (col ? sizeof(double2) * (size_t)S.N * S.Q : 0) + sizeof(double2) * (size_t)S.dim * icpb * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
+static inline size_t lds_bytes(const DevSys& S, int block, bool dbuf, bool blds, int krylov = 0, int icpb = 1, bool col = false,
+                               bool dense = false) {
+  return (dense ? sizeof(double2) * (size_t)S.N * S.N + 16 : 0) + (col ? sizeof(double2) * (size_t)S.N * S.Q : 0) + sizeof(double2) * (size_t)S.dim * icpb * ((dbuf ? 2 : 1) + (blds ? 1 : 0)) + sizeof(double) * 2 * (size_t)table_len(S) +
          sizeof(double) * 2 * NRED * (size_t)((block + 63) / 64) +
          (krylov == 1 ? sizeof(double2) * (size_t)(GMRES_MR + 1) * S.dim + sizeof(double) * GMRES_NSC : 0) +
          (krylov == 2 ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
@@ -391,7 +398,7 @@ struct GenStencil {
     }
   }
 
-  __device__ __forceinline__ void prep(const StepC<Q>&) {}
+  __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>&) {}
 
   // Ladder-operator neighbour sums of oscillator k (control(), mastereq.hpp:818-912):
   //   U1 = sqrt(i+1) x(it+post), U2 = sqrt(i'+1) x(it+N post), D1 = sqrt(i) x(it-post), D2 = sqrt(i') x(it-N post)
@@ -572,7 +579,7 @@ struct QubitStencil {
   double qb[HOIST ? Q : 1], qk[HOIST ? Q : 1];    // controls q_k with the bra / ket digit sign of this element
 
   // once per (sub-)step: fold the digit signs into the controls
-  __device__ __forceinline__ void prep(const StepC<Q>& c) {
+  __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>& c) {
     if (HOIST) {
 #pragma unroll
       for (int k = 0; k < Q; k++) {
@@ -822,7 +829,7 @@ struct ColStencil {
     }
   }
 
-  __device__ __forceinline__ void prep(const StepC<Q>&) {}
+  __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>&) {}
 
   // see GenStencil::ladder
   __device__ __forceinline__ void ladder(const DevSys& S, const Lds& L, const double2* __restrict__ sx, int k, int j, double2& A,
@@ -999,7 +1006,7 @@ struct QubitSlotStencil {
     }
   }
 
-  __device__ __forceinline__ void prep(const StepC<Q>& c) {
+  __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>& c) {
     const unsigned tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
@@ -1118,6 +1125,16 @@ struct DenseStencil : GenStencil<Q, LIND, EPT, EPE> {
   using Base::ofs;
   using Base::dig;
 
+  // once per (sub-)step: stage G(t) in LDS (every element reads 2N entries of it per operator application)
+  // (S.dense == 2: the matrix fits, N <= 64; otherwise it is read from the table through L2)
+  __device__ __forceinline__ void prep(const DevSys& S, const Lds& L, const StepC<Q>& c) {
+    if (!L.gmat) return;
+    if (blockDim.x > 64) __syncthreads();  // nobody still reads the previous step's matrix
+    const int nn = S.N * S.N;
+    for (int e = threadIdx.x; e < nn; e += blockDim.x) L.gmat[e] = c.g[e];
+    if (blockDim.x > 64) __syncthreads();
+  }
+
   __device__ __forceinline__ static double2 cmul_acc(double2 acc, double2 a, double2 b) {  // acc + a b
     acc.x = fma(a.x, b.x, fma(-a.y, b.y, acc.x));
     acc.y = fma(a.x, b.y, fma(a.y, b.x, acc.y));
@@ -1160,7 +1177,7 @@ struct DenseStencil : GenStencil<Q, LIND, EPT, EPE> {
                                            const double2 xs) const {
     const int N = S.N, i0 = opaque(it[j]), top = S.dim - 1;
     const int I = LIND ? i0 % N : i0, Ip = LIND ? i0 / N : 0;
-    const double2* __restrict__ G = c.g;
+    const double2* __restrict__ G = L.gmat ? L.gmat : c.g;
     double2 y = commutator<TRANS>(S, sx, I, Ip, [&](int r, int cc) { return G[r * N + cc]; });
     if (LIND) {
       y.x = fma(dd[j], xs.x, y.x);
@@ -1355,7 +1372,7 @@ struct Team {
   int nb;       // batch size
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, int nbatch, int krylov = 0) {
-    L = carve(smem, S, V::DBUF, V::BLDS, krylov, ICPB, V::COL);
+    L = carve(smem, S, V::DBUF, V::BLDS, krylov, ICPB, V::COL, V::DENSE && S.dense == 2);
     st.init(S, L);
     cur = 0;
     redslot = 0;
@@ -1825,7 +1842,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
       scalarize<Q>(c, jpairs);
     }
     c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
-    tm.st.prep(c);
+    tm.st.prep(S, tm.L, c);
     if (traj) {
 #pragma unroll
       for (int j = 0; j < EPT; j++)
@@ -2098,7 +2115,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     if (!CARRY) scalarize<Q>(c, jpairs);
     c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
-    tm.st.prep(c);
+    tm.st.prep(S, tm.L, c);
     double cf[2 * Q * ICPB];
 #pragma unroll
     for (int i = 0; i < 2 * Q * ICPB; i++) cf[i] = 0.0;
@@ -2133,7 +2150,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       StepC<Q> c1;
       load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
       c1.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
-      tm.st.prep(c1);
+      tm.st.prep(S, tm.L, c1);
       tm.publish(xb);
       double2 t[EPT];
       tm.template apply_all<true>(S, c1, xb, t);
@@ -2254,7 +2271,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_apply(const DevSys S, co
   StepC<Q> c;
   load_step<Q>(ctlrow, c, S.npairs > 0);
   c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) : nullptr;  // one-row table for the test hook
-  tm.st.prep(c);
+  tm.st.prep(S, tm.L, c);
   if (transpose) tm.template apply_all<true>(S, c, x, y);
   else tm.template apply_all<false>(S, c, x, y);
 #pragma unroll

@@ -328,7 +328,7 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   QD_HIP(hipMemcpy(h->d_g0.p, g0.data(), sizeof(double) * g0.size(), hipMemcpyHostToDevice));
   QD_HIP(hipMemcpy(h->d_hcr.p, cr.data(), sizeof(double) * cr.size(), hipMemcpyHostToDevice));
   QD_HIP(hipMemcpy(h->d_hci.p, ci.data(), sizeof(double) * ci.size(), hipMemcpyHostToDevice));
-  h->S.dense = 1;
+  h->S.dense = nn * 16 <= 64 * 1024 ? 2 : 1;  // 2: G(t) of the current sub-step is staged in LDS (N <= 64)
   h->S.hcr = h->d_hcr.p;
   h->S.hci = h->d_hci.p;
   h->S.gtab = nullptr;

@@ -24,7 +24,7 @@ struct DevSys {
   double g1off[QD_MAX_OSC];  // gamma_1 of the off-diagonal decay term: 0 unless |gamma_1| > 1e-12 (mastereq.hpp:759)
   double xikl[QD_MAX_PAIRS], J[QD_MAX_PAIRS];
   // user-supplied dense Hamiltonians (qd_set_hamiltonian); the standard Hamiltonian model is then unused
-  int dense, pad1;
+  int dense, pad1;     // 0: matrix-free stencil; 1: dense operator, G(t) read from the table; 2: ... staged in LDS per sub-step
   const double* hcr;   // [Q][N*N] Re(Hc_k), row-major
   const double* hci;   // [Q][N*N] Im(Hc_k)
   const double* gtab;  // [rows][N*N] interleaved complex: G(t_row) = -i H(t_row), one row per control-table row

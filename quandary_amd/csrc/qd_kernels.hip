@@ -274,15 +274,16 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   c.var = var;
   c.block = colv[var] ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
   c.gmres = 0;
-  c.lds = lds_bytes(S, c.block, dbuf[var], false, 0, icpb[var], colv[var]);
+  const bool dn = S.dense == 2;  // G(t) staged in LDS
+  c.lds = lds_bytes(S, c.block, dbuf[var], false, 0, icpb[var], colv[var], dn);
   if (gm && icpb[var] == 1) {
-    const size_t in_lds = lds_bytes(S, c.block, dbuf[var], false, 1, icpb[var], colv[var]);
+    const size_t in_lds = lds_bytes(S, c.block, dbuf[var], false, 1, icpb[var], colv[var], dn);
     if (ept[var] == 1 && in_lds <= 160 * 1024) {  // Krylov basis in LDS
       c.gmres = 1;
       c.lds = in_lds;
     } else {  // Krylov basis in global memory
       c.gmres = 2;
-      c.lds = lds_bytes(S, c.block, dbuf[var], false, 2, icpb[var], colv[var]);
+      c.lds = lds_bytes(S, c.block, dbuf[var], false, 2, icpb[var], colv[var], dn);
     }
   }
   return c;
