@@ -36,10 +36,12 @@ namespace qd {
 // LEAN   throughput regime: no register-carried prefetches, the vectors that are idle during a linear
 //        solve are parked in L2/HBM explicitly (SweepArgs::stash) instead of being spilled by the compiler
 // DENSE  user-supplied dense Hamiltonians (DenseStencil) instead of the matrix-free stencil
-template <int EPT_, int MAXB_, bool DBUF_, bool ONEWAVE_, int ICPB_ = 1, bool COL_ = false, bool LEAN_ = false, bool DENSE_ = false>
+// PACKED several columns per wave in the column layout (N <= 32)
+template <int EPT_, int MAXB_, bool DBUF_, bool ONEWAVE_, int ICPB_ = 1, bool COL_ = false, bool LEAN_ = false, bool DENSE_ = false,
+          bool PACKED_ = false>
 struct VariantDef {
   static constexpr int EPT = EPT_, MAXB = MAXB_, ICPB = ICPB_, FENCE = 1;
-  static constexpr bool DBUF = DBUF_, ONEWAVE = ONEWAVE_, BLDS = false, COL = COL_, LEAN = LEAN_, DENSE = DENSE_;
+  static constexpr bool DBUF = DBUF_, ONEWAVE = ONEWAVE_, BLDS = false, COL = COL_, LEAN = LEAN_, DENSE = DENSE_, PACKED = PACKED_;
 };
 template <int VAR> struct Variant;
 template <> struct Variant<0> : VariantDef<1, 64, false, true> {};     // dim <= 64: one wave, no barriers
@@ -63,7 +65,9 @@ template <> struct Variant<10> : VariantDef<6, 640, true, false, 1, true, true> 
 template <> struct Variant<11> : VariantDef<1, 64, false, true, 1, false, false, true> {};
 template <> struct Variant<12> : VariantDef<1, 256, true, false, 1, false, false, true> {};
 template <> struct Variant<13> : VariantDef<4, 256, true, false, 1, false, false, true> {};
-constexpr int NVARIANTS = 14;
+// V14: packed column layout for 17 <= N <= 32 (256 < dim <= 1024, non-qubit Lindblad): floor(64/N) columns per wave slot
+template <> struct Variant<14> : VariantDef<4, 256, true, false, 1, true, true, false, true> {};
+constexpr int NVARIANTS = 15;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 
@@ -750,7 +754,10 @@ struct QubitStencil {
 // scalar unit or in one broadcast LDS read; every bra-side quantity is an invariant of the thread.
 // Nothing per slot has to be kept in vector registers except the two diagonal coefficients.
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT>
+// PACKED (N <= 32): floor(64 / N) columns share one wave, lane = (column within the wave slot) N + row.  The ket
+// side is then uniform per lane group instead of per wave (plain vector arithmetic instead of scalars),
+// and only the bra neighbours of the stride-1 oscillator still come from registers (adjacent lanes).
+template <int Q, int EPT, bool PACKED = false>
 struct ColStencil {
   static constexpr bool NEEDS_SLOTS = true;  // apply() takes the thread's other elements of the vector being read
   static constexpr int DB = packed_digit_bits(Q);
@@ -758,6 +765,7 @@ struct ColStencil {
   bool valid[EPT];
   double dw[EPT], dd[EPT];
   int N, row, col0;
+  int cpw, lc;  // PACKED: columns per wave slot, this lane's column within the slot
   unsigned dbra;
   double su[Q], sd[Q];    // sqrt(i_k + 1) (0 at the top level), sqrt(i_k) of this thread's row
   double g1u[Q], g1d[Q];  // gamma_1 su / gamma_1 sd (T1 off-diagonal, forward / transposed)
@@ -765,14 +773,18 @@ struct ColStencil {
   int ofs[Q];
 
   __device__ __forceinline__ static int dig(unsigned d, int k) { return (int)((d >> (DB * k)) & ((1u << DB) - 1u)); }
-  __device__ __forceinline__ int colof(int j) const { return min(col0 + j, N - 1); }  // wave-uniform
+  // column of slot j (clamped): wave-uniform unless PACKED
+  __device__ __forceinline__ int colof(int j) const { return PACKED ? min((col0 + j) * cpw + lc, N - 1) : min(col0 + j, N - 1); }
 
   __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
     N = S.N;
     const int lane = threadIdx.x & 63;
-    col0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * EPT;  // wave w owns the columns w EPT .. w EPT + EPT - 1
-    const bool rowok = lane < N;
-    row = rowok ? lane : N - 1;
+    col0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * EPT;  // wave w owns the column slots w EPT .. w EPT + EPT - 1
+    cpw = PACKED ? 64 / N : 1;
+    lc = PACKED ? lane / N : 0;
+    const bool rowok = PACKED ? lc < cpw : lane < N;
+    row = rowok ? (PACKED ? lane - lc * N : lane) : N - 1;
+    if (!rowok) lc = cpw - 1;
     int o = 0;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
@@ -804,7 +816,7 @@ struct ColStencil {
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int craw = col0 + j, cc = min(craw, N - 1);
+      const int craw = PACKED ? (col0 + j) * cpw + lc : col0 + j, cc = min(craw, N - 1);
       valid[j] = rowok && craw < N;
       it[j] = cc * N + row;
       int ipa[Q];
@@ -869,7 +881,7 @@ struct ColStencil {
       const double2 ct = L.coltab[cc * Q + k];
       const int r0 = opaque(row), ru = opaque(rup[k]), rd = opaque(rdn[k]);  // addresses are re-derived, not hoisted
       const bool last = (k == Q - 1);
-      const bool reg_up = last && j < EPT - 1, reg_dn = last && j > 0;  // compile-time after unrolling
+      const bool reg_up = !PACKED && last && j < EPT - 1, reg_dn = !PACKED && last && j > 0;  // compile-time after unrolling
       const double2 xu = last ? lane_shift<true>(xs) : sx[cN + ru];
       const double2 xd = last ? lane_shift<false>(xs) : sx[cN + rd];
       const double2 xup = reg_up ? xnext : sx[cu + r0];
@@ -1198,24 +1210,24 @@ struct DenseStencil : GenStencil<Q, LIND, EPT, EPE> {
   }
 };
 
-template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false, bool DENSE = false>
+template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false, bool DENSE = false, bool PACKED = false>
 struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, bool LIND, int EPT, int EPE>
-struct StencilSel<Q, LIND, EPT, EPE, true, false, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
-template <int Q, int EPT, int EPE>
-struct StencilSel<Q, true, EPT, EPE, false, true, false> { typedef ColStencil<Q, EPT> type; };
+struct StencilSel<Q, LIND, EPT, EPE, true, false, false, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
+template <int Q, int EPT, int EPE, bool PACKED>
+struct StencilSel<Q, true, EPT, EPE, false, true, false, PACKED> { typedef ColStencil<Q, EPT, PACKED> type; };
 template <int Q>
-struct StencilSel<Q, true, 4, 4, true, false, false> { typedef QubitSlotStencil<Q> type; };
+struct StencilSel<Q, true, 4, 4, true, false, false, false> { typedef QubitSlotStencil<Q> type; };
 template <int Q, bool LIND, int EPT, int EPE>
-struct StencilSel<Q, LIND, EPT, EPE, false, false, true> { typedef DenseStencil<Q, LIND, EPT, EPE> type; };
+struct StencilSel<Q, LIND, EPT, EPE, false, false, true, false> { typedef DenseStencil<Q, LIND, EPT, EPE> type; };
 
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
 template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const GenStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
 template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const QubitStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
-template <int Q, int EPT>
-__device__ __forceinline__ bool slot_valid(const ColStencil<Q, EPT>& st, int j) { return st.valid[j]; }
+template <int Q, int EPT, bool PACKED>
+__device__ __forceinline__ bool slot_valid(const ColStencil<Q, EPT, PACKED>& st, int j) { return st.valid[j]; }
 template <int Q>
 __device__ __forceinline__ bool slot_valid(const QubitSlotStencil<Q>& st, int j) { return st.valid[j]; }
 template <int Q, bool LIND, int EPT, int EPE>
@@ -1362,7 +1374,7 @@ struct Team {
   static constexpr int EPT = V::EPT;    // slots per thread
   static constexpr int ICPB = V::ICPB;  // initial conditions per workgroup (interleaved in the same threads)
   static constexpr int EPE = EPT / ICPB;  // elements per thread of ONE initial condition
-  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL, V::DENSE>::type ST;
+  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL, V::DENSE, V::PACKED>::type ST;
   ST st;
   Lds L;
   int cur;      // which LDS buffer holds the vector that may be stencil-read

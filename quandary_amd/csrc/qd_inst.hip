@@ -27,7 +27,7 @@ constexpr bool variant_built() {
   // units/s); V3 and V5 (1024-thread blocks: 128 VGPRs are not enough, 8-12x slower than V2 on C5); V8 and
   // V10 (column layout with 4 / 6 columns per wave: 4.0M vs 4.85M units/s of V9 on C4).
   if (kDense) return VAR >= 11 && VAR <= 13;
-  if (!kQubit) return VAR <= 2 || VAR == 4 || (kLind && VAR == 9);
+  if (!kQubit) return VAR <= 2 || VAR == 4 || (kLind && (VAR == 9 || VAR == 14));
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
   return VAR == 2;
@@ -94,6 +94,7 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
     case 11: return FN<11>(__VA_ARGS__);     \
     case 12: return FN<12>(__VA_ARGS__);     \
     case 13: return FN<13>(__VA_ARGS__);     \
+    case 14: return FN<14>(__VA_ARGS__);     \
     default: return hipErrorInvalidValue;    \
   }
 

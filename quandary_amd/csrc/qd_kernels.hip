@@ -238,10 +238,10 @@ __global__ void k_gmat(const DevSys S, const double* __restrict__ g0, const doub
 // regime): more elements per thread so that several workgroups share a CU.
 constexpr int QD_COL_DEFAULT = 9;
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
-  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2, 4, 8, 6, 1, 1, 4}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1};
-  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640, 64, 256, 256};
-  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true, true, true, true, false, true, true};
-  static const bool colv[NVARIANTS] = {false, false, false, false, false, false, false, false, true, true, true, false, false, false};
+  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2, 4, 8, 6, 1, 1, 4, 4}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1};
+  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640, 64, 256, 256, 256};
+  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true, true, true, true, false, true, true, true};
+  static const bool colv[NVARIANTS] = {false, false, false, false, false, false, false, false, true, true, true, false, false, false, true};
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
@@ -250,20 +250,25 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   c.qubit = S.dense ? 2 : qubit ? 1 : 0;
   const bool gm = want_gmres && !getenv("QD_FORCE_NEUMANN");
   // column layout (V8/V9): one wave per column of rho, N <= 64 lanes used
-  auto colblock = [&](int v) { return 64 * ((S.N + ept[v] - 1) / ept[v]); };
+  // V14 packs floor(64 / N) columns into one wave slot
+  auto colblock = [&](int v) {
+    const int cpw = (v == 14 && S.N <= 64) ? 64 / S.N : 1, slots = (S.N + cpw - 1) / cpw;
+    return 64 * ((slots + ept[v] - 1) / ept[v]);
+  };
   auto fits = [&](int v) {
+    if (v == 14 && S.N > 32) return false;
     if (colv[v]) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= maxb[v] && lds_bytes(S, colblock(v), true, false, 2, 1, true) <= 160 * 1024;
     return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v];
   };
   auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
     if (S.dense) return v >= 11 && v <= 13;
-    if (!qubit) return v <= 2 || v == 4 || (S.lindblad && v == 9);
+    if (!qubit) return v <= 2 || v == 4 || (S.lindblad && (v == 9 || v == 14));
     return dim <= 64 ? v == 0 : dim <= 256 ? v == 1 : v == 2;
   };
   int var;
   if (dim <= 64) var = 0;
   else if (dim <= 256) var = 1;
-  else if (dim <= 1024) var = 2;
+  else if (dim <= 1024) var = fits(14) ? 14 : 2;  // packed column layout for non-qubit Lindblad (3x3x3: 18.7M vs 12.4M units/s)
   // column layout when most of its 64 lanes (= rows) are used; measured: N = 36 V4 8.6M vs V9 7.2M units/s,
   // N = 49 4.3M vs 6.7M, N = 64 3.3M vs 5.2M
   else var = (fits(QD_COL_DEFAULT) && S.N >= 44) ? QD_COL_DEFAULT : 4;

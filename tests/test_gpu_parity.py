@@ -84,11 +84,16 @@ def test_objective_and_gradient_vs_oracle(kw, penalties):
     opt.close(); h.close(); orc.close()
 
 
-@pytest.mark.parametrize("var", ["9"])
-@pytest.mark.parametrize("kw", [SHAPES[3], SHAPES[5], SHAPES[7]])
+COL_SHAPES = [SHAPES[3], SHAPES[5], SHAPES[7],
+              pytest.param(dict(nlevels=[3, 3, 3], lindblad=True, nessential=[2, 3, 2], jkl=0.004, detuned=True, init="diagonal, 1"), id="3x3x3-lindblad")]
+
+
+@pytest.mark.parametrize("var", ["9", "14"])
+@pytest.mark.parametrize("kw", COL_SHAPES)
 def test_column_layout_variants(kw, var, monkeypatch):
-    """Column-per-wave kernel (V9, the default for Lindblad systems with dim > 1024) on the 3x20 system and
-    forced onto a small system with dipole-dipole coupling and one with guard levels."""
+    """Column-per-wave kernels: V9 (the default for Lindblad systems with N >= 44) on the 3x20 system and forced
+    onto small systems with dipole-dipole coupling / guard levels; V14 (several columns per wave, N <= 32; not
+    applicable to 3x20, which then runs its default)."""
     monkeypatch.setenv("QD_VAR", var)
     if kw["nlevels"] == [3, 20]:
         kw = {**kw, "init": "basis, 0"}
