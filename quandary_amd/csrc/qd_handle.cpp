@@ -409,8 +409,7 @@ extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, doubl
 }
 
 static int check_cfg(const LaunchCfg& cfg) {
-  static const int maxb[15] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640, 64, 256, 256, 256};
-  if (cfg.var < 0 || cfg.var > 14 || cfg.block > maxb[cfg.var])
+  if (variant_max_block(cfg.var) <= 0 || cfg.block > variant_max_block(cfg.var))
     return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
   if (cfg.lds > 160 * 1024) return fail(QD_ERR_UNSUPPORTED, "state does not fit the 160 KiB LDS of one CU");
   return QD_OK;

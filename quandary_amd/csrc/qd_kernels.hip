@@ -237,11 +237,22 @@ __global__ void k_gmat(const DevSys S, const double* __restrict__ g0, const doub
 // spread one state over as many lanes as it has elements.  Many initial conditions (throughput
 // regime): more elements per thread so that several workgroups share a CU.
 constexpr int QD_COL_DEFAULT = 9;
+
+// host-side view of the kernel variants, generated from the Variant<> traits of qd_device.h
+struct VarInfo {
+  int ept, icpb, maxb;
+  bool dbuf, col;
+};
+template <int V>
+constexpr VarInfo var_info() {
+  return {Variant<V>::EPT, Variant<V>::ICPB, Variant<V>::MAXB, Variant<V>::DBUF, Variant<V>::COL};
+}
+static const VarInfo kVar[NVARIANTS] = {var_info<0>(), var_info<1>(), var_info<2>(),  var_info<3>(),  var_info<4>(),
+                                        var_info<5>(), var_info<6>(), var_info<7>(),  var_info<8>(),  var_info<9>(),
+                                        var_info<10>(), var_info<11>(), var_info<12>(), var_info<13>(), var_info<14>()};
+int variant_max_block(int var) { return (var >= 0 && var < NVARIANTS) ? kVar[var].maxb : 0; }
+
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
-  static const int ept[NVARIANTS] = {1, 1, 4, 4, 8, 1, 2, 2, 4, 8, 6, 1, 1, 4, 4}, icpb[NVARIANTS] = {1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1};
-  static const int maxb[NVARIANTS] = {64, 256, 256, 1024, 512, 1024, 64, 256, 1024, 512, 640, 64, 256, 256, 256};
-  static const bool dbuf[NVARIANTS] = {false, true, true, false, false, true, false, true, true, true, true, false, true, true, true};
-  static const bool colv[NVARIANTS] = {false, false, false, false, false, false, false, false, true, true, true, false, false, false, true};
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
@@ -253,12 +264,12 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
   // V14 packs floor(64 / N) columns into one wave slot
   auto colblock = [&](int v) {
     const int cpw = (v == 14 && S.N <= 64) ? 64 / S.N : 1, slots = (S.N + cpw - 1) / cpw;
-    return 64 * ((slots + ept[v] - 1) / ept[v]);
+    return 64 * ((slots + kVar[v].ept - 1) / kVar[v].ept);
   };
   auto fits = [&](int v) {
     if (v == 14 && S.N > 32) return false;
-    if (colv[v]) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= maxb[v] && lds_bytes(S, colblock(v), true, false, 2, 1, true) <= 160 * 1024;
-    return (dim + (ept[v] / icpb[v]) - 1) / (ept[v] / icpb[v]) <= maxb[v];
+    if (kVar[v].col) return S.lindblad && !qubit && S.N <= 64 && colblock(v) <= kVar[v].maxb && lds_bytes(S, colblock(v), true, false, 2, 1, true) <= 160 * 1024;
+    return (dim + (kVar[v].ept / kVar[v].icpb) - 1) / (kVar[v].ept / kVar[v].icpb) <= kVar[v].maxb;
   };
   auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
     if (S.dense) return v >= 11 && v <= 13;
@@ -277,20 +288,20 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres) {
     const int v = atoi(ev);
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
   }
-  const int epe = ept[var] / icpb[var];
+  const int epe = kVar[var].ept / kVar[var].icpb;
   c.var = var;
-  c.block = colv[var] ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
+  c.block = kVar[var].col ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
   c.gmres = 0;
   const bool dn = S.dense == 2;  // G(t) staged in LDS
-  c.lds = lds_bytes(S, c.block, dbuf[var], false, 0, icpb[var], colv[var], dn);
-  if (gm && icpb[var] == 1) {
-    const size_t in_lds = lds_bytes(S, c.block, dbuf[var], false, 1, icpb[var], colv[var], dn);
-    if (ept[var] == 1 && in_lds <= 160 * 1024) {  // Krylov basis in LDS
+  c.lds = lds_bytes(S, c.block, kVar[var].dbuf, false, 0, kVar[var].icpb, kVar[var].col, dn);
+  if (gm && kVar[var].icpb == 1) {
+    const size_t in_lds = lds_bytes(S, c.block, kVar[var].dbuf, false, 1, kVar[var].icpb, kVar[var].col, dn);
+    if (kVar[var].ept == 1 && in_lds <= 160 * 1024) {  // Krylov basis in LDS
       c.gmres = 1;
       c.lds = in_lds;
     } else {  // Krylov basis in global memory
       c.gmres = 2;
-      c.lds = lds_bytes(S, c.block, dbuf[var], false, 2, icpb[var], colv[var], dn);
+      c.lds = lds_bytes(S, c.block, kVar[var].dbuf, false, 2, kVar[var].icpb, kVar[var].col, dn);
     }
   }
   return c;
