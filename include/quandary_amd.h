@@ -38,8 +38,19 @@
  * vec index = row + col*N, src/util.cpp:150-152); oscillator 0 is the slowest
  * index inside a Hilbert-space index.  A batch is nb states back to back.
  *
+ *   qd_set_hamiltonian          HamiltonianFileReader + initSparseMatSolver + applyRHS_sparsemat
+ *                               (src/hamiltonianfilereader.cpp, src/mastereq.cpp:192-967) for
+ *                               user-supplied Hamiltonians
+ *
  * Units follow the reference config file: frequencies in GHz (multiplied by
  * 2*pi inside, src/mastereq.cpp:29-37, src/oscillator.cpp:15-21), times in ns.
+ *
+ * Supported sizes (QD_ERR_UNSUPPORTED beyond): state dimension dim <= 4096 (one
+ * workgroup owns one initial condition); Lindblad 1..5 oscillators (like the
+ * reference's matrix-free templates), Schroedinger 1..8; at most 256 / 64 / 32 / 16
+ * levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied
+ * Hamiltonians dim <= 1024.  Control segments: "spline", "spline0" (the reference's
+ * "step" and "spline_amplitude" are rejected).  There is no CPU fallback.
  */
 #ifndef QUANDARY_AMD_H
 #define QUANDARY_AMD_H
