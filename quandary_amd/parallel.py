@@ -19,15 +19,20 @@ class DistributedObjective:
         self.scale = 1.0 / replicas
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.device = device
+        self._bufs = {}  # persistent device tensors for the two tiny collectives (no allocation per evaluation)
 
     def _allreduce(self, arr):
         if self.dist is None:
             return arr
         import torch
 
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+        src = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        t = self._bufs.get(src.numel())
+        if t is None:
+            t = self._bufs[src.numel()] = torch.empty(src.numel(), dtype=torch.float64, device=self.device)
+        t.copy_(src.reshape(-1))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy() * self.scale
+        return t.cpu().numpy().reshape(np.shape(arr)) * self.scale
 
     def evalF(self, alpha):
         sums = self._allreduce(self.b.forward_local(alpha, False))
