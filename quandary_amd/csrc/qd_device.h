@@ -128,9 +128,19 @@ __device__ __forceinline__ double2 lane_shift(double2 v) {
   return make_double2(lane_shift<UP>(v.x), lane_shift<UP>(v.y));
 }
 
+// Workgroup-wide synchronisation of the LDS exchange vector.  A single-wave workgroup needs no s_barrier
+// (its LDS operations complete in order), but the COMPILER still needs the fence: lanes communicate through
+// LDS, and without it a load of element it ^ m may legally be hoisted above this lane's store of element
+// `it` (different addresses from one thread's point of view) - observed as loop-invariant neighbour values
+// in the Neumann loop of the 2x2 Schroedinger system.
 template <bool ONEWAVE>
 __device__ __forceinline__ void team_sync() {
-  if (!ONEWAVE) __syncthreads();
+  if (!ONEWAVE) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // Block-wide sum of NV values; every thread returns the same bits, so decisions taken on the result
@@ -634,7 +644,7 @@ struct QubitStencil {
   //   A = (U1 - D1) + (U2 - D2) = s_b x_b + s_k x_k,  B = (U1 + D1) - (U2 + D2) = x_b - x_k
   __device__ __forceinline__ void ladder(const DevSys&, const Lds&, const double2* __restrict__ sx, int k, int j, double2& A,
                                          double2& B) const {
-    const int i0 = opaque(it[j]);
+    const int i0 = HOIST ? it[j] : opaque(it[j]);  // one element per thread: neighbour addresses may live in registers
     const unsigned a = (i0 >> (Q - 1 - k)) & 1;
     const double2 xb = sx[i0 ^ (1 << (Q - 1 - k))];
     A.x = flip_if(xb.x, a);
@@ -653,7 +663,7 @@ struct QubitStencil {
   template <bool TRANS>
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
                                            const double2 xs) const {
-    const int i0 = opaque(it[j]);
+    const int i0 = HOIST ? it[j] : opaque(it[j]);  // one element per thread: neighbour addresses may live in registers
     // all neighbour reads first (one LDS latency per application)
     double2 xb[Q], xk[Q], xl[Q];
 #pragma unroll
@@ -687,7 +697,8 @@ struct QubitStencil {
         double tr = fma(sqk, xk[k].x, sqb * xb[k].x), ti = fma(sqk, xk[k].y, sqb * xb[k].y);
         tr = fma(c.p[k], xb[k].y - xk[k].y, tr);
         ti = fma(-c.p[k], xb[k].x - xk[k].x, ti);
-        if (k & 1) { gr += tr; gi += ti; }
+        if (k == 1) { gr = tr; gi = ti; }  // (no "+= 0.0": fp64 adds are not folded)
+        else if (k & 1) { gr += tr; gi += ti; }
         else { hr += tr; hi += ti; }
       }
     }
