@@ -358,6 +358,10 @@ struct GenStencil {
   double dw[EPT];      // Delta = h(I) - h(I')   (mastereq.hpp:316-403)
   double dd[EPT];      // d = L2 + L1diag         (mastereq.hpp:339-353, :416-433)
   int ofs[Q];          // start of oscillator k in the coefficient tables
+  // latency regime (one element per thread): ladder coefficients of THE element kept in registers instead
+  // of four table reads per oscillator and operator application
+  static constexpr bool HOIST = (EPE == 1);
+  double hsu[HOIST ? Q : 1], hsd[HOIST ? Q : 1], hsup[HOIST ? Q : 1], hsdp[HOIST ? Q : 1];
 
   __device__ __forceinline__ static int dig(unsigned d, int k) { return (int)((d >> (DB * k)) & ((1u << DB) - 1u)); }
 
@@ -409,6 +413,15 @@ struct GenStencil {
       }
       dw[j] = hd - hdp;
       dd[j] = d;
+      if (HOIST && j == 0) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+          hsu[k] = (ia[k] < S.n[k] - 1) ? sqrt((double)(ia[k] + 1)) : 0.0;
+          hsd[k] = sqrt((double)ia[k]);
+          hsup[k] = (LIND && ipa[k] < S.n[k] - 1) ? sqrt((double)(ipa[k] + 1)) : 0.0;
+          hsdp[k] = LIND ? sqrt((double)ipa[k]) : 0.0;
+        }
+      }
     }
   }
 
@@ -451,8 +464,8 @@ struct GenStencil {
   template <bool TRANS>
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
                                            const double2 xs) const {
-    const int i0 = opaque(it[j]), top = S.dim - 1;
-    const unsigned db = opaque(dbra[j]), dk = opaque(dket[j]);
+    const int i0 = HOIST ? it[j] : opaque(it[j]), top = S.dim - 1;
+    const unsigned db = HOIST ? dbra[j] : opaque(dbra[j]), dk = HOIST ? dket[j] : opaque(dket[j]);
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
     double l1r = 0.0, l1i = 0.0;  // T1 off-diagonal contribution
     if (EPE == 1) {
@@ -461,15 +474,15 @@ struct GenStencil {
       double su[Q], sd[Q], sup[Q], sdp[Q];
 #pragma unroll
       for (int k = 0; k < Q; k++) {
-        const int a = dig(db, k), st = S.post[k];
-        su[k] = L.tup[ofs[k] + a];
-        sd[k] = L.tdn[ofs[k] + a];
+        const int st = S.post[k];
+        su[k] = hsu[k];
+        sd[k] = hsd[k];
         xu[k] = sx[min(i0 + st, top)];
         xd[k] = sx[max(i0 - st, 0)];
         if (LIND) {
-          const int ap = dig(dk, k), stp = S.N * st;
-          sup[k] = L.tup[ofs[k] + ap];
-          sdp[k] = L.tdn[ofs[k] + ap];
+          const int stp = S.N * st;
+          sup[k] = hsup[k];
+          sdp[k] = hsdp[k];
           xup[k] = sx[min(i0 + stp, top)];
           xdp[k] = sx[max(i0 - stp, 0)];
           xl[k] = sx[TRANS ? max(i0 - st - stp, 0) : min(i0 + st + stp, top)];
