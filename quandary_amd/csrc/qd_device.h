@@ -38,10 +38,11 @@ namespace qd {
 // DENSE  user-supplied dense Hamiltonians (DenseStencil) instead of the matrix-free stencil
 // PACKED several columns per wave in the column layout (N <= 32)
 template <int EPT_, int MAXB_, bool DBUF_, bool ONEWAVE_, int ICPB_ = 1, bool COL_ = false, bool LEAN_ = false, bool DENSE_ = false,
-          bool PACKED_ = false>
+          bool PACKED_ = false, bool MFMA_ = false>
 struct VariantDef {
   static constexpr int EPT = EPT_, MAXB = MAXB_, ICPB = ICPB_, FENCE = 1;
   static constexpr bool DBUF = DBUF_, ONEWAVE = ONEWAVE_, BLDS = false, COL = COL_, LEAN = LEAN_, DENSE = DENSE_, PACKED = PACKED_;
+  static constexpr bool MFMA = MFMA_;  // dense operator on the matrix cores (v_mfma_f64_16x16x4_f64)
 };
 template <int VAR> struct Variant;
 template <> struct Variant<0> : VariantDef<1, 64, false, true> {};     // dim <= 64: one wave, no barriers
@@ -67,7 +68,10 @@ template <> struct Variant<12> : VariantDef<1, 256, true, false, 1, false, false
 template <> struct Variant<13> : VariantDef<4, 256, true, false, 1, false, false, true> {};
 // V14: packed column layout for 17 <= N <= 32 (256 < dim <= 1024, non-qubit Lindblad): floor(64/N) columns per wave slot
 template <> struct Variant<14> : VariantDef<4, 256, true, false, 1, true, true, false, true> {};
-constexpr int NVARIANTS = 15;
+// V15: dense operator of a 16 x 16 density matrix (dim 256) as complex 16x16x16 products on the fp64 matrix cores:
+// one wave per initial condition, the state lives in the MFMA accumulator layout
+template <> struct Variant<15> : VariantDef<4, 64, false, true, 1, false, false, true, false, true> {};
+constexpr int NVARIANTS = 16;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 
@@ -349,6 +353,7 @@ constexpr int packed_digit_bits(int q) { return q <= 4 ? 8 : q == 5 ? 6 : q == 6
 // ---------------------------------------------------------------------------------------------
 template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct GenStencil {
+  static constexpr bool WHOLE = false;  // apply() works one slot at a time
   static constexpr bool NEEDS_SLOTS = false;  // apply() reads every neighbour from LDS
   static constexpr int DB = packed_digit_bits(Q);  // bits per packed digit
   int it[EPT];         // storage index (clamped to dim-1 for slots beyond the vector)
@@ -595,6 +600,7 @@ __device__ __forceinline__ double flip_if(double v, unsigned cond) {  // cond ? 
 
 template <int Q, bool LIND, int EPT, int EPE = EPT>
 struct QubitStencil {
+  static constexpr bool WHOLE = false;
   static constexpr bool NEEDS_SLOTS = false;
   int it[EPT];
   bool valid[EPT];  // only the single-wave variant can have idle lanes (dim < 64)
@@ -783,6 +789,7 @@ struct QubitStencil {
 // and only the bra neighbours of the stride-1 oscillator still come from registers (adjacent lanes).
 template <int Q, int EPT, bool PACKED = false>
 struct ColStencil {
+  static constexpr bool WHOLE = false;
   static constexpr bool NEEDS_SLOTS = true;  // apply() takes the thread's other elements of the vector being read
   static constexpr int DB = packed_digit_bits(Q);
   int it[EPT];
@@ -982,6 +989,7 @@ struct ColStencil {
 template <int Q>
 struct QubitSlotStencil {
   static_assert(Q >= 2, "needs two oscillators for the slot bits");
+  static constexpr bool WHOLE = false;
   static constexpr bool NEEDS_SLOTS = true;
   static constexpr int EPT = 4;
   static constexpr int TB = 2 * Q - 2;                 // number of thread bits
@@ -1234,16 +1242,122 @@ struct DenseStencil : GenStencil<Q, LIND, EPT, EPE> {
   }
 };
 
-template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false, bool DENSE = false, bool PACKED = false>
+
+// ---------------------------------------------------------------------------------------------
+// dense operator on the matrix cores, N = 16 Lindblad (dim 256): one wave owns rho in the accumulator
+// layout of v_mfma_f64_16x16x4_f64 (slot r of lane l = row (l >> 4) + 4 r, column l & 15), which is at
+// the same time the B-operand layout of the four K-slabs.  Per application
+//   Y = G rho - rho G   = 2 complex 16x16x16 products = 32 MFMA instructions
+// with G (A operand of the first, B operand of the second product) held in registers for the whole
+// sub-step and rho as A operand read transposed from the published LDS vector (4 reads per lane);
+// the transposed real operator swaps the two register sets and conjugates them (G -> G^H).
+// Dissipators and the gradient contraction are inherited from DenseStencil.
+// ---------------------------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <int Q>
+struct DenseMfmaStencil : DenseStencil<Q, true, 4, 4> {
+  typedef DenseStencil<Q, true, 4, 4> Base;
+  static constexpr bool WHOLE = true;  // apply_whole() computes all four slots at once
+  static constexpr int N = 16, EPT = 4;
+  using Base::dbra;
+  using Base::dd;
+  using Base::dig;
+  using Base::dket;
+  using Base::it;
+  using Base::ofs;
+  using Base::valid;
+  double2 gA[4];  // G[l & 15][4 s + (l >> 4)]
+  double2 gB[4];  // G[4 s + (l >> 4)][l & 15]
+  double l1f[EPT][Q], l1t[EPT][Q];  // T1 off-diagonal coefficients of the four elements (one wave per SIMD: registers are plentiful)
+
+  __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
+    Base::init(S, L);  // tables, then re-map the slots onto the accumulator layout
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int I = (lane >> 4) + 4 * j, Ip = lane & 15;
+      it[j] = Ip * N + I;
+      valid[j] = true;
+      int ia[Q], ipa[Q];
+      dbra[j] = 0;
+      dket[j] = 0;
+      double d = 0.0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        ia[k] = (I / S.post[k]) % S.n[k];
+        ipa[k] = (Ip / S.post[k]) % S.n[k];
+        dbra[j] |= (unsigned)ia[k] << (Base::DB * k);
+        dket[j] |= (unsigned)ipa[k] << (Base::DB * k);
+        d += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
+        const bool up = ia[k] < S.n[k] - 1 && ipa[k] < S.n[k] - 1;
+        l1f[j][k] = up ? S.g1off[k] * sqrt((double)(ia[k] + 1)) * sqrt((double)(ipa[k] + 1)) : 0.0;
+        l1t[j][k] = S.g1off[k] * sqrt((double)ia[k]) * sqrt((double)ipa[k]);
+      }
+      dd[j] = d;
+    }
+  }
+
+  __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>& c) {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      gA[s] = c.g[lo * N + 4 * s + hi];
+      gB[s] = c.g[(4 * s + hi) * N + lo];
+    }
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ void apply_whole(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>&,
+                                              const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    mfma_d4 ar = {0.0, 0.0, 0.0, 0.0}, ai = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      // first product: Gt rho, Gt = G (A operand gA) or G^H (A operand conj(gB))
+      const double gr = TRANS ? gB[s].x : gA[s].x, gi = TRANS ? -gB[s].y : gA[s].y;
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(gr, x[s].x, ar, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-gi, x[s].y, ar, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(gr, x[s].y, ai, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(gi, x[s].x, ai, 0, 0, 0);
+      // second product: - rho Gt, rho as A operand (row lo, column 4 s + hi) from the published vector
+      const double2 pa = sx[(4 * s + hi) * N + lo];
+      const double hr = TRANS ? gA[s].x : gB[s].x, hi2 = TRANS ? -gA[s].y : gB[s].y;
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.x, hr, ar, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, hi2, ar, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.x, hi2, ai, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.y, hr, ai, 0, 0, 0);
+    }
+    const int top = S.dim - 1;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      double yr = fma(dd[j], x[j].x, ar[j]), yi = fma(dd[j], x[j].y, ai[j]);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        if (S.g1off[k] == 0.0) continue;  // wave-uniform
+        const int st = S.post[k] * (N + 1);
+        const double l1 = TRANS ? l1t[j][k] : l1f[j][k];
+        const double2 xn = sx[TRANS ? max(it[j] - st, 0) : min(it[j] + st, top)];
+        yr = fma(l1, xn.x, yr);
+        yi = fma(l1, xn.y, yi);
+      }
+      y[j] = make_double2(yr, yi);
+    }
+  }
+};
+
+template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false, bool DENSE = false, bool PACKED = false, bool MFMA = false>
 struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, bool LIND, int EPT, int EPE>
-struct StencilSel<Q, LIND, EPT, EPE, true, false, false, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
+struct StencilSel<Q, LIND, EPT, EPE, true, false, false, false, false> { typedef QubitStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, int EPT, int EPE, bool PACKED>
-struct StencilSel<Q, true, EPT, EPE, false, true, false, PACKED> { typedef ColStencil<Q, EPT, PACKED> type; };
+struct StencilSel<Q, true, EPT, EPE, false, true, false, PACKED, false> { typedef ColStencil<Q, EPT, PACKED> type; };
 template <int Q>
-struct StencilSel<Q, true, 4, 4, true, false, false, false> { typedef QubitSlotStencil<Q> type; };
+struct StencilSel<Q, true, 4, 4, true, false, false, false, false> { typedef QubitSlotStencil<Q> type; };
 template <int Q, bool LIND, int EPT, int EPE>
-struct StencilSel<Q, LIND, EPT, EPE, false, false, true, false> { typedef DenseStencil<Q, LIND, EPT, EPE> type; };
+struct StencilSel<Q, LIND, EPT, EPE, false, false, true, false, false> { typedef DenseStencil<Q, LIND, EPT, EPE> type; };
+template <int Q>
+struct StencilSel<Q, true, 4, 4, false, false, true, false, true> { typedef DenseMfmaStencil<Q> type; };
 
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
 template <int Q, bool LIND, int EPT, int EPE>
@@ -1256,6 +1370,8 @@ template <int Q>
 __device__ __forceinline__ bool slot_valid(const QubitSlotStencil<Q>& st, int j) { return st.valid[j]; }
 template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const DenseStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
+template <int Q>
+__device__ __forceinline__ bool slot_valid(const DenseMfmaStencil<Q>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)
@@ -1398,7 +1514,7 @@ struct Team {
   static constexpr int EPT = V::EPT;    // slots per thread
   static constexpr int ICPB = V::ICPB;  // initial conditions per workgroup (interleaved in the same threads)
   static constexpr int EPE = EPT / ICPB;  // elements per thread of ONE initial condition
-  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL, V::DENSE, V::PACKED>::type ST;
+  typedef typename StencilSel<Q, LIND, EPT, EPE, QUBIT, V::COL, V::DENSE, V::PACKED, V::MFMA>::type ST;
   ST st;
   Lds L;
   int cur;      // which LDS buffer holds the vector that may be stencil-read
@@ -1468,6 +1584,10 @@ struct Team {
 
   template <bool TRANS, bool HASJ>
   __device__ __forceinline__ void apply_sweep(const DevSys& S, const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+    if constexpr (ST::WHOLE) {
+      st.template apply_whole<TRANS>(S, L, vec(), c, x, y);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x);
@@ -1487,9 +1607,13 @@ struct Team {
     double2 yold[EPT];  // the iterate being read (Jacobi update): y is overwritten slot by slot
 #pragma unroll
     for (int j = 0; j < EPT; j++) yold[j] = y[j];
+    double2 tall[ST::WHOLE ? EPT : 1];
+    if constexpr (ST::WHOLE) st.template apply_whole<TRANS>(A.S, L, src, c, yold, tall);
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const double2 t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, yold);
+      double2 t;
+      if constexpr (ST::WHOLE) t = tall[j];
+      else t = apply_slot<TRANS, HASJ>(A.S, src + icslot(j) * dim, c, j, yold);
       const double2 bj = V::BLDS ? L.bvec[lidx(j)] : b[j];
       double2 w;
       w.x = fma(alpha, t.x, bj.x);

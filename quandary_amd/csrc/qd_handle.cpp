@@ -612,7 +612,7 @@ int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, co
   a.xbarT = dxbarT;
   a.jbar = djbar;
   a.coeff = d_coeff.p;
-  LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+  LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
   a.use_gmres = cfg.gmres;
   if (cfg.gmres == 2) {
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;

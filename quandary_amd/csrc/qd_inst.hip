@@ -26,7 +26,7 @@ constexpr bool variant_built() {
   // class never exceed the number of SIMDs, so one initial condition per wave wins, C2 38.6M vs 26.7M
   // units/s); V3 and V5 (1024-thread blocks: 128 VGPRs are not enough, 8-12x slower than V2 on C5); V8 and
   // V10 (column layout with 4 / 6 columns per wave: 4.0M vs 4.85M units/s of V9 on C4).
-  if (kDense) return VAR >= 11 && VAR <= 13;
+  if (kDense) return (VAR >= 11 && VAR <= 13) || (kLind && VAR == 15);
   if (!kQubit) return VAR <= 2 || VAR == 4 || (kLind && (VAR == 9 || VAR == 14));
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
@@ -95,6 +95,7 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
     case 12: return FN<12>(__VA_ARGS__);     \
     case 13: return FN<13>(__VA_ARGS__);     \
     case 14: return FN<14>(__VA_ARGS__);     \
+    case 15: return FN<15>(__VA_ARGS__);     \
     default: return hipErrorInvalidValue;    \
   }
 

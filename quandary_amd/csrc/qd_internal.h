@@ -109,7 +109,7 @@ hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, co
 hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st);
 hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
-LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false);
+LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false, bool adjoint = false);
 size_t krylov_doubles(const DevSys& S, int nb);
 int variant_max_block(int var);  // 0 for an unknown variant  // size of SweepArgs::kry for LaunchCfg::gmres == 2
 

@@ -199,6 +199,9 @@ DENSE_SHAPES = [
     pytest.param(dict(nlevels=[3, 4], lindblad=True, nessential=[2, 3], target="pure", objective="Jfrobenius"), id="dense-3x4-lindblad-guard"),  # dim 144
     pytest.param(dict(nlevels=[4, 6], lindblad=True, target="pure", objective="Jmeasure", init="diagonal, 0"), id="dense-4x6-lindblad"),  # dim 576, 4 el/thread
     pytest.param(dict(nlevels=[10, 12], lindblad=False, target="pure", objective="Jmeasure", init="pure, 1, 2"), id="dense-120-schroedinger"),
+    # N = 16 Lindblad: the matrix-core kernel (v_mfma_f64_16x16x4_f64)
+    pytest.param(dict(nlevels=[4, 4], lindblad=True, nessential=[3, 3], target="pure", objective="Jfrobenius", init="diagonal, 0"), id="dense-4x4-lindblad-mfma"),
+    pytest.param(dict(nlevels=[2, 2, 2, 2], lindblad=True, init="diagonal, 0, 1"), id="dense-2^4-lindblad-mfma"),
 ]
 
 
