@@ -248,6 +248,55 @@ def test_user_hamiltonian_gradient_vs_finite_differences():
     opt.close(); h.close()
 
 
+def _random_case(seed):
+    """A random small system / objective / solver combination (deterministic in `seed`)."""
+    rng = np.random.default_rng(1000 + seed)
+    lind = bool(rng.integers(0, 2))
+    Q = int(rng.integers(1, 4))
+    cap = 40 if lind else 300  # Hilbert-space dimension cap (oracle time)
+    while True:
+        nl = [int(rng.integers(2, 6)) for _ in range(Q)]
+        if int(np.prod(nl)) <= cap:
+            break
+    ness = [int(rng.integers(max(1, n - 1), n + 1)) for n in nl] if rng.integers(0, 2) else None
+    if ness and int(np.prod(ness)) < 2:
+        ness = None
+    objective = ["Jtrace", "Jfrobenius", "Jmeasure"][int(rng.integers(0, 3))]
+    target = "pure" if objective == "Jmeasure" or rng.integers(0, 2) else "gate"
+    nit = int(np.prod(ness if ness else nl))
+    init = ["basis", "diagonal", "pure, " + ", ".join(["0"] * Q)][int(rng.integers(0, 3))]
+    if init == "basis" and (nit * nit if lind else nit) > 64:
+        init = "diagonal"
+    return dict(nlevels=nl, lindblad=lind, nessential=ness, jkl=float(rng.choice([0.0, 0.003])), detuned=bool(rng.integers(0, 2)),
+                target=target, objective=objective, init=init, ntime=int(rng.integers(6, 16)), nspline=int(rng.integers(4, 9)),
+                linsolve=str(rng.choice(["neumann", "gmres"])), stepper=str(rng.choice(["IMR", "IMR", "IMR4", "EE"])),
+                penalties=bool(rng.integers(0, 2)), dt=float(rng.choice([0.01, 0.02])))
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_configurations_vs_oracle(seed):
+    """Seeded sweep over system shapes (1-3 oscillators, 2-5 levels, guard levels, coupling), objectives, initial
+    conditions, steppers, solvers and penalties: objective parts and gradient of the HIP path against the oracle."""
+    kw = _random_case(seed)
+    sp = synthetic_spec(**kw)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-11), (k, kw)
+    if kw["stepper"] == "EE" and not kw["lindblad"]:
+        # Documented deviation (DESIGN.md section 6): for Schroedinger runs the reference re-computes the primal
+        # backwards with the forward stepper (src/timestepper.cpp:229-231), which is exact for the symmetric IMR
+        # family but O(dt) off for explicit Euler; the HIP path always reads the stored forward states.
+        # (Neither gradient is a consistent discrete gradient: the reference's EE adjoint evaluates M at t_stop,
+        # src/timestepper.cpp:506-520.)  Only the objective parts are compared for this debug stepper.
+        pass
+    else:
+        assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13, kw
+    opt.close(); h.close(); orc.close()
+
+
 def test_forward_states_and_trajectory():
     sp, h, orc = _pair(dict(nlevels=[2, 2, 2], lindblad=True), ntime=30)
     opt = capi.Optim(h, sp)
