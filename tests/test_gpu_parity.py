@@ -297,6 +297,36 @@ def test_random_configurations_vs_oracle(seed):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_user_hamiltonians_vs_oracle(seed):
+    """Seeded sweep of the dense-operator path: random level structures (every third one a 16 x 16 density
+    matrix = the matrix-core kernel), random Hermitian Hsys / Hc_k, objectives, solvers, penalties."""
+    rng = np.random.default_rng(5000 + seed)
+    lind = bool(rng.integers(0, 2)) or seed % 3 == 0
+    if seed % 3 == 0:
+        nl = [[4, 4], [2, 2, 2, 2], [2, 8], [16]][int(rng.integers(0, 4))]
+    else:
+        Q = int(rng.integers(1, 4))
+        while True:
+            nl = [int(rng.integers(2, 6)) for _ in range(Q)]
+            if int(np.prod(nl)) <= (30 if lind else 200):
+                break
+    objective = ["Jtrace", "Jfrobenius", "Jmeasure"][int(rng.integers(0, 3))]
+    kw = dict(nlevels=nl, lindblad=lind, target="pure", objective=objective, init="diagonal" if int(np.prod(nl)) <= 64 else "pure, " + ", ".join(["0"] * len(nl)),
+              ntime=int(rng.integers(6, 14)), nspline=int(rng.integers(4, 8)), linsolve=str(rng.choice(["neumann", "gmres"])),
+              stepper=str(rng.choice(["IMR", "IMR", "IMR4"])), penalties=bool(rng.integers(0, 2)), dt=0.004)
+    sp = synthetic_spec(**kw)
+    sp.hamiltonian = _random_hamiltonians(int(np.prod(nl)), len(nl), 100 + seed)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-11), (k, kw)
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13, kw
+    opt.close(); h.close(); orc.close()
+
+
 def test_forward_states_and_trajectory():
     sp, h, orc = _pair(dict(nlevels=[2, 2, 2], lindblad=True), ntime=30)
     opt = capi.Optim(h, sp)
