@@ -62,14 +62,13 @@ extern "C" void qd_destroy(qd_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
-                  &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_pen, &h->d_dpdm, &h->d_out4,
+                  &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_res,
                   &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
   if (h->d_oscs) (void)hipFree(h->d_oscs);
   if (h->d_carriers) (void)hipFree(h->d_carriers);
   if (h->d_pulses) (void)hipFree(h->d_pulses);
-  if (h->d_napply) (void)hipFree(h->d_napply);
   h->h_etable.release();
   h->h_res.release();
   h->h_params.release();
@@ -220,7 +219,6 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     if ((r = upload(&h->d_oscs, h->oscs))) return r;
     if ((r = upload(&h->d_carriers, h->carriers))) return r;
     if ((r = upload(&h->d_pulses, h->pulses))) return r;
-    QD_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_napply), sizeof(unsigned long long)));
     return QD_OK;
   };
   rc = dev_setup();
@@ -356,7 +354,10 @@ extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
 // instead of Q*ncarrier*nsplines basis evaluations per step and initial condition).
 int qd_handle::refresh_tables() {
   if (!params_dirty) return QD_OK;
-  QD_HIP(launch_controls(dctl, d_params.p, d_sched_t.p, d_sched_h.p, (int)sched_t.size(), d_table.p, cs, stream));
+  // step table + energy-penalty table in one launch; it also resets the RHS-application counter of the sweep
+  QD_HIP(launch_controls2(dctl, d_params.p, d_sched_t.p, d_sched_h.p, (int)sched_t.size(), d_table.p, d_etimes.p, d_ezero.p,
+                          (int)etimes.size(), d_etable.p, cs, d_napply, stream));
+  napply_zeroed = d_napply != nullptr;
   if (S.dense) {  // G(t) = -i H(t) for every table row, shared by all initial conditions
     const size_t nn = (size_t)S.N * S.N;
     int r;
@@ -364,7 +365,6 @@ int qd_handle::refresh_tables() {
     S.gtab = d_gtab.p;
     QD_HIP(launch_gmat(S, d_g0.p, d_table.p, cs, (int)sched_t.size(), d_gtab.p, stream));
   }
-  QD_HIP(launch_controls(dctl, d_params.p, d_etimes.p, d_ezero.p, (int)etimes.size(), d_etable.p, cs, stream));
   // asynchronous: complete at the stream synchronisation that ends the sweep (forward_dev)
   QD_HIP(hipMemcpyAsync(h_etable.p, d_etable.p, sizeof(double) * etimes.size() * cs, hipMemcpyDeviceToHost, stream));
   params_dirty = false;
@@ -509,11 +509,16 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
 int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarget* tgp, double* energy) {
   QD_HIP(hipSetDevice(device));
   int r;
-  if ((r = refresh_tables())) return r;
   if (pen.gamma_penalty > 1e-13 && pen.penalty_param > 1e-13 && !tgp)
     return fail(QD_ERR_STATE, "qd_forward: the weighted-J penalty (optim_penalty_param > 0) needs qd_set_target first");
   const size_t n = (size_t)nb * 2 * S.dim;
-  if ((r = d_xT.ensure(n)) || (r = d_pen.ensure(nb)) || (r = d_dpdm.ensure(nb)) || (r = d_out4.ensure((size_t)4 * nb))) return r;
+  if ((r = d_xT.ensure(n)) || (r = d_res.ensure((size_t)6 * nb + 1))) return r;
+  d_pen = d_res.p;
+  d_dpdm = d_res.p + nb;
+  d_out4 = d_res.p + 2 * (size_t)nb;
+  d_napply = reinterpret_cast<unsigned long long*>(d_res.p + 6 * (size_t)nb);
+  napply_zeroed = false;
+  if ((r = refresh_tables())) return r;
   traj_valid = false;
   if (store) {
     size_t nt;
@@ -525,8 +530,8 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
   a.x0 = dx0;
   a.xT = d_xT.p;
   a.traj = store ? d_traj.p : nullptr;
-  a.pen_out = d_pen.p;
-  a.dpdm_out = d_dpdm.p;
+  a.pen_out = d_pen;
+  a.dpdm_out = d_dpdm;
   a.napply = d_napply;
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
   a.use_gmres = cfg.gmres;
@@ -535,17 +540,14 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
-  QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
+  if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
   QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
-  if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4.p, stream));
+  if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));
   // every result of the sweep in one pinned buffer, one synchronisation
   if ((r = h_res.ensure((size_t)6 * nb + 1))) return r;
-  QD_HIP(hipMemcpyAsync(h_res.p, d_pen.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
-  QD_HIP(hipMemcpyAsync(h_res.p + nb, d_dpdm.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
-  if (tgp) QD_HIP(hipMemcpyAsync(h_res.p + 2 * (size_t)nb, d_out4.p, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost, stream));
-  QD_HIP(hipMemcpyAsync(h_res.p + 6 * (size_t)nb, d_napply, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  QD_HIP(hipMemcpyAsync(h_res.p, d_res.p, sizeof(double) * (6 * (size_t)nb + 1), hipMemcpyDeviceToHost, stream));
   QD_HIP(hipStreamSynchronize(stream));
   unsigned long long nap = 0;
   std::memcpy(&nap, h_res.p + 6 * (size_t)nb, sizeof nap);

@@ -83,6 +83,7 @@ struct qd_handle {
   std::vector<double> params;
   qd::DBuf d_params;
   bool params_dirty = true;
+  bool napply_zeroed = false;  // the control kernel of this parameter update has already reset d_napply
   // step schedule
   int nstages = 1, nsub = 0, cs = 0;
   std::vector<double> sched_t, sched_h, etimes;  // host copies
@@ -96,8 +97,10 @@ struct qd_handle {
   qd::DBuf d_tstates, d_purity;
   int target_nb = 0;
   // sweep buffers
-  qd::DBuf d_x0, d_xT, d_traj, d_pen, d_dpdm, d_out4, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
+  qd::DBuf d_x0, d_xT, d_traj, d_res, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
   qd::DBuf d_g0, d_hcr, d_hci, d_gtab, d_gone;  // dense user-Hamiltonian path (qd_set_hamiltonian)
+  // d_res = [pen nb | dpdm nb | out4 4nb | napply]: one contiguous block, one download per sweep
+  double *d_pen = nullptr, *d_dpdm = nullptr, *d_out4 = nullptr;
   unsigned long long* d_napply = nullptr;
   int last_nb = 0;
   bool traj_valid = false;

@@ -98,6 +98,9 @@ struct LaunchCfg {
 // kernel launch wrappers implemented in qd_kernels.hip; all return hipError_t
 hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
                            double* table, int cs, hipStream_t st);
+hipError_t launch_controls2(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
+                            double* table, const double* times2, const double* hs2, int nrows2, double* table2, int cs,
+                            unsigned long long* zero_me, hipStream_t st);
 hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                         const LaunchCfg& cfg, hipStream_t st);
 hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);

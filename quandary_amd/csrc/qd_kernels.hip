@@ -46,7 +46,11 @@ __device__ inline void eval_control_dev(const DevCtlDesc& d, const double* __res
           double b1 = 0.0, b2 = 0.0;
           const double* cf = coeff + g.skip + f * g.nsplines * 2;
           if (g.type == QD_CTRL_BSPLINE) {
-            for (int l = 0; l < g.nsplines; l++) {
+            // only the splines whose support can contain t (the reference loops over all of them, the others
+            // contribute exact zeros: controlbasis.cpp:48-66, :81-96); one spline of margin on each side
+            const int lc = (int)floor((t - g.tstart) / g.dtknot);
+            const int l0 = max(0, lc - 1), l1 = min(g.nsplines - 1, lc + 3);
+            for (int l = l0; l <= l1; l++) {
               if (d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) continue;
               const double B = bspline2(g, l, t);
               b1 += cf[l] * B;
@@ -79,11 +83,23 @@ __device__ inline void eval_control_dev(const DevCtlDesc& d, const double* __res
   }
 }
 
+// Two row sets in one launch (step table + energy-penalty table of one parameter update); `zero_me`
+// (optional) is the RHS-application counter of the sweep that follows.
 __global__ void k_controls(const DevCtlDesc d, const double* __restrict__ params, const double* __restrict__ times,
-                           const double* __restrict__ hs, int nrows, double* __restrict__ table, int cs) {
+                           const double* __restrict__ hs, int nrows, double* __restrict__ table, const double* __restrict__ times2,
+                           const double* __restrict__ hs2, int nrows2, double* __restrict__ table2, int cs,
+                           unsigned long long* __restrict__ zero_me) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int row = idx / d.Q, k = idx % d.Q;
-  if (row >= nrows) return;
+  if (idx == 0 && zero_me) *zero_me = 0ull;
+  int row = idx / d.Q;
+  const int k = idx % d.Q;
+  if (row >= nrows + nrows2) return;
+  if (row >= nrows) {  // second set
+    row -= nrows;
+    times = times2;
+    hs = hs2;
+    table = table2;
+  }
   const double t = times[row];
   double p, q;
   eval_control_dev(d, params, k, t, p, q);
@@ -358,9 +374,16 @@ hipError_t launch_apply(const DevSys& S, const double* ctlrow, int transpose, co
 
 hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
                            double* table, int cs, hipStream_t st) {
-  const int total = nrows * d.Q;
-  if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_controls, dim3((total + 127) / 128), dim3(128), 0, st, d, params, times, hs, nrows, table, cs);
+  return launch_controls2(d, params, times, hs, nrows, table, nullptr, nullptr, 0, nullptr, cs, nullptr, st);
+}
+
+hipError_t launch_controls2(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
+                            double* table, const double* times2, const double* hs2, int nrows2, double* table2, int cs,
+                            unsigned long long* zero_me, hipStream_t st) {
+  const int total = (nrows + nrows2) * d.Q;
+  if (total == 0 && !zero_me) return hipSuccess;
+  hipLaunchKernelGGL(k_controls, dim3((total > 0 ? total + 127 : 128) / 128), dim3(128), 0, st, d, params, times, hs, nrows, table,
+                     times2, hs2, nrows2, table2, cs, zero_me);
   return hipGetLastError();
 }
 
