@@ -679,20 +679,39 @@ struct QubitStencil {
     }
   }
 
+  // The neighbour reads and the arithmetic are separate entry points: the single-wave solver issues the reads
+  // of the NEXT iteration before it reduces the update norm of the current one (Team::neumann).
+  static constexpr bool SPLIT_FETCH = true;
+  struct Nbrs {
+    double2 xb[Q], xk[Q], xl[Q];  // (the ket / T1 sets are unused and eliminated for Schroedinger)
+  };
+  __device__ __forceinline__ void fetch(const double2* __restrict__ sx, int j, Nbrs& n) const {
+    const int i0 = HOIST ? it[j] : opaque(it[j]);  // one element per thread: neighbour addresses may live in registers
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      n.xb[k] = sx[i0 ^ (1 << (Q - 1 - k))];
+      if (LIND) {
+        n.xk[k] = sx[i0 ^ (1 << (2 * Q - 1 - k))];
+        n.xl[k] = sx[i0 ^ ((1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k)))];
+      }
+    }
+  }
+
   template <bool TRANS>
   __device__ __forceinline__ double2 apply(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
                                            const double2 xs) const {
-    const int i0 = HOIST ? it[j] : opaque(it[j]);  // one element per thread: neighbour addresses may live in registers
-    // all neighbour reads first (one LDS latency per application)
-    double2 xb[Q], xk[Q], xl[Q];
-#pragma unroll
-    for (int k = 0; k < Q; k++) {
-      xb[k] = sx[i0 ^ (1 << (Q - 1 - k))];
-      if (LIND) {
-        xk[k] = sx[i0 ^ (1 << (2 * Q - 1 - k))];
-        xl[k] = sx[i0 ^ ((1 << (Q - 1 - k)) | (1 << (2 * Q - 1 - k)))];
-      }
-    }
+    Nbrs n;
+    fetch(sx, j, n);  // all neighbour reads first (one LDS latency per application)
+    return apply_nb<TRANS>(S, sx, c, j, xs, n);
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply_nb(const DevSys& S, const double2* __restrict__ sx, const StepC<Q>& c, int j, const double2 xs,
+                                              const Nbrs& n) const {
+    const int i0 = HOIST ? it[j] : opaque(it[j]);
+    const double2* xb = n.xb;
+    const double2* xk = n.xk;
+    const double2* xl = n.xl;
     // control part with the digit signs folded into q:  q A.x + p B.y = (+-q) xb.x + (+-q) xk.x + p (xb.y - xk.y);
     // two accumulator pairs shorten the dependent fp64 chain (the small-system kernels are latency bound)
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0.0, gi = 0.0;
@@ -1359,6 +1378,9 @@ struct StencilSel<Q, LIND, EPT, EPE, false, false, true, false, false> { typedef
 template <int Q>
 struct StencilSel<Q, true, 4, 4, false, false, true, false, true> { typedef DenseMfmaStencil<Q> type; };
 
+template <typename ST, typename = void> struct has_split_fetch { static constexpr bool value = false; };
+template <typename ST> struct has_split_fetch<ST, decltype((void)ST::SPLIT_FETCH)> { static constexpr bool value = ST::SPLIT_FETCH; };
+
 template <typename ST> __device__ __forceinline__ bool slot_valid(const ST& st, int j);
 template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const GenStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
@@ -1647,6 +1669,30 @@ struct Team {
     const float rel2 = (float)(A.reltol * A.reltol);
     float d0 = 1.f;
     int iter;
+    if constexpr (V::ONEWAVE && !V::DBUF && EPT == 1 && ICPB == 1 && has_split_fetch<ST>::value) {
+      // Single wave, one element per lane (the latency-bound small systems): software-pipelined iteration.  The
+      // neighbour reads of iteration m+1 are issued right after y_{m+1} has been written to LDS and are in flight
+      // while the update norm of iteration m is reduced and tested (readlane -> scalar compare -> branch).
+      typename ST::Nbrs nb;
+      st.fetch(vec(), 0, nb);
+      for (iter = 0; iter < A.maxiter; iter++) {
+        const double2 t = st.template apply_nb<TRANS>(A.S, vec(), c, 0, y[0], nb);
+        double2 w;
+        w.x = fma(alpha, t.x, b[0].x);
+        w.y = fma(alpha, t.y, b[0].y);
+        const double dx = y[0].x - w.x, dy = y[0].y - w.y;
+        const double dl = ok(0) ? dx * dx + dy * dy : 0.0;
+        y[0] = w;
+        if (ok(0)) bufp(cur)[lidx(0)] = w;
+        team_sync<true>();
+        st.fetch(vec(), 0, nb);
+        const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));
+        if (iter == 0) d0 = d;
+        if (d < 1.f) { iter++; break; }
+        if (d < rel2 * d0) { iter++; break; }
+      }
+      return iter;
+    }
     for (iter = 0; iter < A.maxiter; iter++) {
       double dloc[ICPB];
 #pragma unroll
