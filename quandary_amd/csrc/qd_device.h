@@ -1757,7 +1757,8 @@ struct Team {
       const double beta = sqrt(t[0]);
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) break;
-      double2 v = make_double2(r.x / beta, r.y / beta);
+      const double ibeta = 1.0 / beta;  // one reciprocal instead of two fp64 divisions
+      double2 v = make_double2(r.x * ibeta, r.y * ibeta);
       if (on) Vb[e] = v;
       double gcur = beta;  // last entry of the rotated right-hand side
       team_sync<V::ONEWAVE>();
@@ -1792,7 +1793,8 @@ struct Team {
         sum<1>(nn);
         const double hn = sqrt(nn[0]);
         hc[j + 1] = hn;
-        v = hn > 0.0 ? make_double2(w.x / hn, w.y / hn) : make_double2(0.0, 0.0);
+        const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
+        v = make_double2(w.x * ihn, w.y * ihn);
         if (on) Vb[(size_t)(j + 1) * dim + e] = v;
         // Givens rotations on the new column, update of the rotated right-hand side.  Every thread does
         // this redundantly on wave-uniform values; LDS locations are only ever written with values that
@@ -1806,7 +1808,8 @@ struct Team {
         }
         const double a = cur_h, bb = hn;
         const double rr = sqrt(a * a + bb * bb);
-        const double cj = rr == 0.0 ? 1.0 : a / rr, sj = rr == 0.0 ? 0.0 : bb / rr;
+        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
+        const double cj = rr == 0.0 ? 1.0 : a * irr, sj = bb * irr;
         cs[j] = cj;
         sn[j] = sj;
         R[j * GMRES_MR + j] = rr;
@@ -1874,9 +1877,10 @@ struct Team {
       const double beta = sqrt(t1[0]);
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) break;
+      const double ibeta = 1.0 / beta;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        v[j] = make_double2(r[j].x / beta, r[j].y / beta);
+        v[j] = make_double2(r[j].x * ibeta, r[j].y * ibeta);
         if (ok(j)) Vg[at_use<EPE>(st.it[j])] = v[j];
       }
       publish(v);
@@ -1924,9 +1928,10 @@ struct Team {
         sum<1>(nn);
         const double hn = sqrt(nn[0]);
         hc[jj + 1] = hn;
+        const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
-          v[j] = hn > 0.0 ? make_double2(w[j].x / hn, w[j].y / hn) : make_double2(0.0, 0.0);
+          v[j] = make_double2(w[j].x * ihn, w[j].y * ihn);
           if (ok(j)) Vg[(size_t)(jj + 1) * dim + at_use<EPE>(st.it[j])] = v[j];
         }
         // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
@@ -1938,7 +1943,8 @@ struct Team {
         }
         const double a0 = cur_h, bb = hn;
         const double rr = sqrt(a0 * a0 + bb * bb);
-        const double cj = rr == 0.0 ? 1.0 : a0 / rr, sj = rr == 0.0 ? 0.0 : bb / rr;
+        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
+        const double cj = rr == 0.0 ? 1.0 : a0 * irr, sj = bb * irr;
         cs[jj] = cj;
         sn[jj] = sj;
         R[jj * GMRES_MR_G + jj] = rr;
