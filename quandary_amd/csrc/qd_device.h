@@ -365,8 +365,11 @@ struct GenStencil {
   int ofs[Q];          // start of oscillator k in the coefficient tables
   // latency regime (one element per thread): ladder coefficients of THE element kept in registers instead
   // of four table reads per oscillator and operator application
-  static constexpr bool HOIST = (EPE == 1);
-  double hsu[HOIST ? Q : 1], hsd[HOIST ? Q : 1], hsup[HOIST ? Q : 1], hsdp[HOIST ? Q : 1];
+  // ... also for the four-elements-per-thread Schroedinger kernel (V2 is only used for Schroedinger systems with
+  // 256 < dim <= 1024 since the packed column layout took over its Lindblad cases): 4 x 2Q coefficients
+  static constexpr bool HOIST = (EPE == 1) || (!LIND && EPE == 4);
+  static constexpr int HS = HOIST ? EPE : 1;
+  double hsu[HS][HOIST ? Q : 1], hsd[HS][HOIST ? Q : 1], hsup[HS][HOIST && LIND ? Q : 1], hsdp[HS][HOIST && LIND ? Q : 1];
 
   __device__ __forceinline__ static int dig(unsigned d, int k) { return (int)((d >> (DB * k)) & ((1u << DB) - 1u)); }
 
@@ -418,13 +421,15 @@ struct GenStencil {
       }
       dw[j] = hd - hdp;
       dd[j] = d;
-      if (HOIST && j == 0) {
+      if (HOIST && j < EPE) {
 #pragma unroll
         for (int k = 0; k < Q; k++) {
-          hsu[k] = (ia[k] < S.n[k] - 1) ? sqrt((double)(ia[k] + 1)) : 0.0;
-          hsd[k] = sqrt((double)ia[k]);
-          hsup[k] = (LIND && ipa[k] < S.n[k] - 1) ? sqrt((double)(ipa[k] + 1)) : 0.0;
-          hsdp[k] = LIND ? sqrt((double)ipa[k]) : 0.0;
+          hsu[j % HS][k] = (ia[k] < S.n[k] - 1) ? sqrt((double)(ia[k] + 1)) : 0.0;
+          hsd[j % HS][k] = sqrt((double)ia[k]);
+          if (LIND) {
+            hsup[j % HS][k] = (ipa[k] < S.n[k] - 1) ? sqrt((double)(ipa[k] + 1)) : 0.0;
+            hsdp[j % HS][k] = sqrt((double)ipa[k]);
+          }
         }
       }
     }
@@ -473,21 +478,21 @@ struct GenStencil {
     const unsigned db = HOIST ? dbra[j] : opaque(dbra[j]), dk = HOIST ? dket[j] : opaque(dket[j]);
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
     double l1r = 0.0, l1i = 0.0;  // T1 off-diagonal contribution
-    if (EPE == 1) {
-      // latency regime (one element per thread and initial condition): all LDS reads first, then the arithmetic
+    if (HOIST) {
+      // all LDS reads of the element first, then the arithmetic, ladder coefficients from registers
       double2 xu[Q], xd[Q], xup[Q], xdp[Q], xl[Q];
       double su[Q], sd[Q], sup[Q], sdp[Q];
 #pragma unroll
       for (int k = 0; k < Q; k++) {
         const int st = S.post[k];
-        su[k] = hsu[k];
-        sd[k] = hsd[k];
+        su[k] = hsu[j % HS][k];
+        sd[k] = hsd[j % HS][k];
         xu[k] = sx[min(i0 + st, top)];
         xd[k] = sx[max(i0 - st, 0)];
         if (LIND) {
           const int stp = S.N * st;
-          sup[k] = hsup[k];
-          sdp[k] = hsdp[k];
+          sup[k] = hsup[j % HS][k];
+          sdp[k] = hsdp[j % HS][k];
           xup[k] = sx[min(i0 + stp, top)];
           xdp[k] = sx[max(i0 - stp, 0)];
           xl[k] = sx[TRANS ? max(i0 - st - stp, 0) : min(i0 + st + stp, top)];
