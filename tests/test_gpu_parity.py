@@ -166,13 +166,15 @@ def test_other_steppers_column_layout(stepper, monkeypatch):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("levels", [5, 6])
 @pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
-def test_large_schroedinger_state(linsolve):
-    """Schroedinger with 1024 < dim <= 4096 (6^4 = 1296): the 8-elements-per-thread linear-map kernel (V4) with
-    explicit staging, Neumann and GMRES with the Krylov basis in global memory."""
-    sp, h, orc = _pair(dict(nlevels=[6, 6, 6, 6], lindblad=False, nessential=[2, 2, 2, 2], jkl=0.002, detuned=True,
+def test_large_schroedinger_state(linsolve, levels):
+    """Schroedinger beyond 256 elements: 5^4 = 625 (four elements per thread, V2, hoisted ladder coefficients) and
+    6^4 = 1296 (eight elements per thread, V4, explicit staging); Neumann and GMRES with the Krylov basis in
+    global memory."""
+    sp, h, orc = _pair(dict(nlevels=[levels] * 4, lindblad=False, nessential=[2, 2, 2, 2], jkl=0.002, detuned=True,
                             init="pure, 1, 0, 1, 0", target="pure", objective="Jmeasure"), ntime=8, nspline=6, linsolve=linsolve, penalties=True)
-    assert h.dim == 1296
+    assert h.dim == levels ** 4
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     oval, og = orc.evalGradF(sp.params0)
