@@ -1783,7 +1783,13 @@ struct Team {
             if (k <= j) vk = Vb[(size_t)k * dim + e];
             h4[q] = (on && k <= j) ? w.x * vk.x + w.y * vk.y : 0.0;
           }
-          sum<4>(h4);
+          // as many values as there are projections in this block (the first iterations have 1, 2, 3)
+          switch (min(4, j + 1 - k0)) {
+            case 1: sum<1>(reinterpret_cast<double(&)[1]>(h4)); break;
+            case 2: sum<2>(reinterpret_cast<double(&)[2]>(h4)); break;
+            case 3: sum<3>(reinterpret_cast<double(&)[3]>(h4)); break;
+            default: sum<4>(h4); break;
+          }
 #pragma unroll
           for (int q = 0; q < 4; q++)
             if (k0 + q <= j) hc[k0 + q] = h4[q];
@@ -1913,7 +1919,13 @@ struct Team {
                 }
             }
           }
-          sum<4>(h4);
+          // as many values as there are projections in this block (the first iterations have 1, 2, 3)
+          switch (min(4, jj + 1 - k0)) {
+            case 1: sum<1>(reinterpret_cast<double(&)[1]>(h4)); break;
+            case 2: sum<2>(reinterpret_cast<double(&)[2]>(h4)); break;
+            case 3: sum<3>(reinterpret_cast<double(&)[3]>(h4)); break;
+            default: sum<4>(h4); break;
+          }
 #pragma unroll
           for (int q = 0; q < 4; q++)
             if (k0 + q <= jj) hc[k0 + q] = h4[q];
