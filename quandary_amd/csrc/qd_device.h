@@ -1772,16 +1772,19 @@ struct Team {
       while (j < GMRES_MR) {
         const double2 t2 = st.template apply<TRANS>(A.S, L, Vb + (size_t)j * dim, c, 0, v);
         napp++;
-        double2 w = make_double2(v.x - alpha * t2.x, v.y - alpha * t2.y);
-        // classical Gram-Schmidt: all projections against the un-updated w, four per reduction
+        const double2 w0 = make_double2(v.x - alpha * t2.x, v.y - alpha * t2.y);
+        double2 w = w0;
+        // classical Gram-Schmidt: all projections against the un-updated w0, four per reduction; the basis
+        // vectors and the reduced coefficients stay in registers for the subtraction
         for (int k0 = 0; k0 <= j; k0 += 4) {
           double h4[4];
+          double2 vk4[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const int k = k0 + q;
-            double2 vk = make_double2(0.0, 0.0);
-            if (k <= j) vk = Vb[(size_t)k * dim + e];
-            h4[q] = (on && k <= j) ? w.x * vk.x + w.y * vk.y : 0.0;
+            vk4[q] = make_double2(0.0, 0.0);
+            if (k <= j) vk4[q] = Vb[(size_t)k * dim + e];
+            h4[q] = (on && k <= j) ? w0.x * vk4[q].x + w0.y * vk4[q].y : 0.0;
           }
           // as many values as there are projections in this block (the first iterations have 1, 2, 3)
           switch (min(4, j + 1 - k0)) {
@@ -1792,13 +1795,11 @@ struct Team {
           }
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            if (k0 + q <= j) hc[k0 + q] = h4[q];
-        }
-        for (int k = 0; k <= j; k++) {
-          const double2 vk = Vb[(size_t)k * dim + e];
-          const double h = hc[k];
-          w.x -= h * vk.x;
-          w.y -= h * vk.y;
+            if (k0 + q <= j) {
+              hc[k0 + q] = h4[q];  // for the Givens stage
+              w.x -= h4[q] * vk4[q].x;
+              w.y -= h4[q] * vk4[q].y;
+            }
         }
         double nn[1] = {on ? w.x * w.x + w.y * w.y : 0.0};
         sum<1>(nn);
