@@ -26,8 +26,12 @@ constexpr bool variant_built() {
   // class never exceed the number of SIMDs, so one initial condition per wave wins, C2 38.6M vs 26.7M
   // units/s); V3 and V5 (1024-thread blocks: 128 VGPRs are not enough, 8-12x slower than V2 on C5); V8 and
   // V10 (column layout with 4 / 6 columns per wave: 4.0M vs 4.85M units/s of V9 on C4).
-  if (kDense) return (VAR >= 11 && VAR <= 13) || (kLind && VAR == 15);
-  if (!kQubit) return VAR <= 2 || VAR == 4 || (kLind && (VAR == 9 || VAR == 14));
+  // ... and only where the variant's size class is reachable with this many oscillators (every oscillator has at
+  // least two levels: dim >= 2^Q, or 4^Q for Lindblad) - the five-oscillator Lindblad unit alone took 6 minutes
+  constexpr long kMinDim = kLind ? (1L << (2 * QD_Q)) : (1L << QD_Q);
+  constexpr bool fits0 = kMinDim <= 64, fits1 = kMinDim <= 256, fits2 = kMinDim <= 1024;
+  if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4);
+  if (!kQubit) return (VAR == 0 && fits0) || (VAR == 1 && fits1) || (VAR == 2 && fits2) || VAR == 4 || (kLind && (VAR == 9 || VAR == 14));
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
   return VAR == 2;
