@@ -83,6 +83,53 @@ def test_oracle_gradient_matches_finite_differences(lindblad, linsolve, stepper)
     orc.close()
 
 
+@pytest.mark.parametrize("lindblad", [False, True])
+def test_oracle_operator_is_the_master_equation(lindblad):
+    """Independent of every golden file: the oracle's matrix-free operator equals the rotating-frame master equation
+    built from Kronecker products of ladder operators (docs/mkdocs/user_guide.md, model section):
+      H_d = sum_k (w_k - w_k^rot) n_k - xi_k/2 a^+a^+aa - sum_kl xi_kl n_k n_l
+            + sum_kl J_kl [cos(eta t)(a_k^+ a_l + a_k a_l^+) + i sin(eta t)(a_k^+ a_l - a_k a_l^+)],  eta = w_k^rot - w_l^rot
+      H_c = sum_k p_k (a_k + a_k^+) + i q_k (a_k - a_k^+),   L_1k = a_k / sqrt(T1_k),  L_2k = n_k / sqrt(T2_k)."""
+    nl = [3, 2, 2]
+    sp = synthetic_spec(nl, lindblad=lindblad, jkl=0.02, detuned=True, ntime=5)
+    orc = Oracle(sp)
+    orc.set_params(sp.params0)
+    t, Q, N, tw, sy = 0.02, len(nl), int(np.prod(nl)), 2 * np.pi, sp.system
+    a = []
+    for k in range(Q):
+        op = np.array([[1.0 + 0j]])
+        for m in range(Q):
+            op = np.kron(op, np.diag(np.sqrt(np.arange(1, nl[m])), 1) if m == k else np.eye(nl[m]))
+        a.append(op)
+    dag = lambda m: m.conj().T
+    H = np.zeros((N, N), complex)
+    pair = 0
+    for k in range(Q):
+        nk = dag(a[k]) @ a[k]
+        H += tw * (sy.transfreq[k] - sy.rotfreq[k]) * nk - tw * sy.selfkerr[k] / 2 * (nk @ nk - nk)
+        for l in range(k + 1, Q):
+            eta, J = tw * (sy.rotfreq[k] - sy.rotfreq[l]), tw * sy.Jkl[pair]
+            H -= tw * sy.crosskerr[pair] * nk @ (dag(a[l]) @ a[l])
+            H += J * (np.cos(eta * t) * (dag(a[k]) @ a[l] + a[k] @ dag(a[l])) + 1j * np.sin(eta * t) * (dag(a[k]) @ a[l] - a[k] @ dag(a[l])))
+            pair += 1
+    pq = orc.eval_controls(np.array([t]))[0]
+    for k in range(Q):
+        H += pq[k, 0] * (a[k] + dag(a[k])) + 1j * pq[k, 1] * (a[k] - dag(a[k]))
+    x = np.random.default_rng(1).standard_normal(2 * orc.dim)
+    mx, dim = orc.apply_rhs(t, x)[0], orc.dim
+    if lindblad:
+        rho = (x[:dim] + 1j * x[dim:]).reshape(N, N).T  # column-major vec (src/util.cpp:150)
+        y = -1j * (H @ rho - rho @ H)
+        for k in range(Q):
+            for L in (a[k] / np.sqrt(sy.decay_time[k]), dag(a[k]) @ a[k] / np.sqrt(sy.dephase_time[k])):
+                y += L @ rho @ dag(L) - 0.5 * (dag(L) @ L @ rho + rho @ dag(L) @ L)
+        want = y.T.reshape(-1)
+    else:
+        want = -1j * (H @ (x[:dim] + 1j * x[dim:]))
+    np.testing.assert_allclose(mx[:dim] + 1j * mx[dim:], want, rtol=0, atol=1e-13 * np.abs(want).max())
+    orc.close()
+
+
 def _hermitian(n, nosc, seed):
     rng = np.random.default_rng(seed)
     a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
