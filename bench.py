@@ -4,20 +4,24 @@
 A "step" is one pass of the hot path over one batch of synthetic input: one forward sweep
 (OptimProblem::evalF) of ALL initial conditions of the workload through all ntime time steps
 (`--mode grad`: forward + adjoint + gradient, OptimProblem::evalGradF).  Metric (BASELINE.json):
-Lindblad time-steps x initial-conditions per second, whole job.  Default workload = BASELINE.json
-configs[1] (C2: 2x2x2 Lindblad, T1/T2, 64 basis initial conditions, fp64).
+Lindblad time-steps x initial-conditions per second, whole job.
 
-N > 1 ranks, one per GPU; the path shards over initial conditions (independent units) with the
-reference's two exchange steps: the seven objective sums and the gradient are all-reduced with RCCL
-(torch.distributed backend "nccl").
-  --scaling weak   (default) every GPU propagates one full set of the workload's initial conditions;
-                   the batch is the basis replicated N times, the objective is the mean over all
-                   N x ninit members (so the value equals the 1-GPU objective).  A single C2-sized
-                   basis (64 workgroups) does not even fill one MI355X (256 CUs), so dividing it
-                   further only idles GPUs; per-GPU work fixed is the meaningful multi-GPU regime here.
-  --scaling strong the reference's np_init decomposition (src/main.cpp:133-160): the ninit initial
-                   conditions are split contiguously over the ranks, total work fixed (use with the
-                   large batches: --workload c4 / c5).
+  python bench.py                  one GPU: `value` = BASELINE.json configs[1] (C2: 2x2x2 Lindblad, T1/T2, 64
+                                   basis initial conditions, fp64, forward), validated against the CPU oracle on
+                                   the sample the CPU baseline propagates; plus a "workloads" array in the same
+                                   JSON line with the chip-filling workloads (q4, C5 fp64 / fp32-mixed, C4; both
+                                   linear solvers), each with its own roofline block and oracle check.
+  python bench.py --gpus N         N > 1: starts N ranks itself (torch.distributed.run, one per GPU) unless it
+                                   already runs under a launcher.  Default workload = BASELINE.json configs[3]
+                                   (C4: 3x20 Lindblad, 3600 basis initial conditions) in gradient mode, ntime
+                                   500 so that the stored trajectories fit, STRONG scaling: the initial
+                                   conditions are split evenly and contiguously over the GPUs
+                                   (iinit_global = rank*nlocal + i, src/optimproblem.cpp:248) and the seven
+                                   objective sums and the gradient are all-reduced with RCCL
+                                   (src/optimproblem.cpp:454-460, :527).  The 1-GPU point of that series is the
+                                   "c4/grad" entry of the one-GPU line's "workloads".
+  --scaling weak                   every GPU propagates one full set of the workload's initial conditions (the
+                                   objective is the mean over all replicas and equals the 1-GPU objective).
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,6 +29,8 @@ import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TFLOPS = 157.3  # same guide: FP32 vector = FP32 matrix peak (spec)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -51,6 +58,7 @@ def _cpu_worker(args):
     attach_synthetic_hamiltonian(sp)
     orc = Oracle(sp)
     t0 = time.perf_counter()
+    part = None
     for _ in range(reps):
         part = orc.forward_local(sp.params0, rank, nranks)
         if mode == "grad":
@@ -58,12 +66,26 @@ def _cpu_worker(args):
     el = time.perf_counter() - t0
     ap = orc.mean_applies
     orc.close()
-    return el, ap
+    return el, ap, np.asarray(part, dtype=np.float64)
 
 
-def cpu_baseline(spec, mode, target_wall_s=3.0):
+def _native_oracle():
+    """SURVEY 8(d) asks for -march=native: compile the checker for THIS host (the GPU box) when a compiler is there;
+    otherwise keep the portable x86-64-v3 build that travelled with the repository and say so."""
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libqdoracle_native.so"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        os.environ["QD_ORACLE_LIB"] = os.path.join(ROOT, "oracle", "libqdoracle_native.so")
+        return "-O3 -march=native (built on this host)"
+    except Exception as e:  # noqa: BLE001
+        return f"-O3 -march=x86-64-v3 (native build failed: {type(e).__name__})"
+
+
+def cpu_baseline(spec, mode, target_wall_s=3.0, repeats=3):
     """Bounded sample of the same workload on the host cores (rank 0, N=1 only): `cores` workers, each
-    propagating k initial conditions of the workload through a prefix of the time grid."""
+    propagating k initial conditions of the workload through a prefix of the time grid.  Returns the baseline block
+    and the sample description (k, nt, partial sums of worker 0) for the GPU-vs-oracle check."""
+    flags = _native_oracle()
     ninit, ntime = spec.ninit, spec.time.ntime
     cores = min(ninit, os.cpu_count() or 1)
 
@@ -73,10 +95,10 @@ def cpu_baseline(spec, mode, target_wall_s=3.0):
         nranks = ninit // k  # worker w takes initial conditions [w*k, (w+1)*k)
         with mp.get_context("fork").Pool(cores) as pool:
             res = pool.map(_cpu_worker, [(cfg, w, nranks, mode, reps) for w in range(cores)])
-        return max(r[0] for r in res), res[0][1]
+        return max(r[0] for r in res), res[0][1], res[0][2]
 
     nt = min(ntime, 10)
-    el, _ = run(1, nt, 1)  # probe: unit cost per (step x initial condition) per worker
+    el, _, _ = run(1, nt, 1)  # probe: unit cost per (step x initial condition) per worker
     unit = max(el / nt, 1e-7)
     nt = int(min(ntime, max(10, target_wall_s / unit)))
     k = 1
@@ -84,18 +106,55 @@ def cpu_baseline(spec, mode, target_wall_s=3.0):
         if ninit % d == 0 and d * nt * unit <= target_wall_s:
             k = d
     reps = int(min(100, max(1, target_wall_s / (k * nt * unit))))
-    el, applies = run(k, nt, reps)
-    units = cores * k * nt * reps
-    return {
-        "value": units / el,
+    vals = []
+    for _ in range(repeats):
+        el, applies, part0 = run(k, nt, reps)
+        vals.append(cores * k * nt * reps / el)
+    block = {
+        "value": float(np.median(vals)),
         "unit": "timesteps*initconds/s",
         "cores": cores,
         "kind": "port",
+        "spread": {"min": min(vals), "max": max(vals), "runs": repeats},
+        "compiler_flags": flags,
         "sample": (f"CPU restatement of the reference matrix-free path (oracle/qd_oracle.c; the reference itself needs PETSc, "
                    f"which is not available): {cores * k} of the {ninit} initial conditions x first {nt} of {ntime} steps x {reps} "
-                   f"reps, mode={mode}, {cores} worker processes over initial conditions as the reference's np_init, "
-                   f"{applies:.2f} RHS applications/step"),
+                   f"reps, median of {repeats} runs, mode={mode}, {cores} worker processes over initial conditions as the "
+                   f"reference's np_init, {applies:.2f} RHS applications/step"),
     }
+    return block, {"k": k, "nt": nt, "partial0": part0}
+
+
+def oracle_sample(spec, k, nt):
+    """Partial sums of the first k initial conditions over the first nt steps, by the oracle (one process)."""
+    cfg = dict(spec.cfg)
+    cfg["ntime"] = str(nt)
+    with mp.get_context("fork").Pool(1) as pool:
+        res = pool.map(_cpu_worker, [(cfg, 0, spec.ninit // k, "fwd", 1)])
+    return res[0][2]
+
+
+def check_against_oracle(spec, device, k, nt, part_oracle, tol):
+    """The HIP path on the oracle's sample: shard 0 of ninit/k, first nt steps; compares the seven partial sums
+    (src/optimproblem.cpp:292-298).  Returns the largest error relative to max(1, |.|); raises beyond `tol`."""
+    from quandary_amd import capi, config
+    from quandary_amd.workloads import attach_synthetic_hamiltonian
+
+    cfg = dict(spec.cfg)
+    cfg["ntime"] = str(nt)
+    sp = config.build_spec(cfg)
+    attach_synthetic_hamiltonian(sp)
+    sp.precision = getattr(spec, "precision", "f64")
+    h = capi.Handle(sp, device=device)
+    o = capi.Optim(h, sp, rank=0, nranks=spec.ninit // k)
+    part = np.asarray(o.forward_local(sp.params0, False), dtype=np.float64)
+    o.close()
+    h.close()
+    err = float(np.max(np.abs(part - part_oracle) / np.maximum(1.0, np.abs(part_oracle))))
+    if not err <= tol:
+        raise SystemExit(f"bench.py: HIP path differs from the oracle on the {k} x {nt} sample of '{spec.description}': "
+                         f"max error {err:.3e} > {tol:.1e}; refusing to print a value\n  hip    {part}\n  oracle {part_oracle}")
+    return err
 
 
 def flops_per_apply(spec):
@@ -127,138 +186,235 @@ def flops_per_apply(spec):
     return per * spec.dim
 
 
+_PMC = None
+
+
+def pmc_traffic(name, mode, units_per_launch):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_latest.json; FETCH_SIZE x 2 + WRITE_SIZE as
+    the guide prescribes for gfx950), scaled to this launch's number of units; None when not profiled."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        except Exception:  # noqa: BLE001
+            _PMC = {}
+    ent = _PMC.get(f"{name}_{mode}", {})
+    if ent.get("hbm_bytes_per_unit") is not None:
+        return ent["hbm_bytes_per_unit"] * units_per_launch
+    return ent.get("hbm_bytes_per_launch")
+
+
+class Runner:
+    """One workload on this rank's GPU: handle + (sharded) objective + timing."""
+
+    def __init__(self, name, mode, over, dtype, rank, world, local_rank, weak, comm):
+        from quandary_amd import capi
+        from quandary_amd.parallel import DistributedObjective
+        from quandary_amd.workloads import workload_spec
+
+        self.name, self.mode, self.dtype = name, mode, dtype
+        self.spec = workload_spec(name, "simulation" if mode == "fwd" else "gradient", over)
+        self.spec.precision = dtype
+        self.weak = weak
+        self.world = world
+        if not weak and self.spec.ninit % world:
+            raise SystemExit(f"number of GPUs ({world}) must divide the number of initial conditions ({self.spec.ninit})")
+        self.handle = capi.Handle(self.spec, device=local_rank)  # raises loudly without the HIP library / a GPU
+        if weak:
+            self.optim = capi.Optim(self.handle, self.spec, rank=0, nranks=1)  # the whole set on every GPU
+            self.obj = DistributedObjective(self.optim, comm, replicas=world)
+        else:
+            self.optim = capi.Optim(self.handle, self.spec, rank=rank, nranks=world)
+            self.obj = DistributedObjective(self.optim, comm)
+        self.val = None
+
+    def one_step(self):
+        if self.mode == "fwd":
+            self.val = self.obj.evalF(self.spec.params0)
+        else:
+            self.val = self.obj.evalGradF(self.spec.params0)[0]
+        return self.val
+
+    def time(self, steps, warmup, sync):
+        for _ in range(warmup):
+            self.one_step()
+        sync()
+        self.obj.reset_timers()
+        kern_ms = applies = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.one_step()
+            kern_ms += self.handle.forward_ms + (self.handle.adjoint_ms if self.mode == "grad" else 0.0)
+            applies += self.handle.mean_applies
+        sync()
+        return time.perf_counter() - t0, kern_ms, applies / steps
+
+    def report(self, elapsed, kern_ms, mean_applies, steps, fp64_peak):
+        spec, world = self.spec, self.world
+        ntime, ninit, dim = spec.time.ntime, spec.ninit, spec.dim
+        ninit_local = ninit if self.weak else ninit // world
+        ninit_global = ninit_local * world
+        value = ninit_global * ntime * steps / elapsed
+        # roofline of the dominant kernel (k_forward / k_forward + k_adjoint): algorithmic HBM bytes per
+        # (time step x initial condition) = 2 * (2 dim) * sizeof(real) forward (read + write the state once per step),
+        # three times that for forward + adjoint (SURVEY 8(d)); units per launch = local initial conditions x ntime.
+        real = 4 if self.dtype == "f32mixed" else 8
+        alg_bytes = (4 if self.mode == "fwd" else 12) * real * dim
+        units_per_launch = ninit_local * ntime
+        kern_s = kern_ms / 1e3 / steps
+        achieved = alg_bytes * units_per_launch / kern_s / 1e9
+        # secondary roofline (SURVEY 8(d)): canonical flops of the fused step against the MEASURED v_fma_f64 rate
+        # of this device (fp32-mixed: against the fp32 vector peak of the guide)
+        f_apply = flops_per_apply(spec)
+        f_step = mean_applies * f_apply + (12.0 * max(mean_applies - 1.0, 0.0) + 4.0) * dim
+        if self.mode == "grad":
+            f_step *= 3.0  # adjoint step = two more solves of the same size + the gradient contraction (~1 apply)
+        valu_peak = FP32_PEAK_TFLOPS if self.dtype == "f32mixed" else fp64_peak
+        valu_achieved = f_step * units_per_launch / kern_s / 1e12
+        roof = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else ""), self.mode, units_per_launch),
+            "kernel": "k_forward" if self.mode == "fwd" else "k_forward+k_adjoint",
+            "kernel_ms_per_launch": kern_s * 1e3,
+            "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": units_per_launch,
+            ("fp32_valu" if self.dtype == "f32mixed" else "fp64_valu"): {
+                "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
+                "frac": valu_achieved / valu_peak if valu_peak > 0 else None, "flops_per_unit": f_step,
+                "peak_kind": ("FP32 vector peak, MI355X_MICROARCH.md" if self.dtype == "f32mixed"
+                              else "measured v_fma_f64 micro-benchmark (qd_measure_fp64_peak)"),
+                "active_cu_frac": min(1.0, ninit_local / 256.0)},
+        }
+        cfg = {
+            "workload": spec.description, "name": self.name,
+            "mode": "forward sweep (evalF)" if self.mode == "fwd" else "forward + adjoint gradient (evalGradF)",
+            "system_dim": dim, "ninit": ninit_global, "ninit_per_gpu": ninit_local, "ntime": ntime, "dt": spec.time.dt,
+            "timestepper": "IMR", "linearsolver": ("gmres" if spec.solver.linsolve == 0 else "neumann") + " (in-kernel)",
+            "parallelism": (f"{world} GPU(s): one full set of {ninit} initial conditions per GPU (weak)" if self.weak else
+                            f"{ninit} initial conditions split over {world} GPU(s)"),
+            "rhs_applications_per_step": mean_applies,
+            "objective": self.val["objective"],
+        }
+        return value, roof, cfg
+
+    def close(self):
+        self.optim.close()
+        self.handle.close()
+
+
+DTYPE_NAME = {"f64": "f64", "f32mixed": "f32/f64acc"}
+# tolerance of the bench's own oracle check on the partial sums, relative to max(1, |.|)
+CHECK_TOL = {"f64": 1e-9, "f32mixed": 2e-5}
+
+# the chip-filling workloads reported next to the headline on one GPU: (name, mode, linsolve, dtype, overrides, steps)
+EXTRA = [
+    ("q4", "fwd", "neumann", "f64", {}, 5),
+    ("q4", "fwd", "gmres", "f64", {}, 3),
+    ("q4", "fwd", "neumann", "f32mixed", {}, 5),
+    ("c5", "fwd", "neumann", "f64", {}, 3),
+    ("c5", "fwd", "gmres", "f64", {}, 2),
+    ("c5", "grad", "neumann", "f64", {}, 2),
+    ("c5", "fwd", "neumann", "f32mixed", {}, 3),
+    ("c5", "grad", "neumann", "f32mixed", {}, 2),
+    ("c4", "fwd", "neumann", "f64", {"ntime": 250}, 2),
+    ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1),
+    ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1),  # = the 1-GPU point of the `--gpus N` strong-scaling series
+]
+# small systems: no chip-filling possible (4 / 16 single-wave workgroups); reported so that the bench line says it
+SMALL = [("c1", "grad", "gmres", "f64", {}, 3), ("c3", "grad", "neumann", "f64", {}, 3)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "q4", "c4", "c5", "d4"])
-    ap.add_argument("--mode", default="fwd", choices=["fwd", "grad"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 on one GPU, 3 on several)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 3 / 1)")
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "q4", "c4", "c5", "d4"],
+                    help="default: c2 on one GPU, c4 on several")
+    ap.add_argument("--mode", default=None, choices=["fwd", "grad"], help="default: fwd on one GPU, grad on several")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32mixed"],
+                    help="f32mixed: fp32 state exchange / stencil arithmetic, fp64 accumulation (all-qubit Lindblad systems)")
     ap.add_argument("--linsolve", default=None, choices=[None, "neumann", "gmres"])
     ap.add_argument("--ntime", type=int, default=None, help="override the number of time steps of the workload")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override a config entry of the workload, e.g. --set 'initialcondition=diagonal, 0, 1, 2, 3, 4'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = one full set of initial conditions per GPU (default); strong = split the set over the GPUs")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share one GPU for testing")
+    ap.add_argument("--no-workloads", action="store_true", help="one GPU: skip the additional workloads array")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = split the initial conditions over the GPUs (default); weak = one full set per GPU")
+    ap.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="auto: nccl (RCCL over xGMI, called from the library) when every rank has its own GPU, otherwise gloo "
+                         "(several ranks share one GPU: test mode)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    multi = world > 1
+    name = args.workload or ("c4" if multi else "c2")
+    mode = args.mode or ("grad" if multi else "fwd")
+    steps = args.steps if args.steps is not None else (3 if multi else 20)
+    warmup = args.warmup if args.warmup is not None else (1 if multi else 3)
 
     import torch
 
     from quandary_amd import capi
-    from quandary_amd.parallel import DistributedObjective
-    from quandary_amd.workloads import workload_spec
+    from quandary_amd.parallel import make_comm
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "gloo":
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)  # ranks may share a GPU in this mode
+    ndev = torch.cuda.device_count()
+    backend = args.dist_backend
+    if backend == "auto":
+        backend = "nccl" if ndev >= world else "gloo"
+    if multi and backend == "gloo":
+        local_rank = local_rank % max(ndev, 1)  # ranks may share a GPU in this mode
+    if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-    red_dev = "cpu" if (world > 1 and args.dist_backend == "gloo") else f"cuda:{local_rank}"
+    comm = make_comm(backend, rank, world, local_rank) if multi else None
 
-    mode = "simulation" if args.mode == "fwd" else "gradient"
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+            torch.cuda.synchronize()
+
     over = {}
     if args.linsolve:
         over["linearsolver_type"] = args.linsolve
     if args.ntime:
         over["ntime"] = args.ntime
+    elif multi and name == "c4" and mode == "grad":
+        over["ntime"] = 500
     for kv in args.set:
         k, _, v = kv.partition("=")
         over[k.strip()] = v.strip()
-    spec = workload_spec(args.workload, mode, over)
-    weak = world > 1 and args.scaling == "weak"
-    if not weak and spec.ninit % world:
-        raise SystemExit(f"number of GPUs ({world}) must divide the number of initial conditions ({spec.ninit})")
+    weak = multi and args.scaling == "weak"
 
-    handle = capi.Handle(spec, device=local_rank)   # raises loudly without the HIP library / a GPU
-    if weak:
-        optim = capi.Optim(handle, spec, rank=0, nranks=1)   # the whole set on every GPU
-        obj = DistributedObjective(optim, dist, red_dev, replicas=world)
-    else:
-        optim = capi.Optim(handle, spec, rank=rank, nranks=world)
-        obj = DistributedObjective(optim, dist, red_dev)
-    alpha = spec.params0
-
-    def one_step():
-        if args.mode == "fwd":
-            return obj.evalF(alpha)
-        return obj.evalGradF(alpha)[0]
-
-    def sync():
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    kern_ms = 0.0
-    applies = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        val = one_step()
-        kern_ms += handle.forward_ms + (handle.adjoint_ms if args.mode == "grad" else 0.0)
-        applies += handle.mean_applies
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kern_ms = float(t[0]), float(t[1])
-
-    ntime, ninit, dim = spec.time.ntime, spec.ninit, spec.dim
-    ninit_local = ninit if weak else ninit // world
-    ninit_global = ninit_local * world
-    units_total = ninit_global * ntime * args.steps
-    value = units_total / elapsed
-    # roofline of the dominant kernel (k_forward / k_forward + k_adjoint): algorithmic HBM bytes per
-    # (time step x initial condition) = 32*dim (forward: read + write the state once per step, fp64) or
-    # 96*dim (forward + adjoint); units per launch = local initial conditions x ntime.
-    alg_bytes = (32 if args.mode == "fwd" else 96) * dim
-    units_per_launch = ninit_local * ntime
-    kern_s = kern_ms / 1e3 / args.steps
-    achieved = alg_bytes * units_per_launch / kern_s / 1e9
-    # secondary roofline: canonical fp64 flops of the fused step against the MEASURED
-    # v_fma_f64 rate of this device (the state never leaves the CU between steps, so for the small
-    # systems the HBM figure above only says "not HBM bound")
-    mean_applies = applies / args.steps
-    f_apply = flops_per_apply(spec)
-    f_step = mean_applies * f_apply + (12.0 * max(mean_applies - 1.0, 0.0) + 4.0) * dim
-    if args.mode == "grad":
-        f_step *= 3.0  # adjoint step = two more solves of the same size + the gradient contraction (~1 apply)
+    run = Runner(name, mode, over, args.dtype, rank, world, local_rank, weak, comm)
+    elapsed, kern_ms, mean_applies = run.time(steps, warmup, sync)
+    ar_ms = run.obj.allreduce_ms()
+    if comm is not None:
+        red = comm.allreduce_max(np.array([elapsed, kern_ms] + ar_ms, dtype=np.float64))
+        elapsed, kern_ms, ar_ms = float(red[0]), float(red[1]), [float(red[2]), float(red[3])]
     fp64_peak = capi.measure_fp64_peak(local_rank) if rank == 0 else 0.0
-    fp64_achieved = f_step * units_per_launch / kern_s / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
-        try:
-            ent = json.load(open(pmc)).get(f"{args.workload}_{args.mode}", {})
-            if ent.get("hbm_bytes_per_unit") is not None:  # profiled with a shorter time grid: scale to this launch
-                traffic = ent["hbm_bytes_per_unit"] * units_per_launch
-            else:
-                traffic = ent.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    value, roof, cfg = run.report(elapsed, kern_ms, mean_applies, steps, fp64_peak)
 
     out = None
     if rank == 0:
@@ -267,47 +423,74 @@ def main():
             "value": value,
             "unit": "timesteps*initconds/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak" if (weak or world == 1) else "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": DTYPE_NAME[args.dtype],
             "data": "synthetic",
-            "config": {
-                "workload": spec.description,
-                "name": args.workload,
-                "mode": "forward sweep (evalF)" if args.mode == "fwd" else "forward + adjoint gradient (evalGradF)",
-                "system_dim": dim, "ninit": ninit_global, "ninit_per_gpu": ninit_local, "ntime": ntime, "dt": spec.time.dt,
-                "timestepper": "IMR", "linearsolver": ("gmres" if spec.solver.linsolve == 0 else "neumann") + " (in-kernel)",
-                "parallelism": (f"{world} GPU(s): one full set of {ninit} initial conditions per GPU (weak)" if weak else
-                                f"{ninit} initial conditions split over {world} GPU(s)"),
-                "rhs_applications_per_step": applies / args.steps,
-                "objective": val["objective"],
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "k_forward" if args.mode == "fwd" else "k_forward+k_adjoint",
-                "kernel_ms_per_launch": kern_s * 1e3,
-                "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": units_per_launch,
-                "fp64_valu": {"achieved": fp64_achieved, "peak": fp64_peak, "unit": "TFLOP/s",
-                              "frac": fp64_achieved / fp64_peak if fp64_peak > 0 else None,
-                              "flops_per_unit": f_step, "peak_kind": "measured v_fma_f64 micro-benchmark (qd_measure_fp64_peak)",
-                              "active_cu_frac": min(1.0, ninit_local / 256.0)},
-            },
+            "config": cfg,
+            "roofline": roof,
         }
-        if args.mode == "grad":
-            out["grad_wall_ms"] = elapsed / args.steps * 1e3
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, args.mode)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-    optim.close()
-    handle.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if mode == "grad":
+            out["grad_wall_ms"] = elapsed / steps * 1e3
+        if multi:
+            out["ranks_seen"] = comm.world_size()
+            out["dist_backend"] = comm.describe()
+            out["allreduce_ms_per_step"] = {"objective_sums": ar_ms[0] / steps, "gradient": ar_ms[1] / steps}
+    run.close()
+
+    if rank == 0 and not multi:
+        # ---- oracle check of the timed workload + CPU baseline on the same sample -------------------------------
+        if not args.no_cpu_baseline:
+            block, smp = cpu_baseline(run.spec, mode)
+            out["cpu_baseline"] = block
+            out["gpu_over_cpu"] = value / block["value"]
+            k, nt, part0 = smp["k"], smp["nt"], smp["partial0"]
+        else:
+            k, nt = min(run.spec.ninit, 8), min(run.spec.time.ntime, 50)
+            while run.spec.ninit % k:
+                k -= 1
+            part0 = oracle_sample(run.spec, k, nt)
+        err = check_against_oracle(run.spec, local_rank, k, nt, part0, CHECK_TOL[args.dtype])
+        out["oracle_check"] = {"sample": f"first {k} initial conditions x first {nt} steps, seven partial sums of evalF",
+                               "max_err_rel_to_max1": err, "tol": CHECK_TOL[args.dtype]}
+        # ---- the chip-filling workloads, in the same driver-timed line ------------------------------------------
+        if not args.no_workloads:
+            out["workloads"] = []
+            for (wn, wm, ws, wd, wo, wsteps) in EXTRA + SMALL:
+                ent = {"name": wn, "mode": wm, "linearsolver": ws, "dtype": DTYPE_NAME[wd]}
+                try:
+                    r = Runner(wn, wm, {**wo, "linearsolver_type": ws}, wd, 0, 1, local_rank, False, None)
+                    el, km, apl = r.time(wsteps, 1, sync)
+                    v, rf, cf = r.report(el, km, apl, wsteps, fp64_peak)
+                    ent.update({"value": v, "unit": "timesteps*initconds/s", "ms_per_step": el / wsteps * 1e3, "steps": wsteps,
+                                "ninit": cf["ninit"], "ntime": cf["ntime"], "system_dim": cf["system_dim"],
+                                "rhs_applications_per_step": apl, "objective": cf["objective"], "roofline": rf})
+                    if wm == "grad":
+                        ent["grad_wall_ms"] = el / wsteps * 1e3
+                    if ws == "neumann" and wm == "fwd":  # one oracle check per (workload, dtype): small sample, few steps
+                        kk = 8 if r.spec.ninit % 8 == 0 else 1
+                        nn = 20 if r.spec.dim > 256 else 100
+                        ent["oracle_check"] = {"sample": f"first {kk} initial conditions x first {nn} steps",
+                                               "max_err_rel_to_max1": check_against_oracle(r.spec, local_rank, kk, nn, oracle_sample(r.spec, kk, nn), CHECK_TOL[wd]),
+                                               "tol": CHECK_TOL[wd]}
+                    if (wn, wm, ws, wd) == ("q4", "fwd", "neumann", "f64") and not args.no_cpu_baseline:
+                        # north_star: >= 10x the CPU baseline for a 4-qubit open system at 1 GPU
+                        ent["cpu_baseline"], _ = cpu_baseline(r.spec, wm)
+                        ent["gpu_over_cpu"] = v / ent["cpu_baseline"]["value"]
+                    if (wn, wm) in (("c1", "grad"), ("c3", "grad")):
+                        ent["note"] = ("4 / 16 single-wave workgroups on 1024 SIMDs: a latency-bound chain per initial condition; the "
+                                       "GPU gains little over one host core per initial condition on this shape (BASELINE configs 1 and 3)")
+                    r.close()
+                except (Exception, SystemExit) as e:  # noqa: BLE001  (a failed extra never hides the headline)
+                    ent["error"] = f"{type(e).__name__}: {e}"
+                out["workloads"].append(ent)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if rank == 0:
         print(json.dumps(out))
 

@@ -295,6 +295,47 @@ int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const double* globa
 int qd_optim_evalF(qd_optim* o, const double* alpha, qd_objective_value* val);
 int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective_value* val, double* grad);
 
+/* ---------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, initial conditions sharded over the ranks.
+ * Replaces the reference's comm_init communicator (src/main.cpp:133-177) and its
+ * MPI_Allreduce calls (src/optimproblem.cpp:292-298, :454-460, :527) by RCCL
+ * (ncclAllReduce over xGMI) on the handle's HIP stream; partial sums and the
+ * gradient never leave HBM between the sweeps and the collectives.
+ * ------------------------------------------------------------------------- */
+#define QD_COMM_ID_BYTES 128           /* = NCCL_UNIQUE_ID_BYTES                */
+typedef struct qd_comm qd_comm;
+/* rank 0: generate the id (ncclGetUniqueId) and hand its bytes to every rank by any means */
+int qd_comm_unique_id(unsigned char id[QD_COMM_ID_BYTES]);
+int qd_comm_create(const unsigned char id[QD_COMM_ID_BYTES], int rank, int nranks, int device_ordinal, qd_comm** out);
+/* MPI-free bootstrap through a file every rank can see: rank 0 writes the id, the others wait up to timeout_s */
+int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out);
+void qd_comm_destroy(qd_comm* c);
+int qd_comm_size(const qd_comm* c);
+int qd_comm_rank(const qd_comm* c);
+/* host convenience: in-place all-reduce of n doubles, op 0 = sum, 1 = max (staged through HBM, blocking) */
+int qd_comm_allreduce(qd_comm* c, double* buf, int n, int op);
+int qd_comm_barrier(qd_comm* c);
+/* evalF / evalGradF over ALL ranks (every rank calls with its own shard `o` created with the same rank / nranks as
+ * `c`); every rank receives the same value and the complete gradient.  allreduce_ms (NULL or [2]): device time of the
+ * objective-sum and the gradient collective. */
+int qd_optim_evalF_dist(qd_optim* o, qd_comm* c, const double* alpha, qd_objective_value* val, double* allreduce_ms);
+int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* alpha, qd_objective_value* val, double* grad, double* allreduce_ms);
+
+/* ---------------------------------------------------------------------------
+ * Arithmetic of the sweeps.  QD_PRECISION_F64 (default): everything IEEE double like the reference.
+ * QD_PRECISION_F32MIXED (BASELINE config 5): the exchange vector in LDS, the stencil arithmetic, the linear-solver
+ * iterates and the stored trajectory are fp32; the state / adjoint-state accumulators, every norm, objective sum and
+ * gradient coefficient are fp64.  Built for all-qubit Lindblad systems with 4 or 5 oscillators, Neumann solver, IMR
+ * family; QD_ERR_UNSUPPORTED elsewhere.  Call before the first sweep.
+ * ------------------------------------------------------------------------- */
+enum { QD_PRECISION_F64 = 0, QD_PRECISION_F32MIXED = 1 };
+int qd_set_precision(qd_handle* h, int precision);
+int qd_get_precision(const qd_handle* h);
+/* Measurement hook: nrep chained forward applications y <- M(t) (1e-3 y) on nb states, starting from x, in fp32 by the
+ * stencil kernel (mfma = 0) or as the dense Kronecker-factor product G rho - rho G on the fp32 matrix cores (mfma = 1,
+ * five qubits only); *ms = device time of the launch.  DESIGN.md records the comparison. */
+int qd_bench_apply_f32(qd_handle* h, double t, const double* x, double* y, int nb, int nrep, int mfma, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

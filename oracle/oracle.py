@@ -28,7 +28,8 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    lib = C.CDLL(LIB_PATH)
+    # QD_ORACLE_LIB: an alternative build of the same source (bench.py compiles one with -march=native on the measuring host)
+    lib = C.CDLL(os.environ.get("QD_ORACLE_LIB") or LIB_PATH)
     vp = C.c_void_p
     lib.qo_last_error.restype = C.c_char_p
     lib.qo_create.argtypes = [C.POINTER(capi.qd_system), C.POINTER(capi.qd_controls), C.POINTER(capi.qd_time),

@@ -174,7 +174,14 @@ EXPORTS = [
     "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
+    "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
+    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32",
 ]
+COMM_ID_BYTES = 128
+PRECISION = {"f64": 0, "f32mixed": 1}
+c_u8p = C.POINTER(C.c_uint8)
+c_void_p = C.c_void_p
+byref = C.byref
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libquandary_amd.so")
 _lib = None
@@ -229,9 +236,27 @@ def load_library(path=None):
     lib.qd_optim_adjoint_local.argtypes = [vp, c_dp, c_dp, c_dp]
     lib.qd_optim_evalF.argtypes = [vp, c_dp, C.POINTER(qd_objective_value)]
     lib.qd_optim_evalGradF.argtypes = [vp, c_dp, C.POINTER(qd_objective_value), c_dp]
+    lib.qd_comm_unique_id.argtypes = [c_u8p]
+    lib.qd_comm_create.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.qd_comm_create_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
+    lib.qd_comm_destroy.argtypes = [vp]
+    lib.qd_comm_destroy.restype = None
+    lib.qd_comm_size.argtypes = [vp]
+    lib.qd_comm_rank.argtypes = [vp]
+    lib.qd_comm_allreduce.argtypes = [vp, c_dp, C.c_int, C.c_int]
+    lib.qd_comm_barrier.argtypes = [vp]
+    lib.qd_optim_evalF_dist.argtypes = [vp, vp, c_dp, C.POINTER(qd_objective_value), c_dp]
+    lib.qd_optim_evalGradF_dist.argtypes = [vp, vp, c_dp, C.POINTER(qd_objective_value), c_dp, c_dp]
+    lib.qd_set_precision.argtypes = [vp, C.c_int]
+    lib.qd_get_precision.argtypes = [vp]
+    lib.qd_bench_apply_f32.argtypes = [vp, C.c_double, c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp]
     if path is None:
         _lib = lib
     return lib
+
+
+def check(rc, what):
+    _check(load_library(), rc, what)
 
 
 def measure_fp64_peak(device=0):
@@ -266,6 +291,13 @@ class Handle:
         ham = getattr(spec, "hamiltonian", None)  # (Hsys, Hc) complex arrays from hamiltonian_file_Hsys / _Hc
         if ham is not None:
             self.set_hamiltonian(*ham)
+        prec = getattr(spec, "precision", "f64") or "f64"
+        if prec != "f64":
+            self.set_precision(prec)
+
+    def set_precision(self, name):
+        """'f64' (default, like the reference) or 'f32mixed' (fp32 exchange vector / stencil, fp64 accumulation)."""
+        _check(self.lib, self.lib.qd_set_precision(self._h, PRECISION[name]), "qd_set_precision")
 
     def set_hamiltonian(self, hsys, hc=None):
         """User-supplied Hamiltonians: hsys complex [N, N], hc complex [nosc, N, N] or None (rad/ns)."""
@@ -427,3 +459,20 @@ class Optim:
         g = np.zeros(max(self.h.ndesign, 1))
         _check(self.lib, self.lib.qd_optim_evalGradF(self._o, dptr(alpha), C.byref(val), dptr(g)), "qd_optim_evalGradF")
         return val.as_dict(), g[: self.h.ndesign]
+
+    # multi-GPU: every rank calls with the RCCL communicator (qd_comm*) created for the same rank / nranks
+    def evalF_dist(self, comm, alpha):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        val = qd_objective_value()
+        ms = np.zeros(2)
+        _check(self.lib, self.lib.qd_optim_evalF_dist(self._o, comm, dptr(alpha), C.byref(val), dptr(ms)), "qd_optim_evalF_dist")
+        return val.as_dict(), ms
+
+    def evalGradF_dist(self, comm, alpha):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        val = qd_objective_value()
+        g = np.zeros(max(self.h.ndesign, 1))
+        ms = np.zeros(2)
+        _check(self.lib, self.lib.qd_optim_evalGradF_dist(self._o, comm, dptr(alpha), C.byref(val), dptr(g), dptr(ms)),
+               "qd_optim_evalGradF_dist")
+        return val.as_dict(), g[: self.h.ndesign], ms

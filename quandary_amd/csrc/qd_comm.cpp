@@ -1,0 +1,130 @@
+// RCCL communicator behind the C ABI (qd_comm_*): the reference's comm_init split and its MPI_Allreduce calls
+// (src/main.cpp:133-177, src/optimproblem.cpp:292-298, :454-460, :527) as ncclAllReduce over xGMI, one process
+// per GPU, on the handle's HIP stream.  Bootstrap needs no MPI: the ncclUniqueId of rank 0 travels as 128 plain
+// bytes through whatever the caller has (a file on a shared file system here, torch.distributed/gloo in bench.py).
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "qd_handle.h"
+
+using namespace qd;
+
+static int fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+
+#define QD_NCCL(expr)                                                                       \
+  do {                                                                                      \
+    ncclResult_t _r = (expr);                                                               \
+    if (_r != ncclSuccess) return fail(QD_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
+  } while (0)
+
+static_assert(QD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "QD_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+
+extern "C" int qd_comm_unique_id(unsigned char* id) {
+  if (!id) return fail(QD_ERR_INVALID, "qd_comm_unique_id: null argument");
+  ncclUniqueId u;
+  QD_NCCL(ncclGetUniqueId(&u));
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return QD_OK;
+}
+
+extern "C" int qd_comm_create(const unsigned char* id, int rank, int nranks, int device_ordinal, qd_comm** out) {
+  if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(QD_ERR_INVALID, "qd_comm_create: bad argument");
+  *out = nullptr;
+  QD_HIP(hipSetDevice(device_ordinal));
+  qd_comm* c = new qd_comm();
+  c->rank = rank;
+  c->nranks = nranks;
+  c->device = device_ordinal;
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(QD_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    ncclCommDestroy(c->comm);
+    delete c;
+    return fail(QD_ERR_DEVICE, "qd_comm_create: stream creation failed");
+  }
+  *out = c;
+  return QD_OK;
+}
+
+// rank 0 writes the id to `path` (atomically: temporary name + rename), the others wait for the file
+extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out) {
+  if (!path || !out) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: null argument");
+  unsigned char id[QD_COMM_ID_BYTES];
+  if (rank == 0) {
+    int r = qd_comm_unique_id(id);
+    if (r) return r;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) {
+      if (f) fclose(f);
+      return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot write the id file");
+    }
+    fclose(f);
+    if (rename(tmp.c_str(), path) != 0) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish the id file");
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      FILE* f = fopen(path, "rb");
+      if (f) {
+        const size_t n = fread(id, 1, sizeof id, f);
+        fclose(f);
+        if (n == sizeof id) break;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+        return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank 0's id file");
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+  }
+  return qd_comm_create(id, rank, nranks, device_ordinal, out);
+}
+
+extern "C" void qd_comm_destroy(qd_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  c->dbuf.release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  delete c;
+}
+
+extern "C" int qd_comm_size(const qd_comm* c) {
+  if (!c) return QD_ERR_INVALID;
+  int n = 0;
+  if (ncclCommCount(c->comm, &n) != ncclSuccess) return QD_ERR_DEVICE;
+  return n;
+}
+extern "C" int qd_comm_rank(const qd_comm* c) { return c ? c->rank : QD_ERR_INVALID; }
+
+int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_t st) {
+  QD_NCCL(ncclAllReduce(dbuf, dbuf, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st));
+  return QD_OK;
+}
+
+// host convenience (timings, test hooks): staged through a device buffer, blocking
+extern "C" int qd_comm_allreduce(qd_comm* c, double* buf, int n, int op) {
+  if (!c || !buf || n < 0 || (op != 0 && op != 1)) return fail(QD_ERR_INVALID, "qd_comm_allreduce: bad argument");
+  if (n == 0) return QD_OK;
+  QD_HIP(hipSetDevice(c->device));
+  int r;
+  if ((r = c->dbuf.ensure(n))) return r;
+  QD_HIP(hipMemcpyAsync(c->dbuf.p, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  if ((r = qd_comm_allreduce_dev(c, c->dbuf.p, n, op, c->stream))) return r;
+  QD_HIP(hipMemcpyAsync(buf, c->dbuf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  QD_HIP(hipStreamSynchronize(c->stream));
+  return QD_OK;
+}
+
+extern "C" int qd_comm_barrier(qd_comm* c) {
+  double z = 0.0;
+  return qd_comm_allreduce(c, &z, 1, 0);
+}

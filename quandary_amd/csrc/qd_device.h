@@ -2213,7 +2213,8 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep: TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams
 // (primal states come from the stored trajectory for Lindblad AND Schroedinger: 288 GB of HBM make
-// the reference's backward recomputation of the Schroedinger primal unnecessary)
+// the reference's backward recomputation of the Schroedinger primal unnecessary - except for explicit
+// Euler, where the recomputed chain differs from the forward states and defines the reference's gradient)
 // ---------------------------------------------------------------------------------------------
 template <int Q, bool LIND, int VAR, bool QUBIT, bool GM>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs A) {
@@ -2239,6 +2240,43 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     const double* xbT = A.xbarT + (size_t)tm.ic(j) * 2 * dim;
     xb[j] = make_double2(xbT[tm.st.it[j]], xbT[dim + tm.st.it[j]]);
   }
+  const bool jpairs = S.npairs > 0;
+  if (A.stepper_ee && !LIND) {
+    // Schroedinger runs of the reference do not store the forward states: the adjoint loop re-computes the primal
+    // backwards with the FORWARD stepper and a negative step, xprimal <- xprimal + (tstart - tstop) M(tstop) xprimal
+    // (src/timestepper.cpp:229-231 with ExplEuler::evolveFWD :496-507), and so do the dpdm states (:207-211, :236-243).
+    // That is exact for the symmetric IMR family but O(dt) away from the forward states for explicit Euler, and the
+    // reference's EE gradient is defined on this backward chain.  Reproduce it: overwrite the stored trajectory with
+    // the chain x_N, B_N x_N, B_{N-1} B_N x_N, ... (every thread only touches its own elements), then run the
+    // ordinary adjoint loop on it.
+    double* trajw = const_cast<double*>(traj);
+    double2 xp[EPT];
+    load_state(A.nsub, xp);
+    for (int s = A.nsub - 1; s >= 0; s--) {
+      StepC<Q> c1;
+      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);  // M(tstop of step s) = row s + 1
+      if (TM::V::LEAN) scalarize<Q>(c1, jpairs);
+      c1.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
+      tm.st.prep(S, tm.L, c1);
+      const double hneg = -A.ctl[(size_t)s * A.cs];
+      tm.publish(xp);
+      double2 t[EPT];
+      tm.template apply_all<false>(S, c1, xp, t);
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        xp[j].x = fma(hneg, t[j].x, xp[j].x);
+        xp[j].y = fma(hneg, t[j].y, xp[j].y);
+        if (tm.ok(j)) {
+          double* dst = trajw + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
+          const int e = at_use<TM::EPE>(tm.st.it[j]);
+          dst[e] = xp[j].x;
+          dst[dim + e] = xp[j].y;
+        }
+      }
+    }
+    __threadfence_block();
+    team_sync<TM::V::ONEWAVE>();
+  }
   // Latency-bound variants (few elements per thread) carry x_{n+1} in registers and prefetch x_{n-1} one
   // step ahead; the throughput variants re-read them (L2 / HBM) to keep the register footprint small.
   constexpr bool CARRY = !TM::V::LEAN;
@@ -2254,7 +2292,6 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
   const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
-  const bool jpairs = S.npairs > 0;
   bool guard[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.ok(j) && tm.st.is_guard(S, j);

@@ -74,6 +74,8 @@ extern "C" void qd_destroy(qd_handle* h) {
   h->h_params.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -107,9 +109,9 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
   for (int k = 0; k < S.Q; k++) {
     S.n[k] = sys->nlevels[k];
     S.ness[k] = sys->nessential[k];
-    if (S.n[k] < 1 || S.n[k] > 255) {
+    if (S.n[k] < 2 || S.n[k] > 255) {  // (the kernel variants are instantiated for dim >= 2^Q / 4^Q)
       delete h;
-      return fail(QD_ERR_INVALID, "qd_create: nlevels must be in 1..255");
+      return fail(QD_ERR_INVALID, "qd_create: nlevels must be in 2..255");
     }
     if (S.ness[k] < 1 || S.ness[k] > S.n[k]) S.ness[k] = S.n[k];
     N *= S.n[k];
@@ -214,6 +216,8 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     QD_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     QD_HIP(hipEventCreate(&h->ev0));
     QD_HIP(hipEventCreate(&h->ev1));
+    QD_HIP(hipEventCreate(&h->ev2));
+    QD_HIP(hipEventCreate(&h->ev3));
     int r;
     if ((r = upload(&h->d_segs, h->segs))) return r;
     if ((r = upload(&h->d_oscs, h->oscs))) return r;
@@ -307,6 +311,7 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   if (!h || !hsys_re || !hsys_im) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: null system Hamiltonian");
   if ((hc_re == nullptr) != (hc_im == nullptr)) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: give both parts of the control Hamiltonians or neither");
   if (h->S.dim > 1024) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: user Hamiltonians are supported for state dimensions up to 1024");
+  if (h->S.Q > 5) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: the dense-operator kernels are instantiated for 1..5 oscillators");
   QD_HIP(hipSetDevice(h->device));
   const size_t nn = (size_t)h->S.N * h->S.N;
   if ((double)h->sched_t.size() * (double)nn * 16.0 > 16e9)
@@ -332,6 +337,24 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   h->S.gtab = nullptr;
   h->S.hasJ = 0;  // the file model replaces the standard one including the dipole-dipole terms (src/mastereq.cpp:273-284)
   h->params_dirty = true;
+  h->traj_valid = false;
+  return QD_OK;
+}
+
+extern "C" int qd_get_precision(const qd_handle* h) { return h ? h->precision : QD_ERR_INVALID; }
+
+extern "C" int qd_set_precision(qd_handle* h, int precision) {
+  if (!h) return fail(QD_ERR_INVALID, "qd_set_precision: null handle");
+  if (precision != QD_PRECISION_F64 && precision != QD_PRECISION_F32MIXED) return fail(QD_ERR_INVALID, "qd_set_precision: unknown precision");
+  if (precision == QD_PRECISION_F32MIXED) {
+    const DevSys& S = h->S;
+    bool qubits = S.lindblad && !S.dense && (S.Q == 4 || S.Q == 5);
+    for (int k = 0; k < S.Q; k++) qubits = qubits && S.n[k] == 2 && S.ness[k] == 2;
+    if (!qubits || S.hasJ) return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps are built for all-qubit Lindblad systems with 4 or 5 oscillators without dipole-dipole coupling");
+    if (h->sol.linsolve != QD_LINSOLVE_NEUMANN || h->sol.stepper == QD_STEPPER_EE)
+      return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps need the Neumann solver and a stepper of the IMR family");
+  }
+  h->precision = precision;
   h->traj_valid = false;
   return QD_OK;
 }
@@ -434,7 +457,8 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
     QD_HIP(launch_gmat(h->S, h->d_g0.p, h->d_onerow.p, h->cs, 1, h->d_gone.p, h->stream));
     Sone.gtab = h->d_gone.p;
   }
-  QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
+  if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
+  else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
   return QD_OK;
@@ -477,6 +501,7 @@ extern "C" int qd_set_penalty(qd_handle* h, const qd_penalty* pen) {
 
 int qd_handle::traj_doubles(int nb, size_t* n) const {
   *n = (size_t)(nsub + 1) * (size_t)nb * 2 * (size_t)S.dim;
+  if (precision == QD_PRECISION_F32MIXED) *n /= 2;  // float2 per element
   return QD_OK;
 }
 
@@ -507,6 +532,13 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
 }
 
 int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarget* tgp, double* energy) {
+  int r;
+  if ((r = forward_launch(dx0, nb, store, tgp))) return r;
+  return forward_finish(energy);
+}
+
+// enqueue the whole forward sweep (tables, kernel, objective pieces, asynchronous result download) on the handle's stream
+int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTarget* tgp) {
   QD_HIP(hipSetDevice(device));
   int r;
   if (pen.gamma_penalty > 1e-13 && pen.penalty_param > 1e-13 && !tgp)
@@ -542,21 +574,32 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
   if ((r = check_cfg(cfg))) return r;
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
-  QD_HIP(launch_forward(a, cfg, stream));
+  if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
+  else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));
   // every result of the sweep in one pinned buffer, one synchronisation
   if ((r = h_res.ensure((size_t)6 * nb + 1))) return r;
   QD_HIP(hipMemcpyAsync(h_res.p, d_res.p, sizeof(double) * (6 * (size_t)nb + 1), hipMemcpyDeviceToHost, stream));
+  last_nb = nb;
+  pending_store = store;
+  return QD_OK;
+}
+
+// wait for the sweep enqueued by forward_launch (and whatever the caller enqueued behind it) and collect its results
+int qd_handle::forward_finish(double* energy) {
+  const int nb = last_nb;
+  const bool store = pending_store;
   QD_HIP(hipStreamSynchronize(stream));
   unsigned long long nap = 0;
   std::memcpy(&nap, h_res.p + 6 * (size_t)nb, sizeof nap);
   float ms = 0.f;
   QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-  last_fwd_ms = ms;
+  last_fwd_ms = accumulate_fwd_ms ? last_fwd_ms + ms : ms;
   last_mean_applies = (double)nap / ((double)nb * (double)nsub);
   last_nb = nb;
   traj_valid = store;
+  pending_store = false;
   if (energy) *energy = energy_penalty_host();
   return QD_OK;
 }
@@ -595,13 +638,30 @@ extern "C" int qd_get_state(qd_handle* h, int timestep, double* x) {
   if (timestep < 0 || timestep > h->tg.ntime) return fail(QD_ERR_INVALID, "qd_get_state: time step out of range");
   QD_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)h->last_nb * 2 * h->S.dim;
+  if (h->precision == QD_PRECISION_F32MIXED) {  // stored as interleaved float2 per element
+    std::vector<float> tmp(n);
+    QD_HIP(hipMemcpy(tmp.data(), reinterpret_cast<const float*>(h->d_traj.p) + (size_t)timestep * h->nstages * n, sizeof(float) * n, hipMemcpyDeviceToHost));
+    const size_t dim = h->S.dim;
+    for (int b = 0; b < h->last_nb; b++)
+      for (size_t e = 0; e < dim; e++) {
+        x[(size_t)b * 2 * dim + e] = tmp[((size_t)b * dim + e) * 2];
+        x[(size_t)b * 2 * dim + dim + e] = tmp[((size_t)b * dim + e) * 2 + 1];
+      }
+    return QD_OK;
+  }
   QD_HIP(hipMemcpy(x, h->d_traj.p + (size_t)timestep * h->nstages * n, sizeof(double) * n, hipMemcpyDeviceToHost));
   return QD_OK;
 }
 
 int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, const DevTarget* tgp, bool accumulate) {
+  int r;
+  if ((r = adjoint_launch(dxbarT, djbar, nb, tgp, accumulate))) return r;
+  return adjoint_finish(accumulate);
+}
+
+int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb, const DevTarget* tgp, bool accumulate) {
   QD_HIP(hipSetDevice(device));
-  if (!traj_valid || last_nb != nb) return fail(QD_ERR_STATE, "qd_adjoint: needs a forward sweep of the same batch with store_trajectory=1");
+  if (!(traj_valid || pending_store) || last_nb != nb) return fail(QD_ERR_STATE, "qd_adjoint: needs a forward sweep of the same batch with store_trajectory=1");
   if (has_pipulse) return fail(QD_ERR_UNSUPPORTED, "qd_adjoint: derivative of pi-pulses is not implemented in the reference (src/oscillator.cpp:373-378)");
   int r;
   const size_t ncol = (size_t)nsub * 2 * S.Q;
@@ -621,14 +681,30 @@ int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, co
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
-  QD_HIP(hipEventRecord(ev0, stream));
-  QD_HIP(launch_adjoint(a, cfg, stream));
-  QD_HIP(hipEventRecord(ev1, stream));
+  QD_HIP(hipEventRecord(ev2, stream));
+  if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, stream));
+  else QD_HIP(launch_adjoint(a, cfg, stream));
+  QD_HIP(hipEventRecord(ev3, stream));
   QD_HIP(launch_reduce_coeff(d_coeff.p, nb, (int)ncol, d_coeffsum.p, accumulate ? 1 : 0, stream));
+  return QD_OK;
+}
+
+int qd_handle::adjoint_finish(bool accumulate) {
   QD_HIP(hipStreamSynchronize(stream));
   float ms = 0.f;
-  QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+  QD_HIP(hipEventElapsedTime(&ms, ev2, ev3));
   last_adj_ms = accumulate ? last_adj_ms + ms : ms;
+  // explicit Euler + Schroedinger: the kernel has replaced the stored forward states by the reference's backward
+  // recomputation chain (k_adjoint), so the buffer no longer is the forward trajectory
+  if (sol.stepper == QD_STEPPER_EE && !S.lindblad) traj_valid = false;
+  return QD_OK;
+}
+
+int qd_handle::gradient_launch(double ebar, double* dgrad) {
+  QD_HIP(hipSetDevice(device));
+  if (ndesign == 0) return QD_OK;
+  const int nsub_flag = sol.stepper == QD_STEPPER_EE ? -nsub : nsub;
+  QD_HIP(launch_grad(dctl, d_table.p, cs, nsub_flag, d_coeffsum.p, d_etable.p, tg.ntime, ebar, dgrad, ndesign, stream));
   return QD_OK;
 }
 
@@ -637,8 +713,7 @@ int qd_handle::gradient_from_coeffs(double ebar, double* grad) {
   int r;
   if (ndesign == 0) return QD_OK;
   if ((r = d_grad.ensure(ndesign))) return r;
-  const int nsub_flag = sol.stepper == QD_STEPPER_EE ? -nsub : nsub;
-  QD_HIP(launch_grad(dctl, d_table.p, cs, nsub_flag, d_coeffsum.p, d_etable.p, tg.ntime, ebar, d_grad.p, ndesign, stream));
+  if ((r = gradient_launch(ebar, d_grad.p))) return r;
   QD_HIP(hipMemcpyAsync(grad, d_grad.p, sizeof(double) * ndesign, hipMemcpyDeviceToHost, stream));
   QD_HIP(hipStreamSynchronize(stream));
   return QD_OK;
@@ -662,3 +737,32 @@ extern "C" int qd_adjoint(qd_handle* h, const double* xbarT, const double* jbar,
 extern "C" double qd_last_mean_applies(const qd_handle* h) { return h ? h->last_mean_applies : 0.0; }
 extern "C" double qd_last_forward_ms(const qd_handle* h) { return h ? h->last_fwd_ms : 0.0; }
 extern "C" double qd_last_adjoint_ms(const qd_handle* h) { return h ? h->last_adj_ms : 0.0; }
+
+// Measurement hook ("settle the MFMA question"): nrep chained applications of the forward operator
+// to nb copies... of a batch of states with the fp32 stencil kernel (mfma = 0) or with the dense Kronecker-factor
+// product on the fp32 matrix cores (mfma = 1; 2^5 Lindblad only).  y receives the result of the chain, *ms the device time.
+extern "C" int qd_bench_apply_f32(qd_handle* h, double t, const double* x, double* y, int nb, int nrep, int mfma, double* ms) {
+  if (!h || !x || !y || nb < 1 || nrep < 1 || !ms) return fail(QD_ERR_INVALID, "qd_bench_apply_f32: bad argument");
+  const DevSys& S = h->S;
+  bool qubits = S.lindblad && !S.dense && !S.hasJ && (S.Q == 4 || S.Q == 5);
+  for (int k = 0; k < S.Q; k++) qubits = qubits && S.n[k] == 2;
+  if (!qubits || (mfma && S.Q != 5)) return fail(QD_ERR_UNSUPPORTED, "qd_bench_apply_f32: all-qubit Lindblad systems with 4 or 5 oscillators (MFMA: 5)");
+  QD_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)nb * 2 * S.dim;
+  int r;
+  if ((r = h->d_x0.ensure(n)) || (r = h->d_y.ensure(n))) return r;
+  const double tt[2] = {t, 0.0};
+  QD_HIP(hipMemcpyAsync(h->d_onetime.p, tt, sizeof tt, hipMemcpyHostToDevice, h->stream));
+  QD_HIP(launch_controls(h->dctl, h->d_params.p, h->d_onetime.p, h->d_onetime.p + 1, 1, h->d_onerow.p, h->cs, h->stream));
+  QD_HIP(hipMemcpyAsync(h->d_x0.p, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  QD_HIP(launch_apply_f32(S, h->d_onerow.p, 0, h->d_x0.p, h->d_y.p, nb, nrep, mfma, h->stream));  // warm-up
+  QD_HIP(hipEventRecord(h->ev0, h->stream));
+  QD_HIP(launch_apply_f32(S, h->d_onerow.p, 0, h->d_x0.p, h->d_y.p, nb, nrep, mfma, h->stream));
+  QD_HIP(hipEventRecord(h->ev1, h->stream));
+  QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  QD_HIP(hipStreamSynchronize(h->stream));
+  float m = 0.f;
+  QD_HIP(hipEventElapsedTime(&m, h->ev0, h->ev1));
+  *ms = m;
+  return QD_OK;
+}

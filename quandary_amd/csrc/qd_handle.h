@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "qd_internal.h"
 
 #define QD_HIP(expr)                                                                                   \
@@ -64,8 +66,9 @@ struct HBuf {
 
 struct qd_handle {
   int device = 0;
+  int precision = QD_PRECISION_F64;  // qd_set_precision
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // forward / adjoint kernel brackets
   qd::DevSys S{};
   qd_time tg{};
   qd_solver sol{};
@@ -105,12 +108,21 @@ struct qd_handle {
   int last_nb = 0;
   bool traj_valid = false;
   double last_mean_applies = 0.0, last_fwd_ms = 0.0, last_adj_ms = 0.0;
+  bool accumulate_fwd_ms = false;  // chunked re-propagation (qd_optim_adjoint_local): add the chunks' forward times up
 
   // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
   int refresh_tables();
   int traj_doubles(int nb, size_t* n) const;
   // forward sweep on device-resident states; results stay on the device (d_pen, d_dpdm, d_xT, d_out4)
   int forward_dev(const double* dx0, int nb, bool store, const qd::DevTarget* tg, double* energy);
+  // the same in two halves: enqueue only / synchronise and collect (lets the caller queue the reductions, the adjoint
+  // sweep and the collectives behind the forward sweep without a host round trip)
+  int forward_launch(const double* dx0, int nb, bool store, const qd::DevTarget* tg);
+  int forward_finish(double* energy);
+  int adjoint_launch(const double* dxbarT, const double* djbar, int nb, const qd::DevTarget* tg, bool accumulate);
+  int adjoint_finish(bool accumulate);
+  int gradient_launch(double ebar, double* dgrad);  // k_grad into a device buffer [ndesign]
+  bool pending_store = false;
   // adjoint sweep; dxbarT/djbar device pointers; coefficient sums accumulate into d_coeffsum
   int adjoint_dev(const double* dxbarT, const double* djbar, int nb, const qd::DevTarget* tg, bool accumulate);
   // gradient from d_coeffsum (+ energy term ebar); writes host grad[ndesign]
@@ -120,3 +132,13 @@ struct qd_handle {
   const double* res_dpdm() const { return h_res.p + last_nb; }
   const double* res_out4() const { return h_res.p + 2 * (size_t)last_nb; }
 };
+
+// RCCL communicator (qd_comm.cpp): one per process / GPU
+struct qd_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1, device = 0;
+  hipStream_t stream = nullptr;  // for the host-staged convenience calls; the sweeps reduce on the handle's stream
+  qd::DBuf dbuf;
+};
+// in-place all-reduce of a device buffer on stream `st` (op 0 = sum, 1 = max); asynchronous
+int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_t st);

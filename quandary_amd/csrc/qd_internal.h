@@ -109,9 +109,17 @@ hipError_t launch_gmat(const DevSys& S, const double* g0, const double* table, i
 hipError_t launch_objective(const DevSys& S, const DevTarget& tg, const double* x, int nb, double* out4, hipStream_t st);
 hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, const double* rbar_ibar, int nb, double* xbar,
                        hipStream_t st);
+hipError_t launch_partial_sums(const double* res, int nb, const double* w, double inv_ninit, const qd_penalty& pen, const double* etable,
+                               int cs, int Q, int nstep, double* sums, hipStream_t st);
+hipError_t launch_seed_weights(const double* sums, const double* w, int nb, int objective_type, int lindblad, double* rbib, hipStream_t st);
 hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st);
 hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
+// fp32-mixed sweeps of all-qubit Lindblad systems (qd_q32.hip); the trajectory is [nsub+1][nb][dim] float2
+hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st);
+hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st);
+hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
+                            hipStream_t st);
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false, bool adjoint = false);
 size_t krylov_doubles(const DevSys& S, int nb);
 int variant_max_block(int var);  // 0 for an unknown variant  // size of SweepArgs::kry for LaunchCfg::gmres == 2

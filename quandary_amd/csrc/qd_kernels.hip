@@ -226,6 +226,72 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// objective level on the device (multi-GPU path: nothing returns to the host between the sweeps and the collectives)
+// ---------------------------------------------------------------------------------------------
+// The seven partial sums the reference all-reduces over comm_init (src/optimproblem.cpp:258-298) from the per-state
+// results of the forward sweep `res` = [pen nb | dpdm nb | (J_re, J_im, fid_re, fid_im) nb]; the energy penalty
+// (src/timestepper.cpp:444-455) from the table of controls at the step ends.  One workgroup, fixed summation order.
+__global__ void __launch_bounds__(256) k_partial_sums(const double* __restrict__ res, int nb, const double* __restrict__ w, double inv_ninit,
+                                                      qd_penalty pen, const double* __restrict__ etable, int cs, int Q, int nstep,
+                                                      double* __restrict__ sums) {
+  __shared__ double red[8][4];
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const double* pn = res;
+  const double* dp = res + nb;
+  const double* o4 = res + 2 * (size_t)nb;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    const double wi = w[i];
+    if (pen.gamma_penalty > 1e-13) v[QD_SUM_PENALTY] += wi * pen.gamma_penalty * pn[i];
+    if (pen.gamma_penalty_dpdm > 1e-13) v[QD_SUM_DPDM] += wi * pen.gamma_penalty_dpdm * dp[i];
+    v[7] += wi;  // the energy integral is state independent: weight sum x gamma x E
+    v[QD_SUM_COST_RE] += wi * o4[4 * i];
+    v[QD_SUM_COST_IM] += wi * o4[4 * i + 1];
+    v[QD_SUM_FID_RE] += inv_ninit * o4[4 * i + 2];
+    v[QD_SUM_FID_IM] += inv_ninit * o4[4 * i + 3];
+  }
+  double e = 0.0;
+  if (pen.gamma_penalty_energy > 1e-13)
+    for (int n = threadIdx.x; n < nstep; n += 256) {
+      const double* row = etable + (size_t)n * cs;
+      double a = 0.0;
+      for (int k = 0; k < Q; k++) a += row[2 + k] * row[2 + k] + row[2 + Q + k] * row[2 + Q + k];
+      e += a / nstep;
+    }
+  v[QD_SUM_ENERGY] = e;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    v[i] = wave_sum(v[i]);
+    if (lane == 0) red[i][wave] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x;
+    red[i][0] = (red[i][0] + red[i][1]) + (red[i][2] + red[i][3]);
+  }
+  __syncthreads();
+  if (threadIdx.x < QD_NSUMS) {
+    const int i = threadIdx.x;
+    sums[i] = i == QD_SUM_ENERGY ? pen.gamma_penalty_energy * red[7][0] * red[QD_SUM_ENERGY][0] : red[i][0];
+  }
+}
+
+// adjoint seed weights beta_i * finalizeJ_diff(GLOBAL cost) (src/optimproblem.cpp:433-436, :508-511; finalizeJ_diff
+// src/optimtarget.cpp:880-897): only Schroedinger + Jtrace depends on the reduced sums
+__global__ void k_seed_weights(const double* __restrict__ sums, const double* __restrict__ w, int nb, int objective_type, int lindblad,
+                               double* __restrict__ rbib) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  double rb = 1.0, ib = 0.0;
+  if (objective_type == QD_OBJ_JTRACE) {
+    if (lindblad) rb = -1.0;
+    else { rb = -2.0 * sums[QD_SUM_COST_RE]; ib = -2.0 * sums[QD_SUM_COST_IM]; }
+  }
+  rbib[2 * i] = w[i] * rb;
+  rbib[2 * i + 1] = w[i] * ib;
+}
+
+// ---------------------------------------------------------------------------------------------
 // dense user-Hamiltonian path: G(t_row) = -i Hsys + sum_k q_k Im(Hc_k) - i p_k Re(Hc_k) for every row of
 // the control table (Re = Ad + sum q_k Ac_k, Im = Bd + sum p_k Bc_k with Ac = Im(Hc), Bc = -Re(Hc):
 // src/mastereq.cpp:760-795, src/hamiltonianfilereader.cpp:77-84,170-176)
@@ -404,6 +470,17 @@ hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, co
                        hipStream_t st) {
   if (S.lindblad) hipLaunchKernelGGL(k_seed<true>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
   else hipLaunchKernelGGL(k_seed<false>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
+  return hipGetLastError();
+}
+
+hipError_t launch_partial_sums(const double* res, int nb, const double* w, double inv_ninit, const qd_penalty& pen, const double* etable,
+                               int cs, int Q, int nstep, double* sums, hipStream_t st) {
+  hipLaunchKernelGGL(k_partial_sums, dim3(1), dim3(256), 0, st, res, nb, w, inv_ninit, pen, etable, cs, Q, nstep, sums);
+  return hipGetLastError();
+}
+
+hipError_t launch_seed_weights(const double* sums, const double* w, int nb, int objective_type, int lindblad, double* rbib, hipStream_t st) {
+  hipLaunchKernelGGL(k_seed_weights, dim3((nb + 127) / 128), dim3(128), 0, st, sums, w, nb, objective_type, lindblad, rbib);
   return hipGetLastError();
 }
 

@@ -26,10 +26,13 @@ struct qd_optim {
   std::vector<cplx> V;                           // rotated + lifted gate V_f (N x N row-major)
   std::vector<double> weights;                   // beta_i, normalised, global
   std::vector<double> alpha0;
-  double gamma_tik = 0.0, gamma_var = 0.0;
+  double gamma_tik = 0.0, gamma_var = 0.0, ebar = 0.0;
   qd_penalty pen{};
   // device-resident batch
   DBuf d_x0, d_tgt, d_pur, d_rbib, d_jbar, d_xbar;
+  DBuf d_w, d_red;   // multi-GPU path: beta_i of the local shard; [7 sums | ndesign gradient] reduced in place by RCCL
+  HBuf h_red;
+  hipEvent_t evr[4] = {nullptr, nullptr, nullptr, nullptr};  // brackets of the two collectives
   DevTarget tg{};
   std::vector<int> init_id;  // output-file ids of the local initial conditions
   // state between forward_local and adjoint_local
@@ -230,7 +233,10 @@ static void fill_from_file(const qd_handle* h, const double* data, std::vector<d
 extern "C" void qd_optim_destroy(qd_optim* o) {
   if (!o) return;
   (void)hipSetDevice(o->h->device);
-  for (DBuf* b : {&o->d_x0, &o->d_tgt, &o->d_pur, &o->d_rbib, &o->d_jbar, &o->d_xbar}) b->release();
+  for (DBuf* b : {&o->d_x0, &o->d_tgt, &o->d_pur, &o->d_rbib, &o->d_jbar, &o->d_xbar, &o->d_w, &o->d_red}) b->release();
+  o->h_red.release();
+  for (hipEvent_t e : o->evr)
+    if (e) (void)hipEventDestroy(e);
   delete o;
 }
 
@@ -258,6 +264,13 @@ extern "C" int qd_optim_create(qd_handle* h, const qd_objective* ob, int rank, i
   }
   if (ob->n_init_ids < 0 || ob->n_init_ids > QD_MAX_OSC) return bail(QD_ERR_INVALID, "qd_optim_create: bad n_init_ids");
   for (int i = 0; i < ob->n_init_ids; i++) o->init_ids.push_back(ob->init_ids[i]);
+  if (ob->initcond_type == QD_INIT_DIAGONAL || ob->initcond_type == QD_INIT_BASIS || ob->initcond_type == QD_INIT_ENSEMBLE) {
+    // oscillator ids: in range and consecutive, as the reference asserts (src/main.cpp:100-104, src/optimtarget.cpp:138-141)
+    for (size_t i = 0; i < o->init_ids.size(); i++) {
+      if (o->init_ids[i] < 0 || o->init_ids[i] >= S.Q) return bail(QD_ERR_INVALID, "qd_optim_create: initial-condition oscillator id out of range");
+      if (i > 0 && o->init_ids[i] != o->init_ids[i - 1] + 1) return bail(QD_ERR_INVALID, "qd_optim_create: initial-condition oscillator ids must be consecutive");
+    }
+  }
   // number of initial conditions (src/main.cpp:89-128)
   switch (ob->initcond_type) {
     case QD_INIT_FROMFILE: case QD_INIT_PURE: case QD_INIT_PERFORMANCE: case QD_INIT_ENSEMBLE: o->ninit = 1; break;
@@ -266,8 +279,7 @@ extern "C" int qd_optim_create(qd_handle* h, const qd_objective* ob, int rank, i
     case QD_INIT_DIAGONAL: case QD_INIT_BASIS: {
       if (o->init_ids.empty()) return bail(QD_ERR_INVALID, "qd_optim_create: diagonal/basis need oscillator ids");
       int ni = 1;
-      for (int v : o->init_ids)
-        if (v < S.Q) ni *= S.ness[v];
+      for (int v : o->init_ids) ni *= S.ness[v];
       if (ob->initcond_type == QD_INIT_BASIS && S.lindblad) ni *= ni;
       o->ninit = ni;
       break;
@@ -380,6 +392,24 @@ extern "C" int qd_optim_create(qd_handle* h, const qd_objective* ob, int rank, i
     if ((r = o->d_rbib.ensure((size_t)2 * o->nlocal)) || (r = o->d_jbar.ensure((size_t)3 * o->nlocal)) ||
         (r = o->d_xbar.ensure(x0.size())))
       return r;
+    // multi-GPU path: local weights, reduction buffer [7 sums | gradient], event brackets of the collectives
+    if ((r = o->d_w.ensure(o->nlocal)) || (r = o->d_red.ensure((size_t)QD_NSUMS + 1 + h->ndesign)) ||
+        (r = o->h_red.ensure((size_t)QD_NSUMS + 1 + h->ndesign)))
+      return r;
+    QD_HIP(hipMemcpy(o->d_w.p, o->weights.data() + o->first, sizeof(double) * o->nlocal, hipMemcpyHostToDevice));
+    {  // Jbar_penalty, Jbar_penalty_dpdm, Jbar_energy_penalty of solveAdjointODE per local initial condition (src/optimproblem.cpp:514-519)
+      std::vector<double> jbar((size_t)3 * o->nlocal);
+      o->ebar = 0.0;
+      for (int i = 0; i < o->nlocal; i++) {
+        const double w = o->weights[o->first + i];
+        jbar[3 * i] = w * o->pen.gamma_penalty;
+        jbar[3 * i + 1] = w * o->pen.gamma_penalty_dpdm;
+        jbar[3 * i + 2] = w * o->pen.gamma_penalty_energy;
+        if (o->pen.gamma_penalty_energy > 1e-13) o->ebar += jbar[3 * i + 2];
+      }
+      QD_HIP(hipMemcpy(o->d_jbar.p, jbar.data(), sizeof(double) * jbar.size(), hipMemcpyHostToDevice));
+    }
+    for (hipEvent_t& e : o->evr) QD_HIP(hipEventCreate(&e));
     return QD_OK;
   };
   rc = dev();
@@ -490,6 +520,13 @@ static bool trajectory_fits(qd_handle* h, int nb) {
   return (double)need * sizeof(double) < 0.85 * (double)avail;
 }
 
+struct PenaltyScope {
+  qd_handle* h;
+  qd_penalty saved;
+  PenaltyScope(qd_handle* hh, const qd_penalty& p) : h(hh), saved(hh->pen) { h->pen = p; }
+  ~PenaltyScope() { h->pen = saved; }
+};
+
 static DevTarget shifted_target(const qd_optim* o, int offset) {
   DevTarget t = o->tg;
   if (t.tstates) t.tstates += (size_t)offset * 2 * o->h->S.dim;
@@ -502,13 +539,15 @@ extern "C" int qd_optim_forward_local(qd_optim* o, const double* alpha, int stor
   qd_handle* h = o->h;
   QD_HIP(hipSetDevice(h->device));
   int r;
-  h->pen = o->pen;
   if ((r = qd_set_params(h, alpha, h->ndesign))) return r;
   o->last_alpha.assign(alpha, alpha + h->ndesign);
   const int nl = o->nlocal;
   bool store = store_trajectory != 0 && trajectory_fits(h, nl);
   double energy = 0.0;
-  if ((r = h->forward_dev(o->d_x0.p, nl, store, &o->tg, &energy))) return r;
+  {
+    PenaltyScope ps(h, o->pen);  // the objective's penalty block, for this call only (operator-level calls keep theirs)
+    if ((r = h->forward_dev(o->d_x0.p, nl, store, &o->tg, &energy))) return r;
+  }
   o->stored = store;
   o->forward_done = true;
   const double *pen = h->res_pen(), *dpdm = h->res_dpdm(), *o4 = h->res_out4();  // pinned, downloaded with the sweep
@@ -556,6 +595,7 @@ extern "C" int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const do
   const int nl = o->nlocal, nd = h->ndesign;
   const size_t n2 = (size_t)2 * h->S.dim;
   int r;
+  PenaltyScope ps(h, o->pen);
   // adjoint seeds from the GLOBAL cost (src/optimproblem.cpp:433-436, :508-511)
   double rb, ib;
   finalize_J_diff(o, sums[QD_SUM_COST_RE], sums[QD_SUM_COST_IM], &rb, &ib);
@@ -585,7 +625,10 @@ extern "C" int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const do
     for (int off = 0; off < nl; off += chunk) {
       const int nc = std::min(chunk, nl - off);
       DevTarget t = shifted_target(o, off);
-      if ((r = h->forward_dev(o->d_x0.p + (size_t)off * n2, nc, true, &t, nullptr))) return r;
+      h->accumulate_fwd_ms = true;  // last_fwd_ms = the first sweep + every chunk's re-propagation
+      r = h->forward_dev(o->d_x0.p + (size_t)off * n2, nc, true, &t, nullptr);
+      h->accumulate_fwd_ms = false;
+      if (r) return r;
       QD_HIP(launch_seed(h->S, t, h->d_xT.p, o->d_rbib.p + (size_t)2 * off, nc, o->d_xbar.p, h->stream));
       if ((r = h->adjoint_dev(o->d_xbar.p, o->d_jbar.p + (size_t)3 * off, nc, &t, !first))) return r;
       first = false;
@@ -616,4 +659,109 @@ extern "C" int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective
   if ((r = qd_optim_forward_local(o, alpha, 1, sums))) return r;
   if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
   return qd_optim_adjoint_local(o, alpha, sums, grad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU evalF / evalGradF: one process per GPU, this rank's shard, RCCL reductions on the handle's stream.
+// Everything between the forward sweep and the last collective stays in HBM: the partial sums are formed by
+// k_partial_sums, reduced in place by ncclAllReduce, turned into seed weights by k_seed_weights; the gradient is
+// reduced in the buffer k_grad wrote it to.  The reference's two collectives (src/optimproblem.cpp:454-460 before the
+// adjoint seeds, :527 after the sweep) are needed as two only for Schroedinger + Jtrace (:495-511); everywhere else
+// the seed does not depend on the reduced cost (finalizeJ_diff is constant, src/optimtarget.cpp:889-895) and sums and
+// gradient travel in ONE all-reduce of 7 + ndesign doubles.  One host synchronisation per evaluation.
+// ---------------------------------------------------------------------------------------------------------------
+static int dist_finish(qd_optim* o, const double* alpha, bool grad_mode, qd_objective_value* val, double* grad, double* allreduce_ms) {
+  qd_handle* h = o->h;
+  const int nd = h->ndesign;
+  QD_HIP(hipMemcpyAsync(o->h_red.p, o->d_red.p, sizeof(double) * (QD_NSUMS + (grad_mode ? nd : 0)), hipMemcpyDeviceToHost, h->stream));
+  int r;
+  if ((r = h->forward_finish(nullptr))) return r;  // the one synchronisation
+  if (grad_mode && (r = h->adjoint_finish(false))) return r;
+  if (allreduce_ms) {
+    float a = 0.f, b = 0.f;
+    QD_HIP(hipEventElapsedTime(&a, o->evr[0], o->evr[1]));
+    if (grad_mode) QD_HIP(hipEventElapsedTime(&b, o->evr[2], o->evr[3]));
+    allreduce_ms[0] = a;
+    allreduce_ms[1] = b;
+  }
+  if ((r = qd_optim_finalize(o, alpha, o->h_red.p, val))) return r;
+  if (grad_mode) {
+    for (int i = 0; i < nd; i++) grad[i] = o->h_red.p[QD_NSUMS + i];
+    // Tikhonov / variation terms: the reference adds them on rank 0 before the reduction (src/optimproblem.cpp:356-372);
+    // adding them on every rank after it gives every rank the same complete gradient
+    for (int i = 0; i < nd; i++) grad[i] += o->gamma_tik * (alpha[i] - (o->alpha0.empty() ? 0.0 : o->alpha0[i]));
+    control_variation(h, alpha, grad, 0.5 * o->gamma_var);
+  }
+  return QD_OK;
+}
+
+static int dist_forward(qd_optim* o, qd_comm* c, const double* alpha, bool store) {
+  qd_handle* h = o->h;
+  int r;
+  if ((r = qd_set_params(h, alpha, h->ndesign))) return r;
+  o->last_alpha.assign(alpha, alpha + h->ndesign);
+  if ((r = h->forward_launch(o->d_x0.p, o->nlocal, store, &o->tg))) return r;
+  QD_HIP(launch_partial_sums(h->d_res.p, o->nlocal, o->d_w.p, 1.0 / o->ninit, o->pen, h->d_etable.p, h->cs, h->S.Q, h->tg.ntime,
+                             o->d_red.p, h->stream));
+  o->stored = store;
+  o->forward_done = true;
+  (void)c;
+  return QD_OK;
+}
+
+extern "C" int qd_optim_evalF_dist(qd_optim* o, qd_comm* c, const double* alpha, qd_objective_value* val, double* allreduce_ms) {
+  if (!o || !c || !val || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_evalF_dist: null argument");
+  if (c->nranks != o->nranks || c->rank != o->rank) return fail(QD_ERR_INVALID, "qd_optim_evalF_dist: communicator and objective disagree on rank / nranks");
+  qd_handle* h = o->h;
+  QD_HIP(hipSetDevice(h->device));
+  PenaltyScope ps(h, o->pen);
+  int r;
+  if ((r = dist_forward(o, c, alpha, false))) return r;
+  QD_HIP(hipEventRecord(o->evr[0], h->stream));
+  if ((r = qd_comm_allreduce_dev(c, o->d_red.p, QD_NSUMS, 0, h->stream))) return r;
+  QD_HIP(hipEventRecord(o->evr[1], h->stream));
+  return dist_finish(o, alpha, false, val, nullptr, allreduce_ms);
+}
+
+extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* alpha, qd_objective_value* val, double* grad, double* allreduce_ms) {
+  if (!o || !c || !val || !grad || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_evalGradF_dist: null argument");
+  if (c->nranks != o->nranks || c->rank != o->rank) return fail(QD_ERR_INVALID, "qd_optim_evalGradF_dist: communicator and objective disagree on rank / nranks");
+  qd_handle* h = o->h;
+  QD_HIP(hipSetDevice(h->device));
+  PenaltyScope ps(h, o->pen);
+  const int nl = o->nlocal, nd = h->ndesign;
+  int r;
+  if (!trajectory_fits(h, nl)) {
+    // the shard's trajectory exceeds HBM: host-staged path (chunked re-propagation), collectives through the same communicator
+    double sums[QD_NSUMS];
+    if ((r = qd_optim_forward_local(o, alpha, 0, sums))) return r;
+    if ((r = qd_comm_allreduce(c, sums, QD_NSUMS, 0))) return r;
+    if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
+    const int rank_keep = o->rank;
+    o->rank = 1;  // regularisation is added once, after the reduction
+    r = qd_optim_adjoint_local(o, alpha, sums, grad);
+    o->rank = rank_keep;
+    if (r) return r;
+    if ((r = qd_comm_allreduce(c, grad, nd, 0))) return r;
+    for (int i = 0; i < nd; i++) grad[i] += o->gamma_tik * (alpha[i] - (o->alpha0.empty() ? 0.0 : o->alpha0[i]));
+    control_variation(h, alpha, grad, 0.5 * o->gamma_var);
+    if (allreduce_ms) allreduce_ms[0] = allreduce_ms[1] = 0.0;
+    return QD_OK;
+  }
+  if ((r = dist_forward(o, c, alpha, true))) return r;
+  const bool two = !h->S.lindblad && o->objective_type == QD_OBJ_JTRACE;  // seeds need the GLOBAL cost
+  QD_HIP(hipEventRecord(o->evr[0], h->stream));
+  if (two && (r = qd_comm_allreduce_dev(c, o->d_red.p, QD_NSUMS, 0, h->stream))) return r;
+  QD_HIP(hipEventRecord(o->evr[1], h->stream));
+  QD_HIP(launch_seed_weights(o->d_red.p, o->d_w.p, nl, o->objective_type, h->S.lindblad, o->d_rbib.p, h->stream));
+  // (d_jbar = beta_i x penalty coefficients: constants of the objective, resident since qd_optim_create)
+  QD_HIP(launch_seed(h->S, o->tg, h->d_xT.p, o->d_rbib.p, nl, o->d_xbar.p, h->stream));
+  if ((r = h->adjoint_launch(o->d_xbar.p, o->d_jbar.p, nl, &o->tg, false))) return r;
+  if ((r = h->gradient_launch(o->ebar, o->d_red.p + QD_NSUMS))) return r;
+  QD_HIP(hipEventRecord(o->evr[2], h->stream));
+  if (two) r = qd_comm_allreduce_dev(c, o->d_red.p + QD_NSUMS, nd, 0, h->stream);
+  else r = qd_comm_allreduce_dev(c, o->d_red.p, (size_t)QD_NSUMS + nd, 0, h->stream);
+  if (r) return r;
+  QD_HIP(hipEventRecord(o->evr[3], h->stream));
+  return dist_finish(o, alpha, true, val, grad, allreduce_ms);
 }

@@ -1,0 +1,700 @@
+// qd_q32.hip — fp32-mixed sweeps for all-qubit Lindblad systems (BASELINE config 5: 2^5 Lindblad, superoperator
+// dimension 1024, 1024 initial conditions; also the 4-qubit open system).  gfx950 / CDNA4 only.
+//
+// What is fp32 and what is fp64 (QD_PRECISION_F32MIXED, include/quandary_amd.h):
+//   fp32  the exchange vector in LDS (float2 per element: one ds_read_b64 per neighbour, half the LDS bytes and half
+//         the LDS footprint of the fp64 kernels), the stencil arithmetic y = M x / M^T x, the linear-solver iterates
+//         and right-hand sides, the stored trajectory (8 dim bytes per state instead of 16 dim);
+//   fp64  the state x_n and the adjoint state xbar_n themselves (register accumulators: x += h k is an fp64 add of an
+//         fp32 increment, so rounding does not accumulate over the time loop), objective / penalty sums, gradient
+//         coefficients and everything downstream of them (k_reduce_coeff, k_grad, k_objective, k_seed).
+//   The squared update norm of the Neumann iteration is only compared with a threshold and is reduced in fp32 (as in
+//   the fp64 kernels).  fp32 iterates cannot reach the reference's abstol = 1e-10 (timestepper.cpp:536), so the
+//   iteration additionally stops once the update is at the fp32 resolution of the right-hand side:
+//   ||y_{m+1} - y_m|| <= max(abstol, 2^-22 ||b||).
+//
+// Element -> thread map (the slot layout of QubitSlotStencil, qd_device.h): it = tid | j << TB, EPT = 2^SB slots per
+// thread, the slot number is the ket digits of oscillators 0 .. SB-1.  Digit signs, T1 validity and LDS offsets are
+// thread invariants or compile-time constants; the ket neighbours of the slot oscillators are the thread's own slots.
+//
+// Reference semantics (paths relative to the reference repository): stencil include/mastereq.hpp:316-912 as
+// instantiated for two-level systems (src/mastereq.cpp:2412-2893), IMR forward / adjoint src/timestepper.cpp:584-694,
+// Neumann :697-727, time loops :96-253, weighted-J penalty :256-339, gradient coefficients include/mastereq.hpp:553-604.
+#include <hip/hip_runtime.h>
+
+#include "qd_device.h"
+
+namespace qd {
+
+typedef float2 f2;
+
+constexpr float F32_SOLVER_TOL = 2.384185791015625e-07f;  // 2^-22
+
+template <int Q, int SB>
+struct Q32 {
+  static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
+  static constexpr bool ONEWAVE = NT == 64;
+  static constexpr int MINW = 4 * NT / 256 > 0 ? 4 * NT / 256 : 1;  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
+  static constexpr unsigned SLOT_BYTES = 8u << TB;  // LDS distance of consecutive slots (float2 elements)
+  static_assert(NT >= 64 && NT <= 1024, "block size");
+
+  __device__ static constexpr int brabit(int k) { return Q - 1 - k; }
+  __device__ static constexpr int ketbit(int k) { return 2 * Q - 1 - k; }
+  __device__ static constexpr int slotbit(int j, int k) { return (j >> (SB - 1 - k)) & 1; }  // ket digit of oscillator k < SB in slot j
+  __device__ static constexpr int slotflip(int j, int k) { return j ^ (1 << (SB - 1 - k)); }
+
+  float dw[EPT], dd[EPT];        // Delta = h(I) - h(I'), d = L2 + L1diag (mastereq.hpp:316-433)
+  unsigned ab[Q], ak[Q], al[Q];  // byte offsets (slot 0) of the bra / ket (k >= SB) / T1 neighbour of oscillator k
+  float l1f[Q], l1t[Q];          // thread part of the T1 off-diagonal coefficient, forward / transposed
+  float qb[Q], qk[Q];            // q_k with the sign of the bra / ket (k >= SB) digit of this thread [per step]
+  float p[Q], q[Q];              // controls of the current sub-step (wave-uniform)
+
+  __device__ __forceinline__ void init(const DevSys& S) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int it = (int)(tid | ((unsigned)j << TB));
+      double hd = 0.0, hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int a = (it >> brabit(k)) & 1, ap = (it >> ketbit(k)) & 1;
+        hd += S.detune[k] * a;  // the self-Kerr term a(a-1) vanishes for two levels
+        hdp += S.detune[k] * ap;
+        d += S.g2[k] * (a * ap - 0.5 * (a + ap)) - S.g1[k] / 2.0 * (a + ap);
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          const int b = (it >> brabit(l)) & 1, bp = (it >> ketbit(l)) & 1;
+          hd -= S.xikl[pair] * a * b;
+          hdp -= S.xikl[pair] * ap * bp;
+          pair++;
+        }
+      }
+      dw[j] = (float)(hd - hdp);  // differences formed in fp64, rounded once
+      dd[j] = (float)d;
+    }
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const unsigned bb = 1u << brabit(k), kb = 1u << ketbit(k);
+      ab[k] = (tid ^ bb) << 3;
+      ak[k] = k >= SB ? (tid ^ kb) << 3 : 0u;
+      al[k] = k >= SB ? (tid ^ bb ^ kb) << 3 : ab[k];
+      const bool bra0 = (tid & bb) == 0;
+      if (k >= SB) {
+        const bool ket0 = (tid & kb) == 0;
+        l1f[k] = (bra0 && ket0) ? (float)S.g1off[k] : 0.f;
+        l1t[k] = (!bra0 && !ket0) ? (float)S.g1off[k] : 0.f;
+      } else {  // the ket digit is a slot bit: only the bra condition is a thread property
+        l1f[k] = bra0 ? (float)S.g1off[k] : 0.f;
+        l1t[k] = !bra0 ? (float)S.g1off[k] : 0.f;
+      }
+      qb[k] = qk[k] = p[k] = q[k] = 0.f;
+    }
+  }
+
+  // once per sub-step: controls as wave-uniform floats, digit signs folded into q
+  __device__ __forceinline__ void prep(const StepC<Q>& c) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      p[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.p[k])));
+      q[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.q[k])));
+      qb[k] = ((tid >> brabit(k)) & 1) ? -q[k] : q[k];
+      if (k >= SB) qk[k] = ((tid >> ketbit(k)) & 1) ? -q[k] : q[k];
+    }
+  }
+
+  __device__ __forceinline__ static f2 at(const f2* __restrict__ sx, unsigned byteoff, int slot) {
+    return *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(sx) + byteoff + (unsigned)slot * SLOT_BYTES);
+  }
+
+  // y = M x (TRANS = false) or M^T x at slot j; see QubitSlotStencil::apply for the derivation
+  template <bool TRANS>
+  __device__ __forceinline__ f2 apply(const f2* __restrict__ sx, int j, const f2 (&xall)[EPT]) const {
+    const f2 xs = xall[j];
+    float hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0.f, gi = 0.f;
+    float l1r = 0.f, l1i = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const f2 xb = at(sx, ab[k], j);
+      f2 xk;
+      float sqk;
+      if (k < SB) {  // ket neighbour = own slot with the slot bit flipped; the sign of the slot bit is a constant
+        xk = xall[slotflip(j, k)];
+        sqk = slotbit(j, k) ? -q[k] : q[k];
+      } else {
+        xk = at(sx, ak[k], j);
+        sqk = qk[k];
+      }
+      float& ar = (k & 1) ? gr : hr;
+      float& ai = (k & 1) ? gi : hi;
+      ar = fmaf(qb[k], xb.x, ar);
+      ai = fmaf(qb[k], xb.y, ai);
+      ar = fmaf(sqk, xk.x, ar);
+      ai = fmaf(sqk, xk.y, ai);
+      ar = fmaf(p[k], xb.y, ar);
+      ai = fmaf(-p[k], xb.x, ai);
+      ar = fmaf(-p[k], xk.y, ar);
+      ai = fmaf(p[k], xk.x, ai);
+      // T1 off-diagonal: forward needs both digits 0 (the neighbour has both set), transposed both 1
+      const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
+      if (slot_ok) {
+        const f2 xl = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+        const float l1 = TRANS ? l1t[k] : l1f[k];
+        l1r = fmaf(l1, xl.x, l1r);
+        l1i = fmaf(l1, xl.y, l1i);
+      }
+    }
+    hr += gr;
+    hi += gi;
+    f2 y;
+    y.x = fmaf(dd[j], xs.x, TRANS ? -hr : hr) + l1r;
+    y.y = fmaf(dd[j], xs.y, TRANS ? -hi : hi) + l1i;
+    return y;
+  }
+
+  // gradient contraction: A = s_b x_b + s_k x_k, B = x_b - x_k (QubitStencil::ladder), all from LDS
+  __device__ __forceinline__ void ladder(const f2* __restrict__ sx, int k, int j, f2& A, f2& B) const {
+    const unsigned it = threadIdx.x | ((unsigned)j << TB);
+    const f2 xb = sx[it ^ (1u << brabit(k))], xk = sx[it ^ (1u << ketbit(k))];
+    const bool a = (it >> brabit(k)) & 1, ap = (it >> ketbit(k)) & 1;
+    A.x = (a ? -xb.x : xb.x) + (ap ? -xk.x : xk.x);
+    A.y = (a ? -xb.y : xb.y) + (ap ? -xk.y : xk.y);
+    B.x = xb.x - xk.x;
+    B.y = xb.y - xk.y;
+  }
+};
+
+// per-workgroup state of the fp32 sweeps: LDS exchange buffers, reduction scratch, the Neumann solver
+template <int Q, int SB>
+struct Team32 {
+  typedef Q32<Q, SB> ST;
+  static constexpr int EPT = ST::EPT, NW = ST::NW, DIM = ST::DIM;
+  static constexpr bool ONEWAVE = ST::ONEWAVE;
+  ST st;
+  f2* buf;      // two exchange vectors of DIM float2
+  double* red;  // two reduction slots of NRED * NW doubles
+  int cur, redslot;
+
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
+    buf = reinterpret_cast<f2*>(smem);
+    red = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM);
+    cur = 0;
+    redslot = 0;
+    st.init(S);
+  }
+  static size_t lds_bytes() { return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW; }
+  __device__ __forceinline__ int elem(int j) const { return (int)(threadIdx.x | ((unsigned)j << ST::TB)); }
+  __device__ __forceinline__ const f2* vec() const { return buf + cur * DIM; }
+
+  __device__ __forceinline__ void publish(const f2 (&x)[EPT]) {
+    f2* dst = buf + (cur ^ 1) * DIM;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) dst[elem(j)] = x[j];
+    cur ^= 1;
+    team_sync<ONEWAVE>();
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ void apply_all(const f2 (&x)[EPT], f2 (&y)[EPT]) const {
+    const f2* sx = vec();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      y[j] = st.template apply<TRANS>(sx, j, x);
+      slot_fence<EPT>();  // keeps the LDS reads of one slot from being hoisted above the arithmetic of the previous one
+    }
+  }
+
+  template <int NV>
+  __device__ __forceinline__ void sum(double (&v)[NV]) {
+    block_sum<NV, ONEWAVE>(v, red + redslot * NRED * NW);
+    redslot ^= 1;
+  }
+
+  // block-wide sum of two floats; contains the one barrier of a solver iteration (multi-wave blocks)
+  __device__ __forceinline__ void sum2_f32(float& a, float& b) {
+    a = wave_sum_f32(a);
+    b = wave_sum_f32(b);
+    if (ONEWAVE) {
+      team_sync<true>();
+      return;
+    }
+    float* rf = reinterpret_cast<float*>(red + redslot * NRED * NW);
+    redslot ^= 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      rf[wave] = a;
+      rf[NW + wave] = b;
+    }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      sa += rf[w];
+      sb += rf[NW + w];
+    }
+    a = sa;
+    b = sb;
+  }
+
+  // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727) in fp32.
+  // Returns the number of RHS applications; on exit y is in registers.
+  template <bool TRANS>
+  __device__ __forceinline__ int neumann(const SweepArgs& A, float alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
+    float nb2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      y[j] = b[j];
+      nb2 = fmaf(b[j].x, b[j].x, fmaf(b[j].y, b[j].y, nb2));
+    }
+    publish(y);
+    const float abs2 = (float)(A.abstol * A.abstol);
+    const float rel2 = (float)(A.reltol * A.reltol);
+    float d0 = 1.f, tol2 = abs2;
+    int iter;
+    for (iter = 0; iter < A.maxiter; iter++) {
+      const f2* src = vec();
+      f2* dst = buf + (cur ^ 1) * DIM;
+      f2 w[EPT];
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const f2 t = st.template apply<TRANS>(src, j, y);
+        w[j].x = fmaf(alpha, t.x, b[j].x);
+        w[j].y = fmaf(alpha, t.y, b[j].y);
+        const float dx = y[j].x - w[j].x, dy = y[j].y - w[j].y;
+        dl = fmaf(dx, dx, fmaf(dy, dy, dl));
+        dst[elem(j)] = w[j];
+        slot_fence<EPT>();
+      }
+#pragma unroll
+      for (int j = 0; j < EPT; j++) y[j] = w[j];
+      float d = dl, n2 = nb2;
+      sum2_f32(d, n2);  // the barrier that makes dst readable
+      cur ^= 1;
+      if (iter == 0) {
+        d0 = d;
+        tol2 = fmaxf(abs2, F32_SOLVER_TOL * F32_SOLVER_TOL * n2);
+      }
+      if (d <= tol2) { iter++; break; }
+      if (d < rel2 * d0) { iter++; break; }
+    }
+    return iter;
+  }
+};
+
+__device__ __forceinline__ f2 to_f2(const double2 v) { return make_float2((float)v.x, (float)v.y); }
+
+// ---------------------------------------------------------------------------------------------
+// forward sweep (TimeStepper::solveODE for every initial condition of the batch), fp32-mixed
+// ---------------------------------------------------------------------------------------------
+template <int Q, int SB>
+__global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_forward_q32(const SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef Team32<Q, SB> TM;
+  constexpr int EPT = TM::EPT, DIM = TM::DIM;
+  const DevSys& S = A.S;
+  TM tm;
+  tm.init(S, smem);
+  const int ic = blockIdx.x;
+  double2 x[EPT];  // the state itself: fp64 accumulators
+  {
+    const double* x0 = A.x0 + (size_t)ic * 2 * DIM;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = make_double2(x0[tm.elem(j)], x0[DIM + tm.elem(j)]);
+  }
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+  double pen_local = 0.0, pen_uniform = 0.0;
+  unsigned long long napply = 0;
+  f2* traj = reinterpret_cast<f2*>(A.traj);
+
+  for (int s = 0; s < A.nsub; s++) {
+    StepC<Q> c;
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    tm.st.prep(c);
+    const float hf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.h)));
+    f2 xs[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) xs[j] = to_f2(x[j]);
+    if (traj) {
+      f2* dst = traj + ((size_t)s * A.nb + ic) * DIM;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) dst[tm.elem(j)] = xs[j];
+    }
+    tm.publish(xs);
+    f2 rhs[EPT], k[EPT];
+    tm.template apply_all<false>(xs, rhs);  // rhs = M x (ImplMidpoint::evolveFWD, timestepper.cpp:594)
+    napply += 1 + tm.template neumann<false>(A, 0.5f * hf, rhs, k);
+    const double h = to_scalar(c.h);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {  // x += h k: fp64 accumulation of the fp32 stage
+      x[j].x = fma(h, (double)k[j].x, x[j].x);
+      x[j].y = fma(h, (double)k[j].y, x[j].y);
+    }
+    // weighted-J penalty at the end of a FULL time step (timestepper.cpp:141-154, :256-298); all levels are essential
+    if (wj_on && (s + 1) % A.nstages == 0) {
+      const int n = (s + 1) / A.nstages - 1;
+      const double tstop = (n + 1) * A.dt;
+      const double a = (tstop - A.Tfinal) / A.penalty_param;
+      const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        double jr = 0.0, ji = 0.0;
+        evalJ_part<true>(S, A.tg, ic, tm.elem(j), x[j], jr, ji);
+        pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
+      }
+      if (A.tg.objective_type == QD_OBJ_JTRACE) pen_uniform += weight * A.dt;
+    }
+  }
+  {
+    double* xT = A.xT + (size_t)ic * 2 * DIM;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      xT[tm.elem(j)] = x[j].x;
+      xT[DIM + tm.elem(j)] = x[j].y;
+    }
+    if (traj) {
+      f2* dst = traj + ((size_t)A.nsub * A.nb + ic) * DIM;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) dst[tm.elem(j)] = to_f2(x[j]);
+    }
+  }
+  double v[1] = {pen_local};
+  tm.template sum<1>(v);
+  if (threadIdx.x == 0) {
+    A.pen_out[ic] = v[0] + pen_uniform;
+    A.dpdm_out[ic] = 0.0;
+    atomicAdd(A.napply, napply);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams), fp32-mixed
+// ---------------------------------------------------------------------------------------------
+template <int Q, int SB>
+__global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_adjoint_q32(const SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef Team32<Q, SB> TM;
+  constexpr int EPT = TM::EPT, DIM = TM::DIM;
+  const DevSys& S = A.S;
+  TM tm;
+  tm.init(S, smem);
+  const int ic = blockIdx.x;
+  const f2* traj = reinterpret_cast<const f2*>(A.traj);
+  double2 xb[EPT];  // the adjoint state: fp64 accumulators
+  {
+    const double* xbT = A.xbarT + (size_t)ic * 2 * DIM;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) xb[j] = make_double2(xbT[tm.elem(j)], xbT[DIM + tm.elem(j)]);
+  }
+  const double jbar_pen = A.jbar[ic * 3 + 0];
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+
+  for (int s = A.nsub - 1; s >= 0; s--) {
+    // penaltyIntegral_diff at the end of a full step, with the primal x_n (timestepper.cpp:220-227, :300-339)
+    if (wj_on && (s + 1) % A.nstages == 0) {
+      const int n = (s + 1) / A.nstages;
+      const double tstop = n * A.dt;
+      const double a = (tstop - A.Tfinal) / A.penalty_param;
+      const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+      double rb, ib;
+      finalizeJ_diff<true>(A.tg, 0.0, 0.0, rb, ib);
+      const f2* src = traj + ((size_t)(s + 1) * A.nb + ic) * DIM;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const f2 v = src[tm.elem(j)];
+        evalJ_diff_elem<true>(S, A.tg, ic, tm.elem(j), make_double2(v.x, v.y), xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+      }
+    }
+    StepC<Q> c;
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    tm.st.prep(c);
+    const float hf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.h)));
+    f2 x[EPT], z[EPT];
+    {
+      const f2* src = traj + ((size_t)s * A.nb + ic) * DIM;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) x[j] = src[tm.elem(j)];
+    }
+    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694): primal stage (I - h/2 M) k = M x ; z = x + h/2 k
+    tm.publish(x);
+    {
+      f2 rhs[EPT];
+      tm.template apply_all<false>(x, rhs);
+      tm.template neumann<false>(A, 0.5f * hf, rhs, z);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      z[j].x = fmaf(0.5f * hf, z[j].x, x[j].x);
+      z[j].y = fmaf(0.5f * hf, z[j].y, x[j].y);
+    }
+    // adjoint stage (I - h/2 M)^T kbar = xbar ; kbar *= h
+    f2 kb[EPT], bb[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) bb[j] = to_f2(xb[j]);
+    tm.template neumann<true>(A, 0.5f * hf, bb, kb);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      kb[j].x *= hf;
+      kb[j].y *= hf;
+    }
+    // gradient coefficients x^T dM/dp_k z, x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604): fp32 products,
+    // fp64 sums
+    tm.publish(z);
+    double cf[2 * Q];
+#pragma unroll
+    for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
+    {
+      const f2* sx = tm.vec();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+          f2 Av, Bv;
+          tm.st.ladder(sx, k, j, Av, Bv);
+          cf[2 * k] += (double)fmaf(Bv.y, kb[j].x, -Bv.x * kb[j].y);
+          cf[2 * k + 1] += (double)fmaf(Av.x, kb[j].x, Av.y * kb[j].y);
+        }
+      }
+    }
+    tm.template sum<2 * Q>(cf);
+    {
+      double* co = A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q;
+#pragma unroll
+      for (int i = 0; i < 2 * Q; i++)
+        if (threadIdx.x == i) co[i] = cf[i];
+    }
+    // xbar += M^T kbar
+    tm.publish(kb);
+    f2 t[EPT];
+    tm.template apply_all<true>(kb, t);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      xb[j].x += (double)t[j].x;
+      xb[j].y += (double)t[j].y;
+    }
+  }
+  if (A.xbar0) {
+    double* d0 = A.xbar0 + (size_t)ic * 2 * DIM;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      d0[tm.elem(j)] = xb[j].x;
+      d0[DIM + tm.elem(j)] = xb[j].y;
+    }
+  }
+}
+
+// single operator application in fp32 (test hook: qd_apply_rhs with QD_PRECISION_F32MIXED)
+template <int Q, int SB>
+__global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_apply_q32(const DevSys S, const double* __restrict__ ctlrow, int transpose,
+                                                               const double* __restrict__ xin, double* __restrict__ yout, int nrep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef Team32<Q, SB> TM;
+  constexpr int EPT = TM::EPT, DIM = TM::DIM;
+  TM tm;
+  tm.init(S, smem);
+  const int ic = blockIdx.x;
+  f2 x[EPT], y[EPT];
+  const double* x0 = xin + (size_t)ic * 2 * DIM;
+#pragma unroll
+  for (int j = 0; j < EPT; j++) x[j] = make_float2((float)x0[tm.elem(j)], (float)x0[DIM + tm.elem(j)]);
+  StepC<Q> c;
+  load_step<Q>(ctlrow, c, false);
+  tm.st.prep(c);
+  tm.publish(x);
+  if (transpose) tm.template apply_all<true>(x, y);
+  else tm.template apply_all<false>(x, y);
+  // nrep > 1: timing loop of the fp32-stencil-vs-MFMA measurement (y <- M (1e-3 y), keeps the values bounded)
+  for (int r = 1; r < nrep; r++) {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = make_float2(1e-3f * y[j].x, 1e-3f * y[j].y);
+    tm.publish(x);
+    if (transpose) tm.template apply_all<true>(x, y);
+    else tm.template apply_all<false>(x, y);
+  }
+  double* yo = yout + (size_t)ic * 2 * DIM;
+#pragma unroll
+  for (int j = 0; j < EPT; j++) {
+    yo[tm.elem(j)] = (double)y[j].x;
+    yo[DIM + tm.elem(j)] = (double)y[j].y;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The MFMA question: the same operator as a batched dense Kronecker-factor product
+//   Y = G rho - rho G + (dissipators),   G = -i H(t)  (N x N complex, N = 32)
+// on the fp32 matrix cores, v_mfma_f32_32x32x2_f32, one wave per initial condition and 32 x 32 tile.  Per application
+// 2 complex 32x32x32 products = 8 real ones = 128 MFMA instructions of 64 cycles each, against ~220 two-cycle VALU
+// instructions per wave for the stencil: the measurement (qd_bench_apply_f32) is recorded in DESIGN.md.
+// Layouts (cdna_hip_programming.md section 3): A operand lane l holds A[i = l & 31][k = l >> 5], B operand B[k = l >> 5][j = l & 31],
+// C/D: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+// ---------------------------------------------------------------------------------------------
+typedef float mfma_f16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(64) k_apply_mfma32(const DevSys S, const double* __restrict__ ctlrow, const double* __restrict__ xin,
+                                                     double* __restrict__ yout, int nrep) {
+  constexpr int N = 32, Q = 5, NP = 33;           // row stride 33 floats: column reads (lane = row) are conflict-free
+  __shared__ float gre[N * NP], gim[N * NP];      // G(t), row-major
+  __shared__ float rre[N * NP], rim[N * NP];      // rho, row-major [row I][col I']
+  const int lane = threadIdx.x, ic = blockIdx.x;
+  const double* x0 = xin + (size_t)ic * 2 * N * N;
+  // H(t) = diag(h(I)) + sum_k p_k (a_k + a_k^dag) + i q_k (a_k - a_k^dag)  ->  G = -i H:
+  //   G[I][I] = -i h(I);  G[I][I ^ b_k] = -i p_k + s q_k  with s = +1 if digit_k(I) = 1 (the a_k entry) else -1
+  for (int e = lane; e < N * NP; e += 64) {
+    gre[e] = 0.f;
+    gim[e] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < N) {
+    const int I = lane;
+    double hd = 0.0;
+    int pair = 0;
+    for (int k = 0; k < Q; k++) {
+      const int a = (I >> (Q - 1 - k)) & 1;
+      hd += S.detune[k] * a;
+      for (int l = k + 1; l < Q; l++) hd -= S.xikl[pair++] * a * ((I >> (Q - 1 - l)) & 1);
+      const double p = ctlrow[2 + k], q = ctlrow[2 + Q + k];
+      const int J = I ^ (1 << (Q - 1 - k));
+      gre[I * NP + J] = (float)(a ? -q : q);  // -i (p + i q) = q - i p above the diagonal (digit 0), -i (p - i q) = -q - i p below
+      gim[I * NP + J] = (float)(-p);
+    }
+    gim[I * NP + I] = (float)(-hd);
+  }
+  for (int e = lane; e < N * N; e += 64) {  // rho[I][I'] = x[I + N I']
+    const int I = e / N, Ip = e % N;
+    rre[I * NP + Ip] = (float)x0[I + N * Ip];
+    rim[I * NP + Ip] = (float)x0[N * N + I + N * Ip];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int i32 = lane & 31, kh = lane >> 5;
+  mfma_f16 yr, yi;
+  for (int rep = 0; rep < nrep; rep++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) yr[r] = yi[r] = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 2) {
+      const int kk = k0 + kh;
+      // first product G rho: A = G[i][kk], B = rho[kk][j]
+      const float ar = gre[i32 * NP + kk], ai = gim[i32 * NP + kk];
+      const float br = rre[kk * NP + i32], bi = rim[kk * NP + i32];
+      yr = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, yr, 0, 0, 0);
+      yr = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, yr, 0, 0, 0);
+      yi = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, yi, 0, 0, 0);
+      yi = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, yi, 0, 0, 0);
+      // second product - rho G: A = rho[i][kk], B = G[kk][j]
+      const float cr = rre[i32 * NP + kk], ci = rim[i32 * NP + kk];
+      const float dr = gre[kk * NP + i32], di = gim[kk * NP + i32];
+      yr = __builtin_amdgcn_mfma_f32_32x32x2f32(-cr, dr, yr, 0, 0, 0);
+      yr = __builtin_amdgcn_mfma_f32_32x32x2f32(ci, di, yr, 0, 0, 0);
+      yi = __builtin_amdgcn_mfma_f32_32x32x2f32(-cr, di, yi, 0, 0, 0);
+      yi = __builtin_amdgcn_mfma_f32_32x32x2f32(-ci, dr, yi, 0, 0, 0);
+    }
+    // dissipators (diagonal d x, T1 off-diagonal) on the accumulator layout, then write back as the next rho
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float nr[16], ni[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int I = (r & 3) + 8 * (r >> 2) + 4 * kh, Ip = i32;
+      double d = 0.0;
+      float l1r = 0.f, l1i = 0.f;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int a = (I >> (Q - 1 - k)) & 1, ap = (Ip >> (Q - 1 - k)) & 1;
+        d += S.g2[k] * (a * ap - 0.5 * (a + ap)) - S.g1[k] / 2.0 * (a + ap);
+        if (a == 0 && ap == 0) {
+          const int I2 = I | (1 << (Q - 1 - k)), Ip2 = Ip | (1 << (Q - 1 - k));
+          l1r = fmaf((float)S.g1off[k], rre[I2 * NP + Ip2], l1r);
+          l1i = fmaf((float)S.g1off[k], rim[I2 * NP + Ip2], l1i);
+        }
+      }
+      nr[r] = fmaf((float)d, rre[I * NP + Ip], yr[r]) + l1r;
+      ni[r] = fmaf((float)d, rim[I * NP + Ip], yi[r]) + l1i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rep + 1 < nrep) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int I = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        rre[I * NP + i32] = 1e-3f * nr[r];
+        rim[I * NP + i32] = 1e-3f * ni[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else {
+      double* yo = yout + (size_t)ic * 2 * N * N;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int I = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        yo[I + N * i32] = (double)nr[r];
+        yo[N * N + I + N * i32] = (double)ni[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t set_lds32(K kern, size_t bytes) {
+  if (bytes > 48 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return hipSuccess;
+}
+
+// slot bits per thread for a Q-qubit Lindblad system: 2^5 -> 4 elements per thread (256 threads); 2^4 -> one element per
+// thread (256 threads; QD_F32_SB=2 selects the one-wave, four-elements-per-thread layout for measurements)
+static int q32_slot_bits(int Q) {
+  if (Q == 5) return 2;
+  if (const char* ev = getenv("QD_F32_SB")) return atoi(ev) == 2 ? 2 : 0;
+  return 0;
+}
+
+template <int Q, int SB>
+static hipError_t go_fwd(const SweepArgs& a, hipStream_t st) {
+  constexpr int nt = Q32<Q, SB>::NT;
+  const size_t lds = Team32<Q, SB>::lds_bytes();
+  hipLaunchKernelGGL((k_forward_q32<Q, SB>), dim3(a.nb), dim3(nt), lds, st, a);
+  return hipGetLastError();
+}
+template <int Q, int SB>
+static hipError_t go_adj(const SweepArgs& a, hipStream_t st) {
+  constexpr int nt = Q32<Q, SB>::NT;
+  const size_t lds = Team32<Q, SB>::lds_bytes();
+  hipLaunchKernelGGL((k_adjoint_q32<Q, SB>), dim3(a.nb), dim3(nt), lds, st, a);
+  return hipGetLastError();
+}
+template <int Q, int SB>
+static hipError_t go_app(const DevSys& S, const double* ctlrow, int tr, const double* x, double* y, int nb, int nrep, hipStream_t st) {
+  constexpr int nt = Q32<Q, SB>::NT;
+  const size_t lds = Team32<Q, SB>::lds_bytes();
+  hipLaunchKernelGGL((k_apply_q32<Q, SB>), dim3(nb), dim3(nt), lds, st, S, ctlrow, tr, x, y, nrep);
+  return hipGetLastError();
+}
+
+hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st) {
+  const int sb = q32_slot_bits(a.S.Q);
+  if (a.S.Q == 5) return go_fwd<5, 2>(a, st);
+  if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2>(a, st) : go_fwd<4, 0>(a, st);
+  return hipErrorInvalidValue;
+}
+hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st) {
+  const int sb = q32_slot_bits(a.S.Q);
+  if (a.S.Q == 5) return go_adj<5, 2>(a, st);
+  if (a.S.Q == 4) return sb == 2 ? go_adj<4, 2>(a, st) : go_adj<4, 0>(a, st);
+  return hipErrorInvalidValue;
+}
+hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
+                            hipStream_t st) {
+  if (mfma) {
+    if (S.Q != 5 || transpose) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_apply_mfma32, dim3(nb), dim3(64), 0, st, S, ctlrow, x, y, nrep);
+    return hipGetLastError();
+  }
+  const int sb = q32_slot_bits(S.Q);
+  if (S.Q == 5) return go_app<5, 2>(S, ctlrow, transpose, x, y, nb, nrep, st);
+  if (S.Q == 4) return sb == 2 ? go_app<4, 2>(S, ctlrow, transpose, x, y, nb, nrep, st) : go_app<4, 0>(S, ctlrow, transpose, x, y, nb, nrep, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace qd

@@ -7,39 +7,162 @@ collectives per gradient (src/optimproblem.cpp:454-460 and :527):
 
 With `replicas = R` every rank holds a complete set of initial conditions (a batch of R identical
 sets, objective = mean over all members: weak scaling); the reduced sums and the gradient are
-divided by R.  No state or trajectory ever leaves its GPU.  ``torch.distributed`` with backend "nccl" is RCCL over
-xGMI on ROCm; the same code runs with "gloo" on CPU for the tests.  `backend_obj` is anything with
-forward_local / finalize / adjoint_local (quandary_amd.capi.Optim on a GPU)."""
+divided by R.  No state or trajectory ever leaves its GPU.
+
+Communicators (`make_comm`):
+  * "nccl": RCCL over xGMI called from the C++ side of the library (qd_comm_* in include/quandary_amd.h:
+    ncclAllReduce on the handle's HIP stream); torch.distributed (gloo) only distributes the ncclUniqueId.
+  * "gloo": torch.distributed on host buffers - the CPU tests, and several ranks sharing one GPU.
+`backend_obj` is anything with forward_local / finalize / adjoint_local (quandary_amd.capi.Optim on a GPU,
+the oracle's sharded API in the CPU tests)."""
+import os
+import time
+
 import numpy as np
 
 
-class DistributedObjective:
-    def __init__(self, backend_obj, dist=None, device="cpu", replicas=1):
-        self.b = backend_obj
-        self.scale = 1.0 / replicas
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
-        self.device = device
-        self._bufs = {}  # persistent device tensors for the two tiny collectives (no allocation per evaluation)
+class TorchComm:
+    """torch.distributed on host tensors (gloo), or on device tensors (nccl = RCCL) when `device` is a cuda device."""
 
-    def _allreduce(self, arr):
-        if self.dist is None:
-            return arr
+    def __init__(self, backend, rank, world, device="cpu", init=True):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.device = device
+        self.backend = backend
+        self._own = False
+        if init and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            self._own = True
+        self._bufs = {}
+
+    def world_size(self):
+        return self.dist.get_world_size()
+
+    def describe(self):
+        return f"torch.distributed/{self.backend} on {self.device} buffers"
+
+    def _reduce(self, arr, op):
         import torch
 
-        src = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
-        t = self._bufs.get(src.numel())
-        if t is None:
-            t = self._bufs[src.numel()] = torch.empty(src.numel(), dtype=torch.float64, device=self.device)
-        t.copy_(src.reshape(-1))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy().reshape(np.shape(arr)) * self.scale
+        src = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).reshape(-1))
+        if self.device == "cpu":
+            t = src.clone()
+        else:
+            t = self._bufs.get(src.numel())
+            if t is None:
+                t = self._bufs[src.numel()] = torch.empty(src.numel(), dtype=torch.float64, device=self.device)
+            t.copy_(src)
+        self.dist.all_reduce(t, op=op)
+        return t.cpu().numpy().reshape(np.shape(arr))
+
+    def allreduce_sum(self, arr):
+        return self._reduce(arr, self.dist.ReduceOp.SUM)
+
+    def allreduce_max(self, arr):
+        return self._reduce(arr, self.dist.ReduceOp.MAX)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        if self._own and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+class RcclComm(TorchComm):
+    """RCCL from the C++ side of the library: the ncclUniqueId of rank 0 travels through a gloo broadcast, every
+    collective on the data path is ncclAllReduce inside libquandary_amd.so (qd_comm_allreduce)."""
+
+    def __init__(self, rank, world, local_rank):
+        import torch
+
+        from . import capi
+
+        super().__init__("gloo", rank, world, "cpu")
+        lib = capi.load_library()
+        ident = np.zeros(capi.COMM_ID_BYTES, dtype=np.uint8)
+        if rank == 0:
+            capi.check(lib.qd_comm_unique_id(ident.ctypes.data_as(capi.c_u8p)), "qd_comm_unique_id")
+        t = torch.from_numpy(ident)
+        self.dist.broadcast(t, src=0)
+        self.lib = lib
+        self.comm = capi.c_void_p()
+        capi.check(lib.qd_comm_create(ident.ctypes.data_as(capi.c_u8p), rank, world, local_rank, capi.byref(self.comm)), "qd_comm_create")
+        self._world = world
+
+    def world_size(self):
+        return int(self.lib.qd_comm_size(self.comm))
+
+    def describe(self):
+        return "RCCL ncclAllReduce called from libquandary_amd.so (qd_comm_*), device buffers on the handle's stream"
+
+    def _rccl(self, arr, op):
+        from . import capi
+
+        a = np.ascontiguousarray(arr, dtype=np.float64).copy()
+        capi.check(self.lib.qd_comm_allreduce(self.comm, capi.dptr(a), a.size, op), "qd_comm_allreduce")
+        return a.reshape(np.shape(arr))
+
+    def allreduce_sum(self, arr):
+        return self._rccl(arr, 0)
+
+    def allreduce_max(self, arr):
+        return self._rccl(arr, 1)
+
+    def close(self):
+        if self.comm:
+            self.lib.qd_comm_destroy(self.comm)
+            self.comm = None
+        super().close()
+
+
+def make_comm(backend, rank, world, local_rank=0):
+    if backend == "nccl":
+        return RcclComm(rank, world, local_rank)
+    return TorchComm(backend, rank, world, "cpu")
+
+
+class DistributedObjective:
+    def __init__(self, backend_obj, comm=None, replicas=1):
+        self.b = backend_obj
+        self.scale = 1.0 / replicas
+        self.comm = comm if (comm is not None and comm.world_size() > 1) else None
+        self._t = [0.0, 0.0]
+        # the library reduces on the device itself when it owns an RCCL communicator (no host round trip between
+        # sweep and collective); otherwise the two reductions go through the communicator's host interface
+        self.native = self.comm is not None and isinstance(self.comm, RcclComm) and hasattr(self.b, "evalGradF_dist") and replicas == 1
+
+    def reset_timers(self):
+        self._t = [0.0, 0.0]
+
+    def allreduce_ms(self):
+        return [1e3 * self._t[0], 1e3 * self._t[1]]
+
+    def _allreduce(self, arr, which):
+        if self.comm is None:
+            return arr
+        t0 = time.perf_counter()
+        out = self.comm.allreduce_sum(arr) * self.scale
+        self._t[which] += time.perf_counter() - t0
+        return out
 
     def evalF(self, alpha):
-        sums = self._allreduce(self.b.forward_local(alpha, False))
+        if self.native:
+            val, ms = self.b.evalF_dist(self.comm.comm, alpha)
+            self._t[0] += ms[0] * 1e-3
+            return val
+        sums = self._allreduce(self.b.forward_local(alpha, False), 0)
         return self.b.finalize(alpha, sums)
 
     def evalGradF(self, alpha):
-        sums = self._allreduce(self.b.forward_local(alpha, True))  # 7 scalars, one collective
+        if self.native:
+            val, grad, ms = self.b.evalGradF_dist(self.comm.comm, alpha)
+            self._t[0] += ms[0] * 1e-3
+            self._t[1] += ms[1] * 1e-3
+            return val, grad
+        sums = self._allreduce(self.b.forward_local(alpha, True), 0)  # 7 scalars, one collective
         val = self.b.finalize(alpha, sums)
-        grad = self._allreduce(self.b.adjoint_local(alpha, sums))   # ndesign doubles, one collective
+        grad = self._allreduce(self.b.adjoint_local(alpha, sums), 1)   # ndesign doubles, one collective
         return val, grad

@@ -46,7 +46,7 @@ def golden_rows(case, fname):
 
 def synthetic_cfg(nlevels, lindblad=True, ntime=20, dt=0.01, nspline=10, jkl=0.0, linsolve="neumann", stepper="IMR",
                   init="basis", target="gate", objective="Jtrace", nessential=None, maxiter=20, penalties=False,
-                  detuned=False):
+                  detuned=False, gate=None):
     """Synthetic systems in the style of SURVEY 8(d) / tests/performance/configs of the reference."""
     Q = len(nlevels)
     lines = [
@@ -71,7 +71,7 @@ def synthetic_cfg(nlevels, lindblad=True, ntime=20, dt=0.01, nspline=10, jkl=0.0
                   f"carrier_frequency{k} = 0.0, -0.2"]
     if target == "gate":
         dim_ess = int(np.prod(nessential if nessential else nlevels))
-        lines.append("optim_target = gate, " + ("cnot" if dim_ess == 4 else ("xgate" if dim_ess == 2 else "qft")))
+        lines.append("optim_target = gate, " + (gate if gate else "cnot" if dim_ess == 4 else ("xgate" if dim_ess == 2 else "qft")))
     else:
         lines.append("optim_target = pure, " + ",".join(["0"] * Q))
     if penalties:

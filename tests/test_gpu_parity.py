@@ -151,7 +151,7 @@ def test_other_steppers(stepper):
     opt.close(); h.close(); orc.close()
 
 
-@pytest.mark.parametrize("stepper", ["IMR4", "EE"])
+@pytest.mark.parametrize("stepper", ["IMR4", "IMR8", "EE"])
 def test_other_steppers_column_layout(stepper, monkeypatch):
     """compositional / explicit steppers through the column-per-wave kernel (staging paths differ from IMR)"""
     monkeypatch.setenv("QD_VAR", "9")
@@ -287,15 +287,66 @@ def test_random_configurations_vs_oracle(seed):
     oval, og = orc.evalGradF(sp.params0)
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-11), (k, kw)
-    if kw["stepper"] == "EE" and not kw["lindblad"]:
-        # Documented deviation: for Schroedinger runs the reference re-computes the primal
-        # backwards with the forward stepper (src/timestepper.cpp:229-231), which is exact for the symmetric IMR
-        # family but O(dt) off for explicit Euler; the HIP path always reads the stored forward states.
-        # (Neither gradient is a consistent discrete gradient: the reference's EE adjoint evaluates M at t_stop,
-        # src/timestepper.cpp:506-520.)  Only the objective parts are compared for this debug stepper.
-        pass
-    else:
-        assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13, kw
+    # (explicit Euler in Schroedinger mode included: the adjoint kernel re-computes the primal backwards with the forward
+    # stepper exactly as the reference does, src/timestepper.cpp:229-231)
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13, kw
+    opt.close(); h.close(); orc.close()
+
+
+FAMILY_CASES = [
+    # initial-condition families that need the Lindblad solver (src/optimtarget.cpp:460-572)
+    pytest.param(dict(nlevels=[2, 2], lindblad=True, init="3states", gate="swap"), id="3states-swap"),
+    pytest.param(dict(nlevels=[3, 2], lindblad=True, nessential=[2, 2], init="Nplus1", gate="cnot"), id="Nplus1-guard-cnot"),
+    pytest.param(dict(nlevels=[2, 2, 2], lindblad=True, init="Nplus1", gate="swap0q"), id="Nplus1-swap0q"),
+    pytest.param(dict(nlevels=[2, 3], lindblad=True, init="ensemble, 0, 1", target="pure", objective="Jmeasure"), id="ensemble-01"),
+    pytest.param(dict(nlevels=[3, 2], lindblad=True, init="ensemble, 1", target="pure", objective="Jfrobenius"), id="ensemble-1"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=True, init="performance", gate="cqnot", objective="Jfrobenius"), id="performance-lindblad-cqnot"),
+    pytest.param(dict(nlevels=[2, 2, 2], lindblad=False, init="performance", gate="cqnot"), id="performance-schroedinger-cqnot"),
+    # remaining gates of initTargetGate (src/gate.cpp:546-571)
+    pytest.param(dict(nlevels=[2], lindblad=True, gate="hadamard"), id="hadamard-lindblad"),
+    pytest.param(dict(nlevels=[3], lindblad=False, nessential=[2], gate="hadamard"), id="hadamard-schroedinger-guard"),
+    pytest.param(dict(nlevels=[2], lindblad=False, gate="ygate"), id="ygate"),
+    pytest.param(dict(nlevels=[2], lindblad=True, gate="zgate", objective="Jfrobenius"), id="zgate"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=False, gate="swap"), id="swap-schroedinger"),
+    pytest.param(dict(nlevels=[2, 2, 2], lindblad=False, gate="swap0q", jkl=0.003, detuned=True), id="swap0q-schroedinger"),
+    pytest.param(dict(nlevels=[3, 3], lindblad=False, nessential=[2, 2], gate="cqnot", init="diagonal, 0, 1"), id="cqnot-guard-diag"),
+]
+
+
+@pytest.mark.parametrize("kw", FAMILY_CASES)
+@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
+def test_initial_condition_and_gate_families(kw, linsolve):
+    """The initial-condition families (3states, Nplus1, ensemble, performance) and gates (swap, swap0q, cqnot, hadamard,
+    ygate, zgate) that the random sweep does not draw: objective parts and gradient against the oracle."""
+    sp, h, orc = _pair(kw, ntime=14, penalties=True, linsolve=linsolve, dt=0.02)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-11), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [
+    pytest.param(dict(nlevels=[2, 2], lindblad=False), id="2x2"),
+    pytest.param(dict(nlevels=[3, 3], lindblad=False, nessential=[2, 2], jkl=0.005, detuned=True), id="3x3-guard-Jkl"),
+    pytest.param(dict(nlevels=[5, 5, 5, 5], lindblad=False, nessential=[2, 2, 2, 2], init="pure, 1, 0, 1, 0", target="pure", objective="Jmeasure"), id="5^4-four-per-thread"),
+])
+def test_explicit_euler_schroedinger_gradient(kw):
+    """ExplEuler in Schroedinger mode: the reference re-computes the primal (and the dpdm states) backwards with the
+    forward stepper (src/timestepper.cpp:207-211, :229-231, :236-243), which differs from the forward states by
+    O(dt); its gradient is defined on that chain.  All penalties on (incl. dpdm)."""
+    sp, h, orc = _pair(kw, ntime=16, stepper="EE", penalties=True, dt=0.01)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-11), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13
+    # the stored trajectory has been replaced by the backward chain: it is no longer offered as forward states
+    with pytest.raises(capi.QuandaryAmdError):
+        h.get_state(0, opt.ninit_local)
     opt.close(); h.close(); orc.close()
 
 
@@ -410,8 +461,6 @@ def test_two_rank_sharding_matches_single_rank():
     full = capi.Optim(h, sp)
     val, g = full.evalGradF(sp.params0)
     full.close()
-    parts, grads = [], []
-    shards = [capi.Optim(h, sp, rank=r, nranks=2) for r in range(2)]
     # forward of both shards, then the global sums, then both adjoints (src/optimproblem.cpp:454-527)
     hs = [capi.Handle(sp) for _ in range(2)]
     shards = [capi.Optim(hs[r], sp, rank=r, nranks=2) for r in range(2)]

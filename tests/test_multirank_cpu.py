@@ -29,26 +29,26 @@ class _OracleShard:
 def _worker(rank, world, port, cfg_text, q, replicated=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import torch.distributed as dist
-
     from oracle.oracle import Oracle
     from quandary_amd import config
-    from quandary_amd.parallel import DistributedObjective
+    from quandary_amd.parallel import DistributedObjective, make_comm
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = make_comm("gloo", rank, world)
+    assert comm.world_size() == world
     sp = config.build_spec(config.parse_config_text(cfg_text))
     orc = Oracle(sp)
     if replicated:  # weak scaling: every rank holds the whole set, sums and gradient are averaged
-        obj = DistributedObjective(_OracleShard(orc, 0, 1), dist, "cpu", replicas=world)
+        obj = DistributedObjective(_OracleShard(orc, 0, 1), comm, replicas=world)
     else:
-        obj = DistributedObjective(_OracleShard(orc, rank, world), dist, "cpu")
+        obj = DistributedObjective(_OracleShard(orc, rank, world), comm)
     val, g = obj.evalGradF(sp.params0)
     val2 = obj.evalF(sp.params0)
+    assert all(t >= 0.0 for t in obj.allreduce_ms())
     q.put((rank, val, g, val2))
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 @pytest.mark.parametrize("lindblad,objective,replicated", [(True, "Jtrace", False), (False, "Jtrace", False), (False, "Jtrace", True)])
