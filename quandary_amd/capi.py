@@ -249,7 +249,7 @@ def load_library(path=None):
     lib.qd_optim_evalGradF_dist.argtypes = [vp, vp, c_dp, C.POINTER(qd_objective_value), c_dp, c_dp]
     lib.qd_set_precision.argtypes = [vp, C.c_int]
     lib.qd_get_precision.argtypes = [vp]
-    lib.qd_bench_apply_f32.argtypes = [vp, C.c_double, c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp]
+    lib.qd_bench_apply_f32.argtypes = [vp, C.c_double, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     if path is None:
         _lib = lib
     return lib
@@ -294,6 +294,15 @@ class Handle:
         prec = getattr(spec, "precision", "f64") or "f64"
         if prec != "f64":
             self.set_precision(prec)
+
+    def bench_apply_f32(self, t, x, nrep=1, mfma=False):
+        """Measurement hook: nrep chained fp32 applications of M(t) by the stencil kernel or on the fp32 matrix cores."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        ms = C.c_double(0.0)
+        _check(self.lib, self.lib.qd_bench_apply_f32(self._h, float(t), dptr(x), dptr(y), x.shape[0], int(nrep), int(bool(mfma)), C.byref(ms)),
+               "qd_bench_apply_f32")
+        return y, ms.value
 
     def set_precision(self, name):
         """'f64' (default, like the reference) or 'f32mixed' (fp32 exchange vector / stencil, fp64 accumulation)."""

@@ -458,6 +458,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
     Sone.gtab = h->d_gone.p;
   }
   if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
+  else if (lean64_available(h->S) && h->sol.linsolve == QD_LINSOLVE_NEUMANN) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
   else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
@@ -574,7 +575,9 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if ((r = check_cfg(cfg))) return r;
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
+  const bool lean64 = lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
+  else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));
@@ -682,7 +685,9 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
+  const bool lean64 = lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, stream));
+  else if (lean64) QD_HIP(launch_adjoint_lean64(a, stream));
   else QD_HIP(launch_adjoint(a, cfg, stream));
   QD_HIP(hipEventRecord(ev3, stream));
   QD_HIP(launch_reduce_coeff(d_coeff.p, nb, (int)ncol, d_coeffsum.p, accumulate ? 1 : 0, stream));

@@ -120,6 +120,11 @@ hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st);
 hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st);
 hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
                             hipStream_t st);
+// the same lean slot kernel instantiated in fp64: Neumann sweeps of the 2^5 Lindblad system (QD_PRECISION_F64)
+bool lean64_available(const DevSys& S);
+hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st);
+hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st);
+hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false, bool adjoint = false);
 size_t krylov_doubles(const DevSys& S, int nb);
 int variant_max_block(int var);  // 0 for an unknown variant  // size of SweepArgs::kry for LaunchCfg::gmres == 2

@@ -26,16 +26,28 @@
 
 namespace qd {
 
-typedef float2 f2;
-
 constexpr float F32_SOLVER_TOL = 2.384185791015625e-07f;  // 2^-22
 
-template <int Q, int SB>
+// R = float: the fp32-mixed sweeps.  R = double: the same lean kernel structure in full fp64 (every value below is a
+// double, the "accumulators" and the exchange vector coincide) - the throughput kernel of the 2^5 Lindblad system in
+// QD_PRECISION_F64: 4 x fewer registers than the general slot kernel of qd_device.h, hence 2 workgroups per CU.
+template <typename R> struct Vec2;
+template <> struct Vec2<float> { typedef float2 type; };
+template <> struct Vec2<double> { typedef double2 type; };
+__device__ __forceinline__ float rfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double rfma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ double uniform(double v) { return to_scalar(v); }
+
+template <int Q, int SB, typename R = float>
 struct Q32 {
+  typedef typename Vec2<R>::type f2;
   static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
   static constexpr bool ONEWAVE = NT == 64;
-  static constexpr int MINW = 4 * NT / 256 > 0 ? 4 * NT / 256 : 1;  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
-  static constexpr unsigned SLOT_BYTES = 8u << TB;  // LDS distance of consecutive slots (float2 elements)
+  static constexpr int BPC = sizeof(R) == 4 ? 4 : 2;  // workgroups per CU the register budget is set for (256-thread groups)
+  static constexpr int MINW = BPC * NT / 256 > 0 ? BPC * NT / 256 : 1;  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
+  static constexpr unsigned EB = sizeof(f2), ESH = sizeof(R) == 4 ? 3 : 4;  // bytes per element, log2
+  static constexpr unsigned SLOT_BYTES = EB << TB;  // LDS distance of consecutive slots
   static_assert(NT >= 64 && NT <= 1024, "block size");
 
   __device__ static constexpr int brabit(int k) { return Q - 1 - k; }
@@ -43,11 +55,11 @@ struct Q32 {
   __device__ static constexpr int slotbit(int j, int k) { return (j >> (SB - 1 - k)) & 1; }  // ket digit of oscillator k < SB in slot j
   __device__ static constexpr int slotflip(int j, int k) { return j ^ (1 << (SB - 1 - k)); }
 
-  float dw[EPT], dd[EPT];        // Delta = h(I) - h(I'), d = L2 + L1diag (mastereq.hpp:316-433)
+  R dw[EPT], dd[EPT];            // Delta = h(I) - h(I'), d = L2 + L1diag (mastereq.hpp:316-433)
   unsigned ab[Q], ak[Q], al[Q];  // byte offsets (slot 0) of the bra / ket (k >= SB) / T1 neighbour of oscillator k
-  float l1f[Q], l1t[Q];          // thread part of the T1 off-diagonal coefficient, forward / transposed
-  float qb[Q], qk[Q];            // q_k with the sign of the bra / ket (k >= SB) digit of this thread [per step]
-  float p[Q], q[Q];              // controls of the current sub-step (wave-uniform)
+  R l1f[Q], l1t[Q];              // thread part of the T1 off-diagonal coefficient, forward / transposed
+  R qb[Q], qk[Q];                // q_k with the sign of the bra / ket (k >= SB) digit of this thread [per step]
+  R p[Q], q[Q];                  // controls of the current sub-step (wave-uniform)
 
   __device__ __forceinline__ void init(const DevSys& S) {
     const unsigned tid = threadIdx.x;
@@ -70,25 +82,25 @@ struct Q32 {
           pair++;
         }
       }
-      dw[j] = (float)(hd - hdp);  // differences formed in fp64, rounded once
-      dd[j] = (float)d;
+      dw[j] = (R)(hd - hdp);  // differences formed in fp64, rounded once
+      dd[j] = (R)d;
     }
 #pragma unroll
     for (int k = 0; k < Q; k++) {
       const unsigned bb = 1u << brabit(k), kb = 1u << ketbit(k);
-      ab[k] = (tid ^ bb) << 3;
-      ak[k] = k >= SB ? (tid ^ kb) << 3 : 0u;
-      al[k] = k >= SB ? (tid ^ bb ^ kb) << 3 : ab[k];
+      ab[k] = (tid ^ bb) << ESH;
+      ak[k] = k >= SB ? (tid ^ kb) << ESH : 0u;
+      al[k] = k >= SB ? (tid ^ bb ^ kb) << ESH : ab[k];
       const bool bra0 = (tid & bb) == 0;
       if (k >= SB) {
         const bool ket0 = (tid & kb) == 0;
-        l1f[k] = (bra0 && ket0) ? (float)S.g1off[k] : 0.f;
-        l1t[k] = (!bra0 && !ket0) ? (float)S.g1off[k] : 0.f;
+        l1f[k] = (bra0 && ket0) ? (R)S.g1off[k] : (R)0;
+        l1t[k] = (!bra0 && !ket0) ? (R)S.g1off[k] : (R)0;
       } else {  // the ket digit is a slot bit: only the bra condition is a thread property
-        l1f[k] = bra0 ? (float)S.g1off[k] : 0.f;
-        l1t[k] = !bra0 ? (float)S.g1off[k] : 0.f;
+        l1f[k] = bra0 ? (R)S.g1off[k] : (R)0;
+        l1t[k] = !bra0 ? (R)S.g1off[k] : (R)0;
       }
-      qb[k] = qk[k] = p[k] = q[k] = 0.f;
+      qb[k] = qk[k] = p[k] = q[k] = (R)0;
     }
   }
 
@@ -97,8 +109,8 @@ struct Q32 {
     const unsigned tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
-      p[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.p[k])));
-      q[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.q[k])));
+      p[k] = uniform((R)c.p[k]);
+      q[k] = uniform((R)c.q[k]);
       qb[k] = ((tid >> brabit(k)) & 1) ? -q[k] : q[k];
       if (k >= SB) qk[k] = ((tid >> ketbit(k)) & 1) ? -q[k] : q[k];
     }
@@ -112,13 +124,13 @@ struct Q32 {
   template <bool TRANS>
   __device__ __forceinline__ f2 apply(const f2* __restrict__ sx, int j, const f2 (&xall)[EPT]) const {
     const f2 xs = xall[j];
-    float hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0.f, gi = 0.f;
-    float l1r = 0.f, l1i = 0.f;
+    R hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0, gi = 0;
+    R l1r = 0, l1i = 0;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
       const f2 xb = at(sx, ab[k], j);
       f2 xk;
-      float sqk;
+      R sqk;
       if (k < SB) {  // ket neighbour = own slot with the slot bit flipped; the sign of the slot bit is a constant
         xk = xall[slotflip(j, k)];
         sqk = slotbit(j, k) ? -q[k] : q[k];
@@ -126,36 +138,36 @@ struct Q32 {
         xk = at(sx, ak[k], j);
         sqk = qk[k];
       }
-      float& ar = (k & 1) ? gr : hr;
-      float& ai = (k & 1) ? gi : hi;
-      ar = fmaf(qb[k], xb.x, ar);
-      ai = fmaf(qb[k], xb.y, ai);
-      ar = fmaf(sqk, xk.x, ar);
-      ai = fmaf(sqk, xk.y, ai);
-      ar = fmaf(p[k], xb.y, ar);
-      ai = fmaf(-p[k], xb.x, ai);
-      ar = fmaf(-p[k], xk.y, ar);
-      ai = fmaf(p[k], xk.x, ai);
+      R& ar = (k & 1) ? gr : hr;
+      R& ai = (k & 1) ? gi : hi;
+      ar = rfma(qb[k], xb.x, ar);
+      ai = rfma(qb[k], xb.y, ai);
+      ar = rfma(sqk, xk.x, ar);
+      ai = rfma(sqk, xk.y, ai);
+      ar = rfma(p[k], xb.y, ar);
+      ai = rfma(-p[k], xb.x, ai);
+      ar = rfma(-p[k], xk.y, ar);
+      ai = rfma(p[k], xk.x, ai);
       // T1 off-diagonal: forward needs both digits 0 (the neighbour has both set), transposed both 1
       const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
       if (slot_ok) {
         const f2 xl = at(sx, al[k], k < SB ? slotflip(j, k) : j);
-        const float l1 = TRANS ? l1t[k] : l1f[k];
-        l1r = fmaf(l1, xl.x, l1r);
-        l1i = fmaf(l1, xl.y, l1i);
+        const R l1 = TRANS ? l1t[k] : l1f[k];
+        l1r = rfma(l1, xl.x, l1r);
+        l1i = rfma(l1, xl.y, l1i);
       }
     }
     hr += gr;
     hi += gi;
     f2 y;
-    y.x = fmaf(dd[j], xs.x, TRANS ? -hr : hr) + l1r;
-    y.y = fmaf(dd[j], xs.y, TRANS ? -hi : hi) + l1i;
+    y.x = rfma(dd[j], xs.x, TRANS ? -hr : hr) + l1r;
+    y.y = rfma(dd[j], xs.y, TRANS ? -hi : hi) + l1i;
     return y;
   }
 
   // gradient contraction: A = s_b x_b + s_k x_k, B = x_b - x_k (QubitStencil::ladder), all from LDS
   __device__ __forceinline__ void ladder(const f2* __restrict__ sx, int k, int j, f2& A, f2& B) const {
-    const unsigned it = threadIdx.x | ((unsigned)j << TB);
+    const unsigned it = opaque((unsigned)(threadIdx.x | ((unsigned)j << TB)));
     const f2 xb = sx[it ^ (1u << brabit(k))], xk = sx[it ^ (1u << ketbit(k))];
     const bool a = (it >> brabit(k)) & 1, ap = (it >> ketbit(k)) & 1;
     A.x = (a ? -xb.x : xb.x) + (ap ? -xk.x : xk.x);
@@ -165,27 +177,44 @@ struct Q32 {
   }
 };
 
-// per-workgroup state of the fp32 sweeps: LDS exchange buffers, reduction scratch, the Neumann solver
-template <int Q, int SB>
+// per-workgroup state of the sweeps: LDS exchange buffers, reduction scratch, the Neumann solver
+template <int Q, int SB, typename R>
 struct Team32 {
-  typedef Q32<Q, SB> ST;
+  typedef Q32<Q, SB, R> ST;
+  typedef typename ST::f2 f2;
   static constexpr int EPT = ST::EPT, NW = ST::NW, DIM = ST::DIM;
   static constexpr bool ONEWAVE = ST::ONEWAVE;
+  static constexpr bool F32 = sizeof(R) == 4;
   ST st;
-  f2* buf;      // two exchange vectors of DIM float2
-  double* red;  // two reduction slots of NRED * NW doubles
+  f2* buf;       // two exchange vectors of DIM elements
+  double* red;   // two reduction slots of NRED * NW doubles
+  double2* acc;  // the fp64 state accumulators, parked here while a linear solve runs (EPT > 1; only ever touched by the owning thread)
   int cur, redslot;
+  static constexpr bool PARK = EPT > 1;
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
     buf = reinterpret_cast<f2*>(smem);
     red = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM);
+    acc = reinterpret_cast<double2*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW);
     cur = 0;
     redslot = 0;
     st.init(S);
   }
-  static size_t lds_bytes() { return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW; }
+  static size_t lds_bytes() { return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0); }
   __device__ __forceinline__ int elem(int j) const { return (int)(threadIdx.x | ((unsigned)j << ST::TB)); }
   __device__ __forceinline__ const f2* vec() const { return buf + cur * DIM; }
+  __device__ __forceinline__ void park(const double2 (&v)[EPT]) const {
+    if (PARK) {
+#pragma unroll
+      for (int j = 0; j < EPT; j++) acc[elem(j)] = v[j];
+    }
+  }
+  __device__ __forceinline__ void unpark(double2 (&v)[EPT]) const {
+    if (PARK) {
+#pragma unroll
+      for (int j = 0; j < EPT; j++) v[j] = acc[elem(j)];
+    }
+  }
 
   __device__ __forceinline__ void publish(const f2 (&x)[EPT]) {
     f2* dst = buf + (cur ^ 1) * DIM;
@@ -237,18 +266,21 @@ struct Team32 {
     b = sb;
   }
 
-  // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727) in fp32.
-  // Returns the number of RHS applications; on exit y is in registers.
+  // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727).
+  // Returns the number of RHS applications; on exit y is in registers.  The squared update norm is only compared
+  // with a threshold: it is accumulated per thread in R and reduced over the workgroup in fp32, scaled by 1/abstol^2
+  // (fp64 sweeps; keeps the fp32 value away from the subnormal range) exactly as in qd_device.h.
   template <bool TRANS>
-  __device__ __forceinline__ int neumann(const SweepArgs& A, float alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
-    float nb2 = 0.f;
+  __device__ __forceinline__ int neumann(const SweepArgs& A, R alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
+    R nb2 = 0;
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       y[j] = b[j];
-      nb2 = fmaf(b[j].x, b[j].x, fmaf(b[j].y, b[j].y, nb2));
+      if (F32) nb2 = rfma(b[j].x, b[j].x, rfma(b[j].y, b[j].y, nb2));
     }
     publish(y);
-    const float abs2 = (float)(A.abstol * A.abstol);
+    const R scale = F32 ? (R)1 : (R)(1.0 / (A.abstol * A.abstol));
+    const float abs2 = F32 ? (float)(A.abstol * A.abstol) : 1.f;
     const float rel2 = (float)(A.reltol * A.reltol);
     float d0 = 1.f, tol2 = abs2;
     int iter;
@@ -256,42 +288,62 @@ struct Team32 {
       const f2* src = vec();
       f2* dst = buf + (cur ^ 1) * DIM;
       f2 w[EPT];
-      float dl = 0.f;
+      R dl = 0;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         const f2 t = st.template apply<TRANS>(src, j, y);
-        w[j].x = fmaf(alpha, t.x, b[j].x);
-        w[j].y = fmaf(alpha, t.y, b[j].y);
-        const float dx = y[j].x - w[j].x, dy = y[j].y - w[j].y;
-        dl = fmaf(dx, dx, fmaf(dy, dy, dl));
+        w[j].x = rfma(alpha, t.x, b[j].x);
+        w[j].y = rfma(alpha, t.y, b[j].y);
+        const R dx = y[j].x - w[j].x, dy = y[j].y - w[j].y;
+        dl = rfma(dx, dx, rfma(dy, dy, dl));
         dst[elem(j)] = w[j];
         slot_fence<EPT>();
       }
 #pragma unroll
       for (int j = 0; j < EPT; j++) y[j] = w[j];
-      float d = dl, n2 = nb2;
+      float d = F32 ? (float)dl : (float)fmin((double)(dl * scale), 1e30), n2 = (float)nb2;
       sum2_f32(d, n2);  // the barrier that makes dst readable
       cur ^= 1;
       if (iter == 0) {
         d0 = d;
-        tol2 = fmaxf(abs2, F32_SOLVER_TOL * F32_SOLVER_TOL * n2);
+        if (F32) tol2 = fmaxf(abs2, F32_SOLVER_TOL * F32_SOLVER_TOL * n2);
       }
-      if (d <= tol2) { iter++; break; }
+      if (F32 ? d <= tol2 : d < 1.f) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
     }
     return iter;
   }
 };
 
-__device__ __forceinline__ f2 to_f2(const double2 v) { return make_float2((float)v.x, (float)v.y); }
+template <typename R> __device__ __forceinline__ typename Vec2<R>::type to_r2(const double2 v);
+template <> __device__ __forceinline__ float2 to_r2<float>(const double2 v) { return make_float2((float)v.x, (float)v.y); }
+template <> __device__ __forceinline__ double2 to_r2<double>(const double2 v) { return v; }
+
+// Stored trajectory.  fp32-mixed: [nsub+1][nb][dim] interleaved float2; fp64: the layout of every other fp64 kernel and of
+// qd_get_state, [nsub+1][nb][2 dim] blocked [u ; v].
+template <typename R> struct Traj;
+template <> struct Traj<float> {
+  __device__ __forceinline__ static void store(double* base, size_t state, int dim, int e, float2 v) { reinterpret_cast<float2*>(base)[state * dim + e] = v; }
+  __device__ __forceinline__ static float2 load(const double* base, size_t state, int dim, int e) { return reinterpret_cast<const float2*>(base)[state * dim + e]; }
+};
+template <> struct Traj<double> {
+  __device__ __forceinline__ static void store(double* base, size_t state, int dim, int e, double2 v) {
+    base[state * 2 * dim + e] = v.x;
+    base[state * 2 * dim + dim + e] = v.y;
+  }
+  __device__ __forceinline__ static double2 load(const double* base, size_t state, int dim, int e) {
+    return make_double2(base[state * 2 * dim + e], base[state * 2 * dim + dim + e]);
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
-// forward sweep (TimeStepper::solveODE for every initial condition of the batch), fp32-mixed
+// forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int SB>
-__global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_forward_q32(const SweepArgs A) {
+template <int Q, int SB, typename R>
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_forward_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB> TM;
+  typedef Team32<Q, SB, R> TM;
+  typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
   TM tm;
@@ -307,28 +359,28 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_forwar
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   double pen_local = 0.0, pen_uniform = 0.0;
   unsigned long long napply = 0;
-  f2* traj = reinterpret_cast<f2*>(A.traj);
 
   for (int s = 0; s < A.nsub; s++) {
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
     tm.st.prep(c);
-    const float hf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.h)));
+    const R hf = uniform((R)c.h);
     f2 xs[EPT];
 #pragma unroll
-    for (int j = 0; j < EPT; j++) xs[j] = to_f2(x[j]);
-    if (traj) {
-      f2* dst = traj + ((size_t)s * A.nb + ic) * DIM;
+    for (int j = 0; j < EPT; j++) xs[j] = to_r2<R>(x[j]);
+    if (A.traj) {
 #pragma unroll
-      for (int j = 0; j < EPT; j++) dst[tm.elem(j)] = xs[j];
+      for (int j = 0; j < EPT; j++) Traj<R>::store(A.traj, (size_t)s * A.nb + ic, DIM, tm.elem(j), xs[j]);
     }
     tm.publish(xs);
+    tm.park(x);  // the fp64 accumulators are dead weight during the solve
     f2 rhs[EPT], k[EPT];
     tm.template apply_all<false>(xs, rhs);  // rhs = M x (ImplMidpoint::evolveFWD, timestepper.cpp:594)
-    napply += 1 + tm.template neumann<false>(A, 0.5f * hf, rhs, k);
+    napply += 1 + tm.template neumann<false>(A, (R)0.5 * hf, rhs, k);
+    tm.unpark(x);
     const double h = to_scalar(c.h);
 #pragma unroll
-    for (int j = 0; j < EPT; j++) {  // x += h k: fp64 accumulation of the fp32 stage
+    for (int j = 0; j < EPT; j++) {  // x += h k: fp64 accumulation of the stage
       x[j].x = fma(h, (double)k[j].x, x[j].x);
       x[j].y = fma(h, (double)k[j].y, x[j].y);
     }
@@ -341,7 +393,7 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_forwar
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         double jr = 0.0, ji = 0.0;
-        evalJ_part<true>(S, A.tg, ic, tm.elem(j), x[j], jr, ji);
+        evalJ_part<true>(S, A.tg, ic, opaque(tm.elem(j)), x[j], jr, ji);
         pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
       }
       if (A.tg.objective_type == QD_OBJ_JTRACE) pen_uniform += weight * A.dt;
@@ -354,10 +406,9 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_forwar
       xT[tm.elem(j)] = x[j].x;
       xT[DIM + tm.elem(j)] = x[j].y;
     }
-    if (traj) {
-      f2* dst = traj + ((size_t)A.nsub * A.nb + ic) * DIM;
+    if (A.traj) {
 #pragma unroll
-      for (int j = 0; j < EPT; j++) dst[tm.elem(j)] = to_f2(x[j]);
+      for (int j = 0; j < EPT; j++) Traj<R>::store(A.traj, (size_t)A.nsub * A.nb + ic, DIM, tm.elem(j), to_r2<R>(x[j]));
     }
   }
   double v[1] = {pen_local};
@@ -370,18 +421,18 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_forwar
 }
 
 // ---------------------------------------------------------------------------------------------
-// adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams), fp32-mixed
+// adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int SB>
-__global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_adjoint_q32(const SweepArgs A) {
+template <int Q, int SB, typename R>
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_adjoint_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB> TM;
+  typedef Team32<Q, SB, R> TM;
+  typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
   const int ic = blockIdx.x;
-  const f2* traj = reinterpret_cast<const f2*>(A.traj);
   double2 xb[EPT];  // the adjoint state: fp64 accumulators
   {
     const double* xbT = A.xbarT + (size_t)ic * 2 * DIM;
@@ -401,47 +452,52 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_adjoin
       const double weight = 1.0 / A.penalty_param * exp(-(a * a));
       double rb, ib;
       finalizeJ_diff<true>(A.tg, 0.0, 0.0, rb, ib);
-      const f2* src = traj + ((size_t)(s + 1) * A.nb + ic) * DIM;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const f2 v = src[tm.elem(j)];
-        evalJ_diff_elem<true>(S, A.tg, ic, tm.elem(j), make_double2(v.x, v.y), xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+        const f2 v = Traj<R>::load(A.traj, (size_t)(s + 1) * A.nb + ic, DIM, tm.elem(j));
+        evalJ_diff_elem<true>(S, A.tg, ic, opaque(tm.elem(j)), make_double2(v.x, v.y), xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
       }
     }
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
     tm.st.prep(c);
-    const float hf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c.h)));
+    const R hf = uniform((R)c.h);
     f2 x[EPT], z[EPT];
-    {
-      const f2* src = traj + ((size_t)s * A.nb + ic) * DIM;
 #pragma unroll
-      for (int j = 0; j < EPT; j++) x[j] = src[tm.elem(j)];
-    }
+    for (int j = 0; j < EPT; j++) x[j] = Traj<R>::load(A.traj, (size_t)s * A.nb + ic, DIM, tm.elem(j));
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694): primal stage (I - h/2 M) k = M x ; z = x + h/2 k
     tm.publish(x);
+    tm.park(xb);  // the fp64 adjoint accumulators are dead weight until xbar += M^T kbar
     {
       f2 rhs[EPT];
       tm.template apply_all<false>(x, rhs);
-      tm.template neumann<false>(A, 0.5f * hf, rhs, z);
+      tm.template neumann<false>(A, (R)0.5 * hf, rhs, z);
+    }
+    if (TM::PARK) {  // x is cheaper to re-read (L2) than to keep across the solve
+#pragma unroll
+      for (int j = 0; j < EPT; j++) x[j] = Traj<R>::load(A.traj, (size_t)s * A.nb + ic, DIM, opaque(tm.elem(j)));
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      z[j].x = fmaf(0.5f * hf, z[j].x, x[j].x);
-      z[j].y = fmaf(0.5f * hf, z[j].y, x[j].y);
+      z[j].x = rfma((R)0.5 * hf, z[j].x, x[j].x);
+      z[j].y = rfma((R)0.5 * hf, z[j].y, x[j].y);
     }
     // adjoint stage (I - h/2 M)^T kbar = xbar ; kbar *= h
     f2 kb[EPT], bb[EPT];
+    if (TM::PARK) {
 #pragma unroll
-    for (int j = 0; j < EPT; j++) bb[j] = to_f2(xb[j]);
-    tm.template neumann<true>(A, 0.5f * hf, bb, kb);
+      for (int j = 0; j < EPT; j++) bb[j] = to_r2<R>(tm.acc[tm.elem(j)]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPT; j++) bb[j] = to_r2<R>(xb[j]);
+    }
+    tm.template neumann<true>(A, (R)0.5 * hf, bb, kb);
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       kb[j].x *= hf;
       kb[j].y *= hf;
     }
-    // gradient coefficients x^T dM/dp_k z, x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604): fp32 products,
-    // fp64 sums
+    // gradient coefficients x^T dM/dp_k z, x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604): products in R, fp64 sums
     tm.publish(z);
     double cf[2 * Q];
 #pragma unroll
@@ -454,8 +510,8 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_adjoin
         for (int k = 0; k < Q; k++) {
           f2 Av, Bv;
           tm.st.ladder(sx, k, j, Av, Bv);
-          cf[2 * k] += (double)fmaf(Bv.y, kb[j].x, -Bv.x * kb[j].y);
-          cf[2 * k + 1] += (double)fmaf(Av.x, kb[j].x, Av.y * kb[j].y);
+          cf[2 * k] += (double)rfma(Bv.y, kb[j].x, -Bv.x * kb[j].y);
+          cf[2 * k + 1] += (double)rfma(Av.x, kb[j].x, Av.y * kb[j].y);
         }
       }
     }
@@ -470,6 +526,7 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_adjoin
     tm.publish(kb);
     f2 t[EPT];
     tm.template apply_all<true>(kb, t);
+    tm.unpark(xb);
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       xb[j].x += (double)t[j].x;
@@ -486,12 +543,13 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_adjoin
   }
 }
 
-// single operator application in fp32 (test hook: qd_apply_rhs with QD_PRECISION_F32MIXED)
-template <int Q, int SB>
-__global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_apply_q32(const DevSys S, const double* __restrict__ ctlrow, int transpose,
-                                                               const double* __restrict__ xin, double* __restrict__ yout, int nrep) {
+// single operator application (test hook: qd_apply_rhs with QD_PRECISION_F32MIXED; timing loop of the MFMA measurement)
+template <int Q, int SB, typename R>
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_apply_q32(const DevSys S, const double* __restrict__ ctlrow, int transpose,
+                                                                                         const double* __restrict__ xin, double* __restrict__ yout, int nrep) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB> TM;
+  typedef Team32<Q, SB, R> TM;
+  typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   TM tm;
   tm.init(S, smem);
@@ -499,17 +557,20 @@ __global__ void __launch_bounds__((Q32<Q, SB>::NT), (Q32<Q, SB>::MINW)) k_apply_
   f2 x[EPT], y[EPT];
   const double* x0 = xin + (size_t)ic * 2 * DIM;
 #pragma unroll
-  for (int j = 0; j < EPT; j++) x[j] = make_float2((float)x0[tm.elem(j)], (float)x0[DIM + tm.elem(j)]);
+  for (int j = 0; j < EPT; j++) x[j] = to_r2<R>(make_double2(x0[tm.elem(j)], x0[DIM + tm.elem(j)]));
   StepC<Q> c;
   load_step<Q>(ctlrow, c, false);
   tm.st.prep(c);
   tm.publish(x);
   if (transpose) tm.template apply_all<true>(x, y);
   else tm.template apply_all<false>(x, y);
-  // nrep > 1: timing loop of the fp32-stencil-vs-MFMA measurement (y <- M (1e-3 y), keeps the values bounded)
+  // nrep > 1: timing loop of the stencil-vs-MFMA measurement (y <- M (1e-3 y), keeps the values bounded)
   for (int r = 1; r < nrep; r++) {
 #pragma unroll
-    for (int j = 0; j < EPT; j++) x[j] = make_float2(1e-3f * y[j].x, 1e-3f * y[j].y);
+    for (int j = 0; j < EPT; j++) {
+      x[j].x = (R)1e-3 * y[j].x;
+      x[j].y = (R)1e-3 * y[j].y;
+    }
     tm.publish(x);
     if (transpose) tm.template apply_all<true>(x, y);
     else tm.template apply_all<false>(x, y);
@@ -650,38 +711,47 @@ static int q32_slot_bits(int Q) {
   return 0;
 }
 
-template <int Q, int SB>
+template <int Q, int SB, typename R>
 static hipError_t go_fwd(const SweepArgs& a, hipStream_t st) {
-  constexpr int nt = Q32<Q, SB>::NT;
-  const size_t lds = Team32<Q, SB>::lds_bytes();
-  hipLaunchKernelGGL((k_forward_q32<Q, SB>), dim3(a.nb), dim3(nt), lds, st, a);
+  constexpr int nt = Q32<Q, SB, R>::NT;
+  const size_t lds = Team32<Q, SB, R>::lds_bytes();
+  auto kf = k_forward_q32<Q, SB, R>;
+  hipError_t e = set_lds32(kf, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3(a.nb), dim3(nt), lds, st, a);
   return hipGetLastError();
 }
-template <int Q, int SB>
+template <int Q, int SB, typename R>
 static hipError_t go_adj(const SweepArgs& a, hipStream_t st) {
-  constexpr int nt = Q32<Q, SB>::NT;
-  const size_t lds = Team32<Q, SB>::lds_bytes();
-  hipLaunchKernelGGL((k_adjoint_q32<Q, SB>), dim3(a.nb), dim3(nt), lds, st, a);
+  constexpr int nt = Q32<Q, SB, R>::NT;
+  const size_t lds = Team32<Q, SB, R>::lds_bytes();
+  auto kf = k_adjoint_q32<Q, SB, R>;
+  hipError_t e = set_lds32(kf, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3(a.nb), dim3(nt), lds, st, a);
   return hipGetLastError();
 }
-template <int Q, int SB>
+template <int Q, int SB, typename R>
 static hipError_t go_app(const DevSys& S, const double* ctlrow, int tr, const double* x, double* y, int nb, int nrep, hipStream_t st) {
-  constexpr int nt = Q32<Q, SB>::NT;
-  const size_t lds = Team32<Q, SB>::lds_bytes();
-  hipLaunchKernelGGL((k_apply_q32<Q, SB>), dim3(nb), dim3(nt), lds, st, S, ctlrow, tr, x, y, nrep);
+  constexpr int nt = Q32<Q, SB, R>::NT;
+  const size_t lds = Team32<Q, SB, R>::lds_bytes();
+  auto kf = k_apply_q32<Q, SB, R>;
+  hipError_t e = set_lds32(kf, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3(nb), dim3(nt), lds, st, S, ctlrow, tr, x, y, nrep);
   return hipGetLastError();
 }
 
 hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q);
-  if (a.S.Q == 5) return go_fwd<5, 2>(a, st);
-  if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2>(a, st) : go_fwd<4, 0>(a, st);
+  if (a.S.Q == 5) return go_fwd<5, 2, float>(a, st);
+  if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2, float>(a, st) : go_fwd<4, 0, float>(a, st);
   return hipErrorInvalidValue;
 }
 hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q);
-  if (a.S.Q == 5) return go_adj<5, 2>(a, st);
-  if (a.S.Q == 4) return sb == 2 ? go_adj<4, 2>(a, st) : go_adj<4, 0>(a, st);
+  if (a.S.Q == 5) return go_adj<5, 2, float>(a, st);
+  if (a.S.Q == 4) return sb == 2 ? go_adj<4, 2, float>(a, st) : go_adj<4, 0, float>(a, st);
   return hipErrorInvalidValue;
 }
 hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
@@ -692,9 +762,22 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
     return hipGetLastError();
   }
   const int sb = q32_slot_bits(S.Q);
-  if (S.Q == 5) return go_app<5, 2>(S, ctlrow, transpose, x, y, nb, nrep, st);
-  if (S.Q == 4) return sb == 2 ? go_app<4, 2>(S, ctlrow, transpose, x, y, nb, nrep, st) : go_app<4, 0>(S, ctlrow, transpose, x, y, nb, nrep, st);
+  if (S.Q == 5) return go_app<5, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
+  if (S.Q == 4) return sb == 2 ? go_app<4, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st) : go_app<4, 0, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   return hipErrorInvalidValue;
+}
+
+// fp64 instantiation of the lean slot kernel: the Neumann sweeps of the 2^5 Lindblad system in QD_PRECISION_F64
+bool lean64_available(const DevSys& S) {
+  if (!S.lindblad || S.dense || S.hasJ || S.Q != 5) return false;
+  for (int k = 0; k < S.Q; k++)
+    if (S.n[k] != 2 || S.ness[k] != 2) return false;
+  return !getenv("QD_NO_LEAN64");
+}
+hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st) { return go_fwd<5, 2, double>(a, st); }
+hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st) { return go_adj<5, 2, double>(a, st); }
+hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
+  return go_app<5, 2, double>(S, ctlrow, transpose, x, y, nb, 1, st);
 }
 
 }  // namespace qd

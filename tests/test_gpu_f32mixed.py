@@ -1,0 +1,134 @@
+"""QD_PRECISION_F32MIXED (BASELINE config 5 "fp32 mixed"): fp32 exchange vector / stencil / solver iterates, fp64
+state accumulators, objective sums and gradient coefficients - against the fp64 CPU oracle.
+
+Error budget (measured on MI355X at ntime 1000: objective 4e-11 .. 1.1e-10 relative, fidelity 4e-11 .. 1.1e-10, gradient
+2.3e-8 .. 4.4e-8 of its norm; 5.3e-7 on the short IMR4 case below, whose gradient norm is only 2.7e-3; the acceptance
+tolerances leave a margin on top; SURVEY 8(d) "Precision"):
+  one operator application      5e-7 relative to max |y|          (fp32 round-off of ~27 products per element)
+  objective, ntime 1000         1e-8 relative
+  fidelity, ntime 1000          1e-8 absolute
+  gradient                      2e-6 of the gradient norm
+The state and adjoint-state accumulators are fp64, so the fp32 round-off of the increments h k does not accumulate over
+the time loop - that is why the budget is so much tighter than fp32 epsilon x ntime.
+The fp64 path stays the default and keeps its 1e-8 gradient tolerance (tests/test_gpu_parity.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, synthetic_spec
+from oracle.oracle import Oracle
+from quandary_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+APPLY_TOL, OBJ_RTOL, FID_ATOL, GRAD_TOL = 5e-7, 1e-8, 1e-8, 2e-6
+
+
+def _spec(q, init, ntime, penalties=False, stepper="IMR"):
+    sp = synthetic_spec([2] * q, lindblad=True, ntime=ntime, dt=0.01, nspline=30, linsolve="neumann", init=init, penalties=penalties, stepper=stepper)
+    return sp
+
+
+@pytest.mark.parametrize("q", [4, 5])
+def test_f32_operator_application(q):
+    sp = _spec(q, "diagonal, 0", 10)
+    sp.precision = "f32mixed"
+    h, orc = capi.Handle(sp), Oracle(sp)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 2 * h.dim))
+    t = 0.037
+    for tr in (False, True):
+        y, yo = h.apply_rhs(t, x, transpose=tr), orc.apply_rhs(t, x, transpose=tr)
+        assert np.abs(y - yo).max() <= APPLY_TOL * np.abs(yo).max()
+    h.close(); orc.close()
+
+
+@pytest.mark.parametrize("q,init,penalties", [(4, "basis, 0, 1", False), (4, "diagonal, 0, 1", True), (5, "diagonal, 0", False), (5, "basis, 4", True)])
+def test_f32_objective_and_gradient_budget_ntime1000(q, init, penalties):
+    """The stated budget over ntime = 1000 (the length of the C5 / q4 workloads) against the fp64 oracle."""
+    sp = _spec(q, init, 1000, penalties)
+    orc = Oracle(sp)
+    oval, og = orc.evalGradF(sp.params0)
+    sp.precision = "f32mixed"
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    val2 = opt.evalF(sp.params0)
+    errs = {"objective_rel": abs(val["objective"] - oval["objective"]) / abs(oval["objective"]),
+            "fidelity_abs": abs(val["fidelity"] - oval["fidelity"]),
+            "gradient_rel_norm": float(np.linalg.norm(g - og) / np.linalg.norm(og)),
+            "rhs_applications_per_step": h.mean_applies}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "f32_errors.jsonl"), "a") as f:
+        f.write(json.dumps({"q": q, "init": init, "penalties": penalties, **errs}) + "\n")
+    assert errs["objective_rel"] <= OBJ_RTOL, errs
+    assert errs["fidelity_abs"] <= FID_ATOL, errs
+    assert errs["gradient_rel_norm"] <= GRAD_TOL, errs
+    assert val2["objective"] == pytest.approx(val["objective"], rel=1e-12)  # evalF and evalGradF run the same forward sweep
+    opt.close(); h.close(); orc.close()
+
+
+def test_f32_compositional_stepper_and_trajectory():
+    """IMR4 sub-steps and the fp32 trajectory store (qd_get_state converts back to the reference layout)."""
+    sp = _spec(4, "diagonal, 0, 1", 40, penalties=True, stepper="IMR4")
+    orc = Oracle(sp)
+    oval, og = orc.evalGradF(sp.params0)
+    _, traj, fin = orc.evalF(sp.params0, out_freq=20, want_final=True)
+    sp.precision = "f32mixed"
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert val["objective"] == pytest.approx(oval["objective"], rel=OBJ_RTOL)
+    assert np.linalg.norm(g - og) <= GRAD_TOL * np.linalg.norm(og)
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(opt.ninit_local)])
+    h.set_params(sp.params0)
+    res = h.forward(x0, store_trajectory=True)
+    np.testing.assert_allclose(res["final_states"], fin, rtol=0, atol=2e-6)
+    for j, n in enumerate((0, 20, 40)):
+        np.testing.assert_allclose(h.get_state(n, x0.shape[0]), traj[:, j, :], rtol=0, atol=2e-6)
+    opt.close(); h.close(); orc.close()
+
+
+def test_f32_is_opt_in_and_rejected_where_not_built():
+    sp = synthetic_spec([2, 2, 2], lindblad=True, ntime=5)  # three qubits: not built
+    sp.precision = "f32mixed"
+    with pytest.raises(capi.QuandaryAmdError, match="fp32-mixed"):
+        capi.Handle(sp)
+    sp = synthetic_spec([2] * 4, lindblad=True, ntime=5, linsolve="gmres")
+    sp.precision = "f32mixed"
+    with pytest.raises(capi.QuandaryAmdError, match="Neumann"):
+        capi.Handle(sp)
+    sp = synthetic_spec([2] * 4, lindblad=True, ntime=5)
+    h = capi.Handle(sp)
+    assert h.lib.qd_get_precision(h._h) == 0  # fp64 unless asked
+    h.close()
+
+
+def test_mfma_f32_dense_product_vs_stencil():
+    """The MFMA question, measured: Y = G rho - rho G on v_mfma_f32_32x32x2_f32 (one wave per initial condition) against
+    the fp32 stencil kernel on 1024 initial conditions of the 2^5 Lindblad system; both agree with the fp64 oracle, the
+    timings go to gpurun_out/mfma_f32_vs_stencil.json (DESIGN.md quotes them)."""
+    sp = _spec(5, "diagonal, 0", 10)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    rng = np.random.default_rng(11)
+    t = 0.041
+    x = rng.standard_normal((2, 2 * h.dim))
+    yo = orc.apply_rhs(t, x)
+    for mfma in (False, True):
+        y, _ = h.bench_apply_f32(t, x, nrep=1, mfma=mfma)
+        assert np.abs(y - yo).max() <= APPLY_TOL * np.abs(yo).max(), mfma
+    xb = rng.standard_normal((1024, 2 * h.dim))
+    out = {}
+    for mfma in (False, True):
+        ms = min(h.bench_apply_f32(t, xb, nrep=200, mfma=mfma)[1] for _ in range(3))
+        out["mfma" if mfma else "stencil"] = {"ms_per_200_applications_x_1024_states": ms, "us_per_application_x_1024_states": ms * 1e3 / 200}
+    out["stencil_over_mfma_speed"] = out["mfma"]["ms_per_200_applications_x_1024_states"] / out["stencil"]["ms_per_200_applications_x_1024_states"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "mfma_f32_vs_stencil.json"), "w"), indent=1)
+    h.close(); orc.close()
