@@ -143,12 +143,14 @@ struct Output {
   std::vector<strvec> outputstr;
   bool full = false, ecomp = false, pcomp = false;
   std::vector<bool> wexp, wpop;
-  void init(const Config& cfg, int Q) {
+  bool root = true;  // rank 0 writes the shared files (history, gradient, parameters, controls); every rank its own trajectories
+  void init(const Config& cfg, int Q, bool is_root) {
+    root = is_root;
     datadir = cfg.str("datadir", "./data_out");
     mkdir(datadir.c_str(), 0777);
     optim_monitor_freq = cfg.integer("optim_monitor_frequency", 10);
     output_frequency = cfg.integer("output_frequency", 1);
-    optimfile = fopen((datadir + "/optim_history.dat").c_str(), "w");
+    optimfile = fopen(root ? (datadir + "/optim_history.dat").c_str() : "/dev/null", "w");
     if (!optimfile) die("cannot write to " + datadir);
     fprintf(optimfile,
             "#\"iter\"    \"Objective\"           \"||Pr(grad)||\"           \"LS step\"           \"F_avg\"           \"Terminal cost\"   "
@@ -173,6 +175,7 @@ struct Output {
     fflush(optimfile);
   }
   void write_vec(const char* name, const std::vector<double>& x) {
+    if (!root) return;
     FILE* f = fopen((datadir + "/" + name).c_str(), "w");
     for (double v : x) fprintf(f, "%1.14e\n", v);
     fclose(f);
@@ -530,13 +533,34 @@ static double norm2(const std::vector<double>& v) {
   return sqrt(s);
 }
 
-// Bounded quasi-Newton (projected L-BFGS with Armijo backtracking) standing in for TAO BQNLS
-// (src/optimproblem.cpp:178-189); monitor / stopping rules as TaoMonitor (src/optimproblem.cpp:586-660).
-static void optimize(const Problem& P, Output& out, qd_handle* h, qd_optim* o, std::vector<double>& x, bool quiet) {
+// One rank's view of evalF / evalGradF: single GPU, or this rank's shard behind an RCCL communicator
+// (QD_NRANKS > 1: one process per GPU, src/main.cpp:133-177 without MPI).
+struct Evaluator {
+  qd_optim* o = nullptr;
+  qd_comm* c = nullptr;
+  int rank = 0, nranks = 1;
+  void F(const double* x, qd_objective_value* v) const {
+    if (c) QDCHK(qd_optim_evalF_dist(o, c, x, v, nullptr));
+    else QDCHK(qd_optim_evalF(o, x, v));
+  }
+  void G(const double* x, qd_objective_value* v, double* g) const {
+    if (c) QDCHK(qd_optim_evalGradF_dist(o, c, x, v, g, nullptr));
+    else QDCHK(qd_optim_evalGradF(o, x, v, g));
+  }
+};
+
+// Bounded quasi-Newton standing in for TAO BQNLS (src/optimproblem.cpp:178-189): L-BFGS on the free variables (active
+// set = variables at a bound whose gradient points outwards), strong-Wolfe line search along the projected path
+// (bracketing + cubic zoom, c1 = 1e-4, c2 = 0.9 as More-Thuente's defaults in TAO); monitor, stopping rules and
+// the final trajectory-writing evaluation as TaoMonitor (src/optimproblem.cpp:586-660).  Iterates differ from
+// TAO's by construction (third-party internals); acceptance = reaching the same thresholds in a comparable number
+// of iterations (tests/test_driver_regression.py).
+static void optimize(const Problem& P, Output& out, qd_handle* h, const Evaluator& ev, std::vector<double>& x, bool quiet) {
   const Config& cfg = P.cfg;
   const int n = (int)x.size(), maxiter = cfg.integer("optim_maxiter", 200), mem = 10;
   const double gatol = cfg.dbl("optim_atol", 1e-8), grtol = cfg.dbl("optim_rtol", 1e-4), fatol = cfg.dbl("optim_ftol", 1e-8),
                inftol = cfg.dbl("optim_inftol", 1e-5);
+  const bool root = ev.rank == 0;
   auto project = [&](std::vector<double>& v) { for (int i = 0; i < n; i++) v[i] = std::min(P.bounds[i], std::max(-P.bounds[i], v[i])); };
   auto pgnorm = [&](const std::vector<double>& xx, const std::vector<double>& g) {
     double s = 0.0;
@@ -546,67 +570,135 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, qd_optim* o, s
     }
     return sqrt(s);
   };
+  auto dot = [&](const std::vector<double>& a, const std::vector<double>& b) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; };
   project(x);
-  std::vector<double> g(n), xn(n), gn(n), d(n);
+  std::vector<double> g(n), xn(n), gn(n), d(n), gm(n);
   std::vector<std::vector<double>> S, Y;
   qd_objective_value v{}, vn{};
-  QDCHK(qd_optim_evalGradF(o, x.data(), &v, g.data()));
+  ev.G(x.data(), &v, g.data());
   const double g0 = pgnorm(x, g);
-  double gnorm = g0, step = 0.0;
+  double gnorm = g0, step = 1.0;
+  int nfev = 1;
   for (int it = 0;; it++) {
-    if (it % out.optim_monitor_freq == 0) write_controls(P, out, h, x);
-    out.optim_row(it, v, gnorm, step);
     const char* why = nullptr;
-    if (1.0 - v.fidelity <= inftol) why = "Optimization converged to small infidelity.";
-    else if (v.cost <= fatol) why = "Optimization finished with small final time cost.";
+    if (1.0 - v.fidelity <= inftol) why = "Optimization converged with small infidelity.";
+    else if (v.cost <= fatol) why = "Optimization converged with small final time cost.";
     else if (it >= maxiter) why = "Optimization stopped at maximum number of iterations.";
     else if (gnorm < gatol) why = "Optimization converged with small gradient norm.";
     else if (gnorm / g0 < grtol) why = "Optimization converged with small relative gradient norm.";
+    // history row every optim_monitor_frequency iterations and on the last one (src/optimproblem.cpp:634-645)
+    if (root && (it % out.optim_monitor_freq == 0 || why)) {
+      out.optim_row(it, v, gnorm, step);
+      if (!quiet) printf("%d  %1.14e + %1.14e + %1.14e + %1.14e + %1.14e + %1.14e  Fidelity = %1.14e  ||Grad|| = %1.14e\n", it, v.cost, v.regul,
+                         v.penalty, v.penalty_dpdm, v.penalty_energy, v.penalty_variation, v.fidelity, gnorm);
+    }
     if (why) {
-      if (!quiet) printf("%s\n", why);
+      if (root && !quiet) printf("%s (%d function/gradient evaluations)\n", why, nfev);
       break;
     }
-    // two-loop recursion
-    d = g;
+    if (root && it % out.optim_monitor_freq == 0) write_controls(P, out, h, x);
+    // active set and masked gradient
+    for (int i = 0; i < n; i++) {
+      const bool act = (x[i] <= -P.bounds[i] && g[i] > 0.0) || (x[i] >= P.bounds[i] && g[i] < 0.0);
+      gm[i] = act ? 0.0 : g[i];
+    }
+    // two-loop recursion on the masked gradient
+    d = gm;
     std::vector<double> al(S.size());
     for (int k = (int)S.size() - 1; k >= 0; k--) {
-      double sy = 0, sd = 0;
-      for (int i = 0; i < n; i++) { sy += S[k][i] * Y[k][i]; sd += S[k][i] * d[i]; }
-      al[k] = sd / sy;
+      const double sy = dot(S[k], Y[k]);
+      al[k] = dot(S[k], d) / sy;
       for (int i = 0; i < n; i++) d[i] -= al[k] * Y[k][i];
     }
     if (!S.empty()) {
-      double sy = 0, yy = 0;
-      for (int i = 0; i < n; i++) { sy += S.back()[i] * Y.back()[i]; yy += Y.back()[i] * Y.back()[i]; }
-      for (int i = 0; i < n; i++) d[i] *= sy / yy;
+      const double sc = dot(S.back(), Y.back()) / dot(Y.back(), Y.back());
+      for (int i = 0; i < n; i++) d[i] *= sc;
     }
     for (size_t k = 0; k < S.size(); k++) {
-      double sy = 0, yd = 0;
-      for (int i = 0; i < n; i++) { sy += S[k][i] * Y[k][i]; yd += Y[k][i] * d[i]; }
-      const double be = yd / sy;
+      const double be = dot(Y[k], d) / dot(S[k], Y[k]);
       for (int i = 0; i < n; i++) d[i] += S[k][i] * (al[k] - be);
     }
-    // projected backtracking line search along -d
-    step = 1.0;
-    bool ok = false;
-    for (int ls = 0; ls < 30; ls++) {
-      for (int i = 0; i < n; i++) xn[i] = x[i] - step * d[i];
-      project(xn);
-      QDCHK(qd_optim_evalGradF(o, xn.data(), &vn, gn.data()));
-      double dec = 0.0;
-      for (int i = 0; i < n; i++) dec += g[i] * (x[i] - xn[i]);
-      if (vn.objective <= v.objective - 1e-4 * dec && dec > 0) { ok = true; break; }
-      step *= 0.5;
-    }
-    if (!ok) {  // fall back to steepest descent memory reset
-      if (S.empty()) { if (!quiet) printf("Line search failed.\n"); break; }
+    for (int i = 0; i < n; i++)
+      if (gm[i] == 0.0 && g[i] != 0.0) d[i] = 0.0;  // stay on the active bounds
+    double dphi0 = -dot(g, d);
+    if (!(dphi0 < 0.0)) {  // not a descent direction: restart from steepest descent
       S.clear();
       Y.clear();
+      d = gm;
+      dphi0 = -dot(g, d);
+      if (!(dphi0 < 0.0)) { if (root && !quiet) printf("Projected gradient vanished.\n"); break; }
+    }
+    // strong-Wolfe line search on phi(a) = f(P(x - a d))
+    const double c1 = 1e-4, c2 = 0.9, phi0 = v.objective;
+    auto eval_at = [&](double a, double& phi, double& dphi) {
+      for (int i = 0; i < n; i++) xn[i] = x[i] - a * d[i];
+      project(xn);
+      ev.G(xn.data(), &vn, gn.data());
+      nfev++;
+      phi = vn.objective;
+      dphi = 0.0;
+      for (int i = 0; i < n; i++) {
+        const double raw = x[i] - a * d[i];
+        if (raw > -P.bounds[i] && raw < P.bounds[i]) dphi -= gn[i] * d[i];  // clamped components do not move
+      }
+    };
+    double a = S.empty() ? std::min(1.0, 1.0 / norm2(d)) : 1.0;
+    double a_lo = 0.0, phi_lo = phi0, dphi_lo = dphi0, a_hi = 0.0, phi_hi = 0.0, dphi_hi = 0.0;
+    double phi = 0.0, dphi = 0.0, a_prev = 0.0, phi_prev = phi0, dphi_prev = dphi0;
+    bool ok = false, bracket = false;
+    for (int ls = 0; ls < 12 && !ok; ls++) {
+      eval_at(a, phi, dphi);
+      if (!(phi <= phi0 + c1 * a * dphi0) || (ls > 0 && phi >= phi_prev)) {
+        a_lo = a_prev; phi_lo = phi_prev; dphi_lo = dphi_prev; a_hi = a; phi_hi = phi; dphi_hi = dphi; bracket = true;
+        break;
+      }
+      if (fabs(dphi) <= -c2 * dphi0) { ok = true; break; }
+      if (dphi >= 0.0) {
+        a_lo = a; phi_lo = phi; dphi_lo = dphi; a_hi = a_prev; phi_hi = phi_prev; dphi_hi = dphi_prev; bracket = true;
+        break;
+      }
+      a_prev = a; phi_prev = phi; dphi_prev = dphi;
+      a *= 2.0;
+    }
+    if (!ok && bracket) {
+      for (int z = 0; z < 15 && !ok; z++) {
+        // minimiser of the cubic through (a_lo, phi_lo, dphi_lo), (a_hi, phi_hi, dphi_hi); bisection when it leaves the interval
+        const double dd1 = dphi_lo + dphi_hi - 3.0 * (phi_lo - phi_hi) / (a_lo - a_hi);
+        const double rad = dd1 * dd1 - dphi_lo * dphi_hi;
+        double at = 0.5 * (a_lo + a_hi);
+        if (rad >= 0.0) {
+          const double dd2 = (a_hi > a_lo ? 1.0 : -1.0) * sqrt(rad);
+          const double cand = a_hi - (a_hi - a_lo) * (dphi_hi + dd2 - dd1) / (dphi_hi - dphi_lo + 2.0 * dd2);
+          const double lo = std::min(a_lo, a_hi), hi = std::max(a_lo, a_hi);
+          if (cand > lo + 0.05 * (hi - lo) && cand < hi - 0.05 * (hi - lo)) at = cand;
+        }
+        a = at;
+        eval_at(a, phi, dphi);
+        if (!(phi <= phi0 + c1 * a * dphi0) || phi >= phi_lo) {
+          a_hi = a; phi_hi = phi; dphi_hi = dphi;
+        } else {
+          if (fabs(dphi) <= -c2 * dphi0) { ok = true; break; }
+          if (dphi * (a_hi - a_lo) >= 0.0) { a_hi = a_lo; phi_hi = phi_lo; dphi_hi = dphi_lo; }
+          a_lo = a; phi_lo = phi; dphi_lo = dphi;
+        }
+      }
+      if (!ok && a_lo > 0.0) {  // best point with sufficient decrease
+        a = a_lo;
+        eval_at(a, phi, dphi);
+        ok = phi <= phi0 + c1 * a * dphi0;
+      }
+    }
+    if (!ok) {
+      if (S.empty()) { if (root && !quiet) printf("Line search failed.\n"); break; }
+      S.clear();
+      Y.clear();
+      it--;  // retry this iteration from steepest descent
       continue;
     }
+    step = a;
     std::vector<double> sk(n), yk(n);
-    double sy = 0.0;
-    for (int i = 0; i < n; i++) { sk[i] = xn[i] - x[i]; yk[i] = gn[i] - g[i]; sy += sk[i] * yk[i]; }
+    for (int i = 0; i < n; i++) { sk[i] = xn[i] - x[i]; yk[i] = gn[i] - g[i]; }
+    const double sy = dot(sk, yk);
     if (sy > 1e-12 * norm2(sk) * norm2(yk)) {
       S.push_back(sk);
       Y.push_back(yk);
@@ -617,7 +709,11 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, qd_optim* o, s
     v = vn;
     gnorm = pgnorm(x, g);
   }
-  write_controls(P, out, h, x);
+  // last iteration: controls + one more forward evaluation that writes the trajectory files (src/optimproblem.cpp:647-656)
+  if (root) write_controls(P, out, h, x);
+  double sums[QD_NSUMS];
+  QDCHK(qd_optim_forward_local(ev.o, x.data(), 1, sums));
+  write_trajectories(P, out, h, ev.o);
 }
 
 int main(int argc, char** argv) {
@@ -639,10 +735,23 @@ int main(int argc, char** argv) {
   (void)slash;
   P.cfg.read(cfgfile);
   build(P);
+  // multi-GPU: one process per GPU, started by any launcher that sets QD_RANK / QD_NRANKS (and optionally QD_DEVICE); the
+  // RCCL id travels through the file QD_COMM_FILE (default <datadir>/.qd_comm_id), no MPI involved
+  Evaluator ev;
+  ev.rank = getenv("QD_RANK") ? atoi(getenv("QD_RANK")) : 0;
+  ev.nranks = getenv("QD_NRANKS") ? atoi(getenv("QD_NRANKS")) : 1;
+  if (ev.nranks < 1 || ev.rank < 0 || ev.rank >= ev.nranks) die("QD_RANK / QD_NRANKS out of range");
+  if (ev.rank != 0) quiet = true;
   Output out;
-  out.init(P.cfg, P.Q);
+  out.init(P.cfg, P.Q, ev.rank == 0);
   qd_handle* h = nullptr;
-  QDCHK(qd_create(&P.sys, &P.ctl, &P.tg, &P.sol, P.cfg.integer("device", 0), &h));
+  int device = P.cfg.integer("device", 0);
+  if (ev.nranks > 1) {
+    const int ndev = qd_device_count();
+    if (ndev < 1) die("no HIP device visible");
+    device = getenv("QD_DEVICE") ? atoi(getenv("QD_DEVICE")) : ev.rank % ndev;
+  }
+  QDCHK(qd_create(&P.sys, &P.ctl, &P.tg, &P.sol, device, &h));
   if (qd_ndesign(h) != (int)P.params0.size()) die("internal: parameter count mismatch");
   {  // user-supplied Hamiltonians (src/main.cpp:309-316, src/hamiltonianfilereader.cpp)
     const std::string fsys = P.cfg.str("hamiltonian_file_Hsys", "none"), fc = P.cfg.str("hamiltonian_file_Hc", "none");
@@ -682,7 +791,13 @@ int main(int argc, char** argv) {
     }
   }
   qd_optim* o = nullptr;
-  QDCHK(qd_optim_create(h, &P.obj, 0, 1, &o));
+  QDCHK(qd_optim_create(h, &P.obj, ev.rank, ev.nranks, &o));
+  ev.o = o;
+  const std::string idfile = getenv("QD_COMM_FILE") ? getenv("QD_COMM_FILE") : out.datadir + "/.qd_comm_id";
+  if (ev.nranks > 1 || getenv("QD_FORCE_COMM")) {  // (QD_FORCE_COMM: one-rank communicator, exercises the RCCL path on a one-GPU box)
+    QDCHK(qd_comm_create_from_file(idfile.c_str(), ev.rank, ev.nranks, device, 120.0, &ev.c));
+    if (!quiet) printf("RCCL communicator over %d ranks (one GPU each); %d initial conditions per rank.\n", ev.nranks, qd_optim_ninit_local(o));
+  }
   if (!quiet) {
     printf("Number of initial conditions: %d\n", qd_optim_ninit(o));
     printf("State dimension (complex): %d\nTime: [0:%g], N=%d, dt=%g\nNumber of control parameters: %d\n", qd_dim(h), P.ntime * P.dt, P.ntime, P.dt,
@@ -693,37 +808,53 @@ int main(int argc, char** argv) {
   const auto t0 = std::chrono::steady_clock::now();
   qd_objective_value v{};
   double gnorm = 0.0;
+  const bool root = ev.rank == 0;
   if (runtype == "simulation") {
-    write_controls(P, out, h, x);
+    if (root) write_controls(P, out, h, x);
     double sums[QD_NSUMS];
     QDCHK(qd_optim_forward_local(o, x.data(), 1, sums));
+    if (ev.c) QDCHK(qd_comm_allreduce(ev.c, sums, QD_NSUMS, 0));
     QDCHK(qd_optim_finalize(o, x.data(), sums, &v));
     write_trajectories(P, out, h, o);
     if (!quiet) printf("\nTotal objective = %1.14e, \n", v.objective);
   } else if (runtype == "gradient") {
-    write_controls(P, out, h, x);
-    double sums[QD_NSUMS];
-    QDCHK(qd_optim_forward_local(o, x.data(), 1, sums));
-    QDCHK(qd_optim_finalize(o, x.data(), sums, &v));
-    write_trajectories(P, out, h, o);
-    QDCHK(qd_optim_adjoint_local(o, x.data(), sums, grad.data()));
+    if (root) write_controls(P, out, h, x);
+    if (ev.c) {  // trajectory files of this rank's initial conditions, then the distributed gradient
+      double sums[QD_NSUMS];
+      QDCHK(qd_optim_forward_local(o, x.data(), 1, sums));
+      write_trajectories(P, out, h, o);
+      ev.G(x.data(), &v, grad.data());
+    } else {
+      double sums[QD_NSUMS];
+      QDCHK(qd_optim_forward_local(o, x.data(), 1, sums));
+      QDCHK(qd_optim_finalize(o, x.data(), sums, &v));
+      write_trajectories(P, out, h, o);
+      QDCHK(qd_optim_adjoint_local(o, x.data(), sums, grad.data()));
+    }
     gnorm = norm2(grad);
     if (!quiet) printf("\nGradient norm: %1.14e\n", gnorm);
     out.write_vec("grad.dat", grad);
   } else if (runtype == "optimization") {
-    optimize(P, out, h, o, x, quiet);
+    optimize(P, out, h, ev, x, quiet);
   } else if (runtype == "evalcontrols") {
-    write_controls(P, out, h, x);
+    if (root) write_controls(P, out, h, x);
   } else {
     printf("\n\n WARNING: Unknown runtype: %s.\n\n", runtype.c_str());
   }
   if (runtype != "optimization") out.optim_row(0, v, gnorm, 0.0);
   const double used = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  if (!quiet) printf("\n Used Time:        %.2f seconds\n Processors used:  1 (MI355X)\n\n", used);
-  FILE* tf = fopen((out.datadir + "/timing.dat").c_str(), "w");  // src/main.cpp:482-487
-  fprintf(tf, "%d  %1.8e\n", 1, used);
-  fclose(tf);
+  if (!quiet) printf("\n Used Time:        %.2f seconds\n Processors used:  %d (MI355X)\n\n", used, ev.nranks);
+  if (root) {
+    FILE* tf = fopen((out.datadir + "/timing.dat").c_str(), "w");  // src/main.cpp:482-487
+    fprintf(tf, "%d  %1.8e\n", ev.nranks, used);
+    fclose(tf);
+  }
   fclose(out.optimfile);
+  if (ev.c) {
+    (void)qd_comm_barrier(ev.c);
+    qd_comm_destroy(ev.c);
+    if (root) remove(idfile.c_str());  // a stale id must not be picked up by the next run
+  }
   qd_optim_destroy(o);
   qd_destroy(h);
   if (!quiet) printf("Output directory: %s\n", out.datadir.c_str());

@@ -121,3 +121,74 @@ def test_optimization_runs_and_descends(tmp_path):
         assert mine[0, col] == pytest.approx(gold[0, col], rel=REF_RTOL, abs=1e-14)
     assert mine[-1, 1] < mine[0, 1]
     assert np.all(np.diff(mine[:, 1]) <= 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,stop_col,threshold_key", [
+    ("cnot", 4, "optim_inftol"),                    # stops on 1 - F_avg <= optim_inftol (Schroedinger gate optimisation, C1)
+    ("xgate", 5, "optim_ftol"),                     # stops on terminal cost <= optim_ftol (Lindblad, 3states, Jfrobenius)
+    ("state-to-state_spline0", 5, "optim_ftol"),    # BSpline0 controls, all penalties, stops on the terminal cost
+])
+def test_optimization_reaches_the_reference_thresholds(case, stop_col, threshold_key, tmp_path):
+    """SURVEY 8(f)3 acceptance: with the reference's own config (unchanged stopping rules, src/optimproblem.cpp:608-624) the
+    bounded quasi-Newton driver reaches the threshold that ended the reference's TAO run, in no more iterations than
+    TAO needed plus a small allowance (the iterates of a different line search differ; the golden files record 17 / 6 /
+    11 iterations), and the final figure of merit is as good as the golden one up to the threshold itself."""
+    src = os.path.join(GOLDEN, case)
+    out = _run(case, str(tmp_path))
+    mine = _load(os.path.join(out, "optim_history.dat"))
+    gold = _load(os.path.join(src, "base", "optim_history.dat"))
+    cfg = dict(l.replace(" ", "").strip().split("=", 1) for l in open(os.path.join(src, case + ".cfg"))
+               if "=" in l and not l.strip().startswith(("#", "/")))
+    thr = float(cfg[threshold_key])
+    final = (1.0 - mine[-1, 4]) if threshold_key == "optim_inftol" else mine[-1, 5]
+    gold_final = (1.0 - gold[-1, 4]) if threshold_key == "optim_inftol" else gold[-1, 5]
+    assert final <= thr, (final, thr)
+    assert gold_final <= thr
+    iters, gold_iters = int(mine[-1, 0]), int(gold[-1, 0])
+    assert iters <= int(1.5 * gold_iters) + 2, (iters, gold_iters)
+    # monitor semantics: optim_monitor_frequency = 1 in these configs -> one row per iteration, objective never increases
+    assert mine.shape[0] == iters + 1
+    assert np.all(np.diff(mine[:, 1]) <= 1e-12)
+    # the last iteration writes controls, parameters and (through one more forward evaluation) the trajectory files
+    for f in ("params.dat", "control0.dat"):
+        assert os.path.exists(os.path.join(out, f))
+    gold_traj = [os.path.basename(g) for pat in ("expected*.dat", "population*.dat", "rho*.dat") for g in glob.glob(os.path.join(src, "base", pat))]
+    for f in gold_traj:
+        assert os.path.exists(os.path.join(out, f)), f
+
+
+@pytest.mark.gpu
+def test_optim_monitor_frequency_gates_history_rows(tmp_path):
+    case = "cnot"
+    src = os.path.join(GOLDEN, case)
+    cfg = open(os.path.join(src, case + ".cfg")).read() + "\noptim_maxiter = 7\noptim_monitor_frequency = 3\n"
+    open(os.path.join(tmp_path, "cnot.cfg"), "w").write(cfg)
+    r = subprocess.run([EXE, "cnot.cfg", "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mine = _load(os.path.join(tmp_path, "data_out", "optim_history.dat"))
+    assert [int(v) for v in mine[:, 0]] == [0, 3, 6, 7]  # every third iteration and the last one (src/optimproblem.cpp:634)
+
+
+@pytest.mark.gpu
+def test_driver_with_rccl_communicator(tmp_path):
+    """The multi-rank mode of the driver (QD_RANK / QD_NRANKS, RCCL id through a file) with a one-rank communicator: the
+    distributed gradient equals the single-process one file by file."""
+    case = "AxC_grad_initBasis0"
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    out1 = _run(case, str(tmp_path / "a"))
+    src = os.path.join(GOLDEN, case)
+    for f in os.listdir(src):
+        if os.path.isfile(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), tmp_path / "b")
+    env = dict(os.environ, QD_RANK="0", QD_NRANKS="1", QD_FORCE_COMM="1")
+    r = subprocess.run([EXE, case + ".cfg"], cwd=tmp_path / "b", capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL communicator" in r.stdout
+    out2 = os.path.join(tmp_path / "b", os.path.relpath(out1, tmp_path / "a"))
+    g1, g2 = _load(os.path.join(out1, "grad.dat")).ravel(), _load(os.path.join(out2, "grad.dat")).ravel()
+    np.testing.assert_allclose(g2, g1, rtol=1e-11, atol=1e-14)
+    h1, h2 = _load(os.path.join(out1, "optim_history.dat")), _load(os.path.join(out2, "optim_history.dat"))
+    np.testing.assert_allclose(h2, h1, rtol=1e-12, atol=1e-15)
+    assert not os.path.exists(os.path.join(out2, ".qd_comm_id"))

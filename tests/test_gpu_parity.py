@@ -553,3 +553,60 @@ def test_error_paths():
     with pytest.raises(capi.QuandaryAmdError):
         capi.Optim(h, sp, rank=0, nranks=3)  # 3 does not divide 4
     h.close()
+
+
+def test_rccl_single_rank_communicator_device_resident_path():
+    """qd_comm_* + qd_optim_evalF_dist / evalGradF_dist on real hardware with a one-rank RCCL communicator (this box has one
+    GPU; two ranks cannot share a device under RCCL): ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on the handle's
+    stream, device-resident partial sums / seed weights / gradient.  Both collective structures: Schroedinger + Jtrace
+    (two all-reduces, the seeds need the reduced cost) and Lindblad (one fused all-reduce of 7 + ndesign doubles)."""
+    lib = capi.load_library()
+    ident = np.zeros(capi.COMM_ID_BYTES, dtype=np.uint8)
+    capi.check(lib.qd_comm_unique_id(ident.ctypes.data_as(capi.c_u8p)), "qd_comm_unique_id")
+    comm = capi.c_void_p()
+    capi.check(lib.qd_comm_create(ident.ctypes.data_as(capi.c_u8p), 0, 1, 0, capi.byref(comm)), "qd_comm_create")
+    assert lib.qd_comm_size(comm) == 1 and lib.qd_comm_rank(comm) == 0
+    buf = np.array([1.5, -2.0, 3.25])
+    capi.check(lib.qd_comm_allreduce(comm, capi.dptr(buf), 3, 0), "qd_comm_allreduce")
+    np.testing.assert_array_equal(buf, [1.5, -2.0, 3.25])
+    for kw in (dict(nlevels=[2, 2], lindblad=False), dict(nlevels=[2, 2, 2], lindblad=True), dict(nlevels=[3, 3], lindblad=True, target="pure", objective="Jfrobenius")):
+        sp = synthetic_spec(**kw, ntime=25, penalties=True)
+        h = capi.Handle(sp)
+        opt = capi.Optim(h, sp)
+        val, g = opt.evalGradF(sp.params0)
+        vd, gd, ms = opt.evalGradF_dist(comm, sp.params0)
+        vf, _ = opt.evalF_dist(comm, sp.params0)
+        for k in OBJ_KEYS:
+            assert vd[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15), k
+            assert vf[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15), k
+        np.testing.assert_allclose(gd, g, rtol=1e-11, atol=1e-15)
+        assert ms[0] >= 0.0 and ms[1] >= 0.0
+        opt.close(); h.close()
+    lib.qd_comm_destroy(comm)
+
+
+def test_bench_two_ranks_matches_one_rank():
+    """`python bench.py --gpus 2` starts its two ranks itself (no launcher), splits the initial conditions (strong scaling)
+    and prints the same objective as the one-GPU run.  With fewer than two GPUs visible the ranks share the device and
+    the collectives go through gloo (RCCL refuses two ranks on one device); the log is kept in gpurun_out/."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    outdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(outdir, exist_ok=True)
+    common = ["--workload", "c2", "--mode", "grad", "--steps", "2", "--warmup", "1", "--ntime", "200", "--no-workloads", "--no-cpu-baseline"]
+    res = {}
+    for n in (1, 2):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + common, capture_output=True, text=True, timeout=600)
+        with open(os.path.join(outdir, f"bench_{n}rank.log"), "w") as f:
+            f.write(p.stdout + "\n--- stderr ---\n" + p.stderr)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[n] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res[2]["n_gpus"] == 2 and res[2]["ranks_seen"] == 2 and res[2]["scaling"] == "strong"
+    assert res[2]["config"]["ninit_per_gpu"] * 2 == res[1]["config"]["ninit"]
+    assert res[2]["config"]["objective"] == pytest.approx(res[1]["config"]["objective"], rel=1e-12)
+    assert set(res[2]["allreduce_ms_per_step"]) == {"objective_sums", "gradient"}
