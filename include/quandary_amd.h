@@ -45,8 +45,10 @@
  * Units follow the reference config file: frequencies in GHz (multiplied by
  * 2*pi inside, src/mastereq.cpp:29-37, src/oscillator.cpp:15-21), times in ns.
  *
- * Supported sizes (QD_ERR_UNSUPPORTED beyond): state dimension dim <= 4096 (one
- * workgroup owns one initial condition); Lindblad 1..5 oscillators (like the
+ * Supported sizes (QD_ERR_UNSUPPORTED beyond): state dimension dim <= QD_MAX_DIM = 2^22 (one
+ * workgroup owns one initial condition; up to 4096 the state lives in the CU's LDS, above it the
+ * vectors of a step live in global memory and are exchanged through L2 - Neumann solver, IMR family);
+ * Lindblad 1..5 oscillators (like the
  * reference's matrix-free templates), Schroedinger 1..8; at most 256 / 64 / 32 / 16
  * levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied
  * Hamiltonians dim <= 1024.  Control segments: "spline", "spline0" (the reference's
@@ -64,6 +66,7 @@ extern "C" {
 
 #define QD_MAX_OSC 8
 #define QD_MAX_PAIRS (QD_MAX_OSC * (QD_MAX_OSC - 1) / 2)
+#define QD_MAX_DIM (1 << 22)
 
 /* error codes */
 #define QD_OK 0

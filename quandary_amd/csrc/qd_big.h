@@ -1,0 +1,448 @@
+// qd_big.h — sweeps for states that do not fit one CU's LDS (dim > 4096): the reference's matrix-free templates go up to
+// <20,20> (Lindblad dim 160 000), <4,4,4,4> (65 536) and <3,3,3,3,3> (59 049) (src/mastereq.cpp:3046-3047, :3150-3151, :3202).
+// One workgroup (1024 threads) still owns one initial condition for the whole time loop, but the vectors of the step
+// (state, right-hand side, solver iterates, adjoint state, ...) live in a per-state work area in global memory and
+// are exchanged through L2 (4 MiB per XCD; workgroup-scope visibility through the fences of __syncthreads()).  Each
+// thread loops over its elements; the per-element invariants (digits, Delta, d) come from a table built once per
+// system (k_big_table) instead of registers.  The stencil itself is GenStencil::apply / ::ladder of qd_device.h with the
+// element's invariants loaded into the (one-slot) stencil object - the same code that the LDS kernels run.
+#pragma once
+#include "qd_device.h"
+
+namespace qd {
+
+constexpr int BIG_NV = 10;      // work vectors per initial condition
+constexpr int BIG_BLOCK = 1024;
+
+// per-element invariants: coef = (Delta, d), dig = (packed bra digits, packed ket digits)
+template <int Q, bool LIND>
+__global__ void k_big_table(const DevSys S, double2* __restrict__ coef, uint2* __restrict__ dig) {
+  constexpr int DB = packed_digit_bits(Q);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.dim) return;
+  const int I = LIND ? e % S.N : e, Ip = LIND ? e / S.N : 0;
+  unsigned dbra = 0, dket = 0;
+  int ia[Q], ipa[Q];
+#pragma unroll
+  for (int k = 0; k < Q; k++) {
+    ia[k] = (I / S.post[k]) % S.n[k];
+    ipa[k] = LIND ? (Ip / S.post[k]) % S.n[k] : 0;
+    dbra |= (unsigned)ia[k] << (DB * k);
+    dket |= (unsigned)ipa[k] << (DB * k);
+  }
+  double hd = 0.0, hdp = 0.0, d = 0.0;
+  int pair = 0;
+#pragma unroll
+  for (int k = 0; k < Q; k++) {
+    hd += S.detune[k] * ia[k] - S.xi[k] / 2.0 * ia[k] * (ia[k] - 1);
+    if (LIND) {
+      hdp += S.detune[k] * ipa[k] - S.xi[k] / 2.0 * ipa[k] * (ipa[k] - 1);
+      d += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
+    }
+#pragma unroll
+    for (int l = k + 1; l < Q; l++) {
+      hd -= S.xikl[pair] * ia[k] * ia[l];
+      if (LIND) hdp -= S.xikl[pair] * ipa[k] * ipa[l];
+      pair++;
+    }
+  }
+  coef[e] = make_double2(hd - hdp, d);
+  dig[e] = make_uint2(dbra, dket);
+}
+
+template <int Q, bool LIND>
+struct BigTeam {
+  typedef GenStencil<Q, LIND, 1, 2> ST;  // one slot, table-driven (non-hoisted) formulation
+  ST st;
+  Lds L;
+  int dim, redslot;
+  const double2* coef;
+  const uint2* dig;
+
+  static size_t lds_bytes(const DevSys& S) { return sizeof(double) * 2 * (size_t)table_len(S) + sizeof(double) * 2 * NRED * (BIG_BLOCK / 64); }
+
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
+    dim = S.dim;
+    redslot = 0;
+    coef = reinterpret_cast<const double2*>(S.ecoef);
+    dig = reinterpret_cast<const uint2*>(S.edig);
+    const int tl = table_len(S);
+    L.buf0 = nullptr;
+    L.bstride = 0;
+    L.tup = reinterpret_cast<double*>(smem);
+    L.tdn = L.tup + tl;
+    L.red = L.tdn + tl;
+    L.bvec = nullptr; L.gmat = nullptr; L.coltab = nullptr; L.kry = nullptr; L.ksc = nullptr;
+    int o = 0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      st.ofs[k] = o;
+      o += S.n[k];
+    }
+    for (int k = 0; k < Q; k++)
+      for (int a = threadIdx.x; a < S.n[k]; a += blockDim.x) {
+        L.tup[st.ofs[k] + a] = (a < S.n[k] - 1) ? sqrt((double)(a + 1)) : 0.0;
+        L.tdn[st.ofs[k] + a] = sqrt((double)a);
+      }
+    st.valid[0] = true;
+    __syncthreads();
+  }
+  // make element e the stencil's slot
+  __device__ __forceinline__ void at(int e) {
+    const double2 cf = coef[e];
+    const uint2 dg = dig[e];
+    st.it[0] = e;
+    st.dw[0] = cf.x;
+    st.dd[0] = cf.y;
+    st.dbra[0] = dg.x;
+    st.dket[0] = dg.y;
+  }
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply(const DevSys& S, const StepC<Q>& c, const double2* __restrict__ src, int e) {
+    at(e);
+    return st.template apply<TRANS>(S, L, src, c, 0, src[e]);
+  }
+  template <int NV>
+  __device__ __forceinline__ void sum(double (&v)[NV]) {
+    block_sum<NV, false>(v, L.red + redslot * NRED * (BIG_BLOCK / 64));
+    redslot ^= 1;
+  }
+  __device__ __forceinline__ float sum_f32(float v) {
+    double* red = L.red + redslot * NRED * (BIG_BLOCK / 64);
+    redslot ^= 1;
+    return block_sum_f32<false>(v, red);
+  }
+
+  // Neumann iteration (timestepper.cpp:697-727): (I - alpha M^{(T)}) y = b, b in Bv; iterates alternate between Ya and Yb.
+  // Returns the vector that holds the solution; *iters = RHS applications.
+  template <bool TRANS>
+  __device__ __forceinline__ double2* neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
+                                              double2* Yb, int* iters) {
+    for (int e = threadIdx.x; e < dim; e += blockDim.x) Ya[e] = Bv[e];
+    __syncthreads();
+    const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
+    const float rel2 = (float)(A.reltol * A.reltol);
+    float d0 = 1.f;
+    int iter;
+    double2 *cur = Ya, *nxt = Yb;
+    for (iter = 0; iter < A.maxiter; iter++) {
+      double dl = 0.0;
+      for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+        const double2 t = apply<TRANS>(A.S, c, cur, e);
+        const double2 bj = Bv[e], yo = cur[e];
+        double2 w;
+        w.x = fma(alpha, t.x, bj.x);
+        w.y = fma(alpha, t.y, bj.y);
+        const double dx = yo.x - w.x, dy = yo.y - w.y;
+        dl += dx * dx + dy * dy;
+        nxt[e] = w;
+      }
+      const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier (and its workgroup-scope fences)
+      double2* t2 = cur;
+      cur = nxt;
+      nxt = t2;
+      if (iter == 0) d0 = d;
+      if (d < 1.f) { iter++; break; }
+      if (d < rel2 * d0) { iter++; break; }
+    }
+    *iters = iter;
+    return cur;
+  }
+};
+
+template <int Q, bool LIND>
+__global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef BigTeam<Q, LIND> TM;
+  const DevSys& S = A.S;
+  TM tm;
+  tm.init(S, smem);
+  const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+  double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
+  double2 *X = W, *B = W + dim, *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *XM1 = W + 4 * (size_t)dim, *XM2 = W + 5 * (size_t)dim;
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+  const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
+  const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
+  const bool jpairs = S.npairs > 0;
+  {
+    const double* x0 = A.x0 + (size_t)ic * 2 * dim;
+    for (int e = tid; e < dim; e += nt) {
+      const double2 v = make_double2(x0[e], x0[dim + e]);
+      X[e] = v;
+      if (dpdm_on) XM1[e] = XM2[e] = v;
+    }
+  }
+  __syncthreads();
+  double pen_local = 0.0, dpdm_local = 0.0, pen_uniform = 0.0;
+  unsigned long long napply = 0;
+  const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
+  for (int s = 0; s < A.nsub; s++) {
+    StepC<Q> c;
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    scalarize<Q>(c, jpairs);
+    c.g = nullptr;
+    if (A.traj) {
+      double* dst = A.traj + ((size_t)s * A.nb + ic) * 2 * dim;
+      for (int e = tid; e < dim; e += nt) {
+        const double2 v = X[e];
+        dst[e] = v.x;
+        dst[dim + e] = v.y;
+      }
+    }
+    for (int e = tid; e < dim; e += nt) B[e] = tm.template apply<false>(S, c, X, e);  // rhs = M x
+    napply++;
+    __syncthreads();
+    if (A.stepper_ee) {
+      for (int e = tid; e < dim; e += nt) {
+        const double2 r = B[e];
+        double2 v = X[e];
+        v.x = fma(c.h, r.x, v.x);
+        v.y = fma(c.h, r.y, v.y);
+        X[e] = v;
+      }
+    } else {
+      int its;
+      const double2* K = tm.template neumann<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
+      napply += its;
+      for (int e = tid; e < dim; e += nt) {
+        const double2 k = K[e];
+        double2 v = X[e];
+        v.x = fma(c.h, k.x, v.x);
+        v.y = fma(c.h, k.y, v.y);
+        X[e] = v;
+      }
+    }
+    __syncthreads();
+    // in-loop penalties at the end of a FULL time step (timestepper.cpp:141-154)
+    if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
+      const int n = (s + 1) / A.nstages - 1;
+      const double tstop = (n + 1) * A.dt;
+      if (pen_on) {
+        double weight = 0.0;
+        if (wj_on) {
+          const double a = (tstop - A.Tfinal) / A.penalty_param;
+          weight = 1.0 / A.penalty_param * exp(-(a * a));
+        }
+        if (wj_reduce) {
+          double v[2] = {0.0, 0.0};
+          for (int e = tid; e < dim; e += nt) evalJ_part<LIND>(S, A.tg, ic, e, X[e], v[0], v[1]);
+          tm.template sum<2>(v);
+          pen_uniform += weight * finalizeJ<LIND>(A.tg, v[0], v[1]) * A.dt;
+        } else if (wj_on) {
+          for (int e = tid; e < dim; e += nt) {
+            double jr = 0.0, ji = 0.0;
+            evalJ_part<LIND>(S, A.tg, ic, e, X[e], jr, ji);
+            pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
+          }
+          if (A.tg.objective_type == QD_OBJ_JTRACE) pen_uniform += weight * A.dt;
+        }
+        if (A.leak_on) {
+          for (int e = tid; e < dim; e += nt) {
+            tm.at(e);
+            if (tm.st.is_guard(S, 0)) {
+              const double2 v = X[e];
+              pen_local += (v.x * v.x + v.y * v.y) / A.ntime;
+            }
+          }
+        }
+      }
+      if (dpdm_on) {
+        for (int e = tid; e < dim; e += nt) {
+          const double2 v = X[e], m1 = XM1[e], m2 = XM2[e];
+          if (n > 0) {
+            const double t1 = v.x * v.x - 2.0 * m1.x * m1.x + m2.x * m2.x;
+            const double t2 = v.y * v.y - 2.0 * m1.y * m1.y + m2.y * m2.y;
+            dpdm_local += dtinv4 * (t1 + t2) * (t1 + t2);
+          }
+          XM2[e] = m1;
+          XM1[e] = v;
+        }
+      }
+    }
+  }
+  {
+    double* xT = A.xT + (size_t)ic * 2 * dim;
+    double* dst = A.traj ? A.traj + ((size_t)A.nsub * A.nb + ic) * 2 * dim : nullptr;
+    for (int e = tid; e < dim; e += nt) {
+      const double2 v = X[e];
+      xT[e] = v.x;
+      xT[dim + e] = v.y;
+      if (dst) {
+        dst[e] = v.x;
+        dst[dim + e] = v.y;
+      }
+    }
+  }
+  double v[2] = {pen_local, dpdm_local};
+  tm.template sum<2>(v);
+  if (tid == 0) {
+    A.pen_out[ic] = v[0] + pen_uniform;
+    A.dpdm_out[ic] = v[1] / A.ntime;
+    atomicAdd(A.napply, napply);
+  }
+}
+
+template <int Q, bool LIND>
+__global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef BigTeam<Q, LIND> TM;
+  const DevSys& S = A.S;
+  TM tm;
+  tm.init(S, smem);
+  const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+  double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
+  double2 *X = W, *B = W + dim, *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *Z = W + 6 * (size_t)dim, *KB = W + 7 * (size_t)dim,
+          *XB = W + 8 * (size_t)dim;
+  const double* traj = A.traj;
+  auto state = [&](int s, int e) {
+    const double* src = traj + ((size_t)s * A.nb + ic) * 2 * dim;
+    return make_double2(src[e], src[dim + e]);
+  };
+  {
+    const double* xbT = A.xbarT + (size_t)ic * 2 * dim;
+    for (int e = tid; e < dim; e += nt) XB[e] = make_double2(xbT[e], xbT[dim + e]);
+  }
+  const double jbar_pen = A.jbar[ic * 3 + 0], jbar_dpdm = A.jbar[ic * 3 + 1];
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+  const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
+  const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
+  const bool jpairs = S.npairs > 0;
+  const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
+  const int ntime = A.ntime;
+  __syncthreads();
+  for (int s = A.nsub - 1; s >= 0; s--) {
+    // ---- penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227)
+    if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
+      const int n = (s + 1) / A.nstages;
+      const double tstop = n * A.dt;
+      double rb = 0.0, ib = 0.0, weight = 0.0;
+      if (wj_on) {
+        const double a = (tstop - A.Tfinal) / A.penalty_param;
+        weight = 1.0 / A.penalty_param * exp(-(a * a));
+        if (wj_reduce) {
+          double v[2] = {0.0, 0.0};
+          for (int e = tid; e < dim; e += nt) evalJ_part<LIND>(S, A.tg, ic, e, state(s + 1, e), v[0], v[1]);
+          tm.template sum<2>(v);
+          finalizeJ_diff<LIND>(A.tg, v[0], v[1], rb, ib);
+        } else {
+          finalizeJ_diff<LIND>(A.tg, 0.0, 0.0, rb, ib);
+        }
+      }
+      for (int e = tid; e < dim; e += nt) {
+        const double2 xn = state(s + 1, e);
+        double2 xb = XB[e];
+        if (dpdm_on) {  // penaltyDpDm_diff (timestepper.cpp:372-442)
+          const double Jb = jbar_dpdm / ntime, xr = xn.x, xi = xn.y;
+          double acc = 0.0;
+          double2 m1 = make_double2(0, 0), m2 = m1, p1 = m1, p2 = m1;
+          if (n > 1) m2 = state((n - 2) * A.nstages, e);
+          if (n > 0) m1 = state((n - 1) * A.nstages, e);
+          if (n < ntime) p1 = state((n + 1) * A.nstages, e);
+          if (n < ntime - 1) p2 = state((n + 2) * A.nstages, e);
+          if (n > 1) acc += 2.0 * ((m2.x * m2.x - 2.0 * m1.x * m1.x + xr * xr) + (m2.y * m2.y - 2.0 * m1.y * m1.y + xi * xi));
+          if (n > 0 && n < ntime) acc += -4.0 * ((m1.x * m1.x - 2.0 * xr * xr + p1.x * p1.x) + (m1.y * m1.y - 2.0 * xi * xi + p1.y * p1.y));
+          if (n < ntime - 1) acc += 2.0 * ((xr * xr - 2.0 * p1.x * p1.x + p2.x * p2.x) + (xi * xi - 2.0 * p1.y * p1.y + p2.y * p2.y));
+          xb.x += acc * 2.0 * xr * dtinv4 * Jb;
+          xb.y += acc * 2.0 * xi * dtinv4 * Jb;
+        }
+        if (wj_on) evalJ_diff_elem<LIND>(S, A.tg, ic, e, xn, xb, weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+        if (pen_on && A.leak_on) {
+          tm.at(e);
+          if (tm.st.is_guard(S, 0)) {
+            xb.x += 2.0 * xn.x * jbar_pen / ntime;
+            xb.y += 2.0 * xn.y * jbar_pen / ntime;
+          }
+        }
+        XB[e] = xb;
+      }
+    }
+    StepC<Q> c;
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    scalarize<Q>(c, jpairs);
+    c.g = nullptr;
+    for (int e = tid; e < dim; e += nt) X[e] = state(s, e);
+    __syncthreads();
+    double cf[2 * Q];
+#pragma unroll
+    for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
+    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694)
+    for (int e = tid; e < dim; e += nt) B[e] = tm.template apply<false>(S, c, X, e);
+    __syncthreads();
+    int its;
+    {
+      const double2* K = tm.template neumann<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
+      for (int e = tid; e < dim; e += nt) {
+        const double2 k = K[e], x = X[e];
+        Z[e] = make_double2(fma(0.5 * c.h, k.x, x.x), fma(0.5 * c.h, k.y, x.y));
+      }
+    }
+    __syncthreads();
+    {
+      const double2* K = tm.template neumann<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
+      for (int e = tid; e < dim; e += nt) {
+        const double2 k = K[e];
+        KB[e] = make_double2(c.h * k.x, c.h * k.y);
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < dim; e += nt) {  // gradient coefficients (mastereq.hpp:553-604) and xbar += M^T kbar
+      tm.at(e);
+      const double2 kb = KB[e];
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        double2 Av, Bv;
+        tm.st.ladder(S, tm.L, Z, k, 0, Av, Bv);
+        cf[2 * k] += Bv.y * kb.x - Bv.x * kb.y;
+        cf[2 * k + 1] += Av.x * kb.x + Av.y * kb.y;
+      }
+      const double2 t = tm.st.template apply<true>(S, tm.L, KB, c, 0, kb);
+      double2 xb = XB[e];
+      xb.x += t.x;
+      xb.y += t.y;
+      XB[e] = xb;
+    }
+    tm.template sum<2 * Q>(cf);
+    {
+      double* co = A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q;
+#pragma unroll
+      for (int i = 0; i < 2 * Q; i++)
+        if (tid == i) co[i] = cf[i];
+    }
+    __syncthreads();
+  }
+  if (A.xbar0) {
+    double* d0 = A.xbar0 + (size_t)ic * 2 * dim;
+    for (int e = tid; e < dim; e += nt) {
+      const double2 v = XB[e];
+      d0[e] = v.x;
+      d0[dim + e] = v.y;
+    }
+  }
+}
+
+template <int Q, bool LIND>
+__global__ void __launch_bounds__(BIG_BLOCK) k_apply_big(const DevSys S, const double* __restrict__ ctlrow, int transpose,
+                                                         const double* __restrict__ xin, double* __restrict__ yout) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  BigTeam<Q, LIND> tm;
+  tm.init(S, smem);
+  const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+  double2* X = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
+  const double* x0 = xin + (size_t)ic * 2 * dim;
+  for (int e = tid; e < dim; e += nt) X[e] = make_double2(x0[e], x0[dim + e]);
+  __syncthreads();
+  StepC<Q> c;
+  load_step<Q>(ctlrow, c, S.npairs > 0);
+  scalarize<Q>(c, S.npairs > 0);
+  c.g = nullptr;
+  double* yo = yout + (size_t)ic * 2 * dim;
+  for (int e = tid; e < dim; e += nt) {
+    const double2 y = transpose ? tm.template apply<true>(S, c, X, e) : tm.template apply<false>(S, c, X, e);
+    yo[e] = y.x;
+    yo[dim + e] = y.y;
+  }
+}
+
+}  // namespace qd

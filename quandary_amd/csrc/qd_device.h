@@ -71,7 +71,9 @@ template <> struct Variant<14> : VariantDef<4, 256, true, false, 1, true, true, 
 // V15: dense operator of a 16 x 16 density matrix (dim 256) as complex 16x16x16 products on the fp64 matrix cores:
 // one wave per initial condition, the state lives in the MFMA accumulator layout
 template <> struct Variant<15> : VariantDef<4, 64, false, true, 1, false, false, true, false, true> {};
-constexpr int NVARIANTS = 16;
+// V16: states beyond one CU's LDS (dim > 4096): work vectors in global memory, exchanged through L2 (qd_big.h)
+template <> struct Variant<16> : VariantDef<1, 1024, false, false> {};
+constexpr int NVARIANTS = 17;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 

@@ -63,7 +63,7 @@ extern "C" void qd_destroy(qd_handle* h) {
   (void)hipSetDevice(h->device);
   for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_res,
-                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
+                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_ecoef, &h->d_edig, &h->d_work, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
   if (h->d_oscs) (void)hipFree(h->d_oscs);
@@ -119,9 +119,13 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     if (S.n[k] > S.maxn) S.maxn = S.n[k];
   }
   long long dim = S.lindblad ? N * N : N;
-  if (dim > 4096) {
+  if (dim > QD_MAX_DIM) {
     delete h;
-    return fail(QD_ERR_UNSUPPORTED, "qd_create: state dimension > 4096 needs the tiled large-system kernels (not built yet)");
+    return fail(QD_ERR_UNSUPPORTED, "qd_create: state dimension above QD_MAX_DIM (2^22)");
+  }
+  if (dim > 4096 && sol->stepper == QD_STEPPER_EE) {
+    delete h;
+    return fail(QD_ERR_UNSUPPORTED, "qd_create: the explicit-Euler debug stepper is not built for state dimensions > 4096");
   }
   {  // packed digits (qd_device.h: packed_digit_bits)
     const int maxlev = S.Q <= 4 ? 256 : S.Q == 5 ? 64 : S.Q == 6 ? 32 : 16;
@@ -431,7 +435,22 @@ extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, doubl
   return QD_OK;
 }
 
+// element table (once per handle) and work vectors (per batch size) of the large-state variant
+int qd_handle::ensure_big(int nb) {
+  int r;
+  if (!d_ecoef.p) {
+    if ((r = d_ecoef.ensure((size_t)2 * S.dim)) || (r = d_edig.ensure((size_t)S.dim))) return r;
+    QD_HIP(launch_big_table(S, d_ecoef.p, reinterpret_cast<unsigned*>(d_edig.p), stream));
+    S.ecoef = d_ecoef.p;
+    S.edig = reinterpret_cast<const unsigned*>(d_edig.p);
+  }
+  if ((r = d_work.ensure(big_work_doubles(S, nb)))) return r;
+  S.work = d_work.p;
+  return QD_OK;
+}
+
 static int check_cfg(const LaunchCfg& cfg) {
+  if (cfg.var == 16 && cfg.gmres) return fail(QD_ERR_UNSUPPORTED, "state dimensions > 4096 are built with the Neumann solver (linearsolver_type = neumann)");
   if (variant_max_block(cfg.var) <= 0 || cfg.block > variant_max_block(cfg.var))
     return fail(QD_ERR_UNSUPPORTED, "state dimension too large for the single-workgroup kernels");
   if (cfg.lds > 160 * 1024) return fail(QD_ERR_UNSUPPORTED, "state does not fit the 160 KiB LDS of one CU");
@@ -451,6 +470,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
   QD_HIP(hipMemcpyAsync(h->d_x0.p, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   LaunchCfg cfg = pick_config(h->S, nb);
   if ((r = check_cfg(cfg))) return r;
+  if (cfg.var == 16 && (r = h->ensure_big(nb))) return r;
   qd::DevSys Sone = h->S;
   if (h->S.dense) {
     if ((r = h->d_gone.ensure((size_t)2 * h->S.N * h->S.N))) return r;
@@ -458,7 +478,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
     Sone.gtab = h->d_gone.p;
   }
   if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
-  else if (lean64_available(h->S) && h->sol.linsolve == QD_LINSOLVE_NEUMANN) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
+  else if (cfg.var != 16 && lean64_available(h->S) && h->sol.linsolve == QD_LINSOLVE_NEUMANN) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
   else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
@@ -558,6 +578,10 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     traj_doubles(nb, &nt);
     if ((r = d_traj.ensure(nt))) return r;
   }
+  {
+    LaunchCfg c0 = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+    if (c0.var == 16 && (r = ensure_big(nb))) return r;
+  }
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   a.x0 = dx0;
@@ -575,7 +599,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if ((r = check_cfg(cfg))) return r;
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
-  const bool lean64 = lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
+  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
@@ -670,6 +694,10 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   const size_t ncol = (size_t)nsub * 2 * S.Q;
   if ((r = d_coeff.ensure((size_t)nb * ncol)) || (r = d_coeffsum.ensure(ncol))) return r;
   if ((r = d_stash.ensure((size_t)2 * nb * 2 * S.dim))) return r;
+  {
+    LaunchCfg c0 = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, true);
+    if (c0.var == 16 && (r = ensure_big(nb))) return r;
+  }
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   a.stash = d_stash.p;
@@ -685,7 +713,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
-  const bool lean64 = lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
+  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, stream));
   else QD_HIP(launch_adjoint(a, cfg, stream));

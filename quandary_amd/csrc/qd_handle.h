@@ -101,6 +101,8 @@ struct qd_handle {
   int target_nb = 0;
   // sweep buffers
   qd::DBuf d_x0, d_xT, d_traj, d_res, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
+  qd::DBuf d_ecoef, d_edig, d_work;  // large states (qd_big.h): element table, work vectors
+  int ensure_big(int nb);            // no-op unless the launch configuration is the large-state variant
   qd::DBuf d_g0, d_hcr, d_hci, d_gtab, d_gone;  // dense user-Hamiltonian path (qd_set_hamiltonian)
   // d_res = [pen nb | dpdm nb | out4 4nb | napply]: one contiguous block, one download per sweep
   double *d_pen = nullptr, *d_dpdm = nullptr, *d_out4 = nullptr;

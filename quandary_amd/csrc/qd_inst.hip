@@ -3,6 +3,7 @@
 // kernels for the kernel variants that make sense for that case and exports plain launch functions
 // for the dispatcher in qd_kernels.hip.
 #include "qd_device.h"
+#include "qd_big.h"
 
 #if !defined(QD_Q) || !defined(QD_L) || !defined(QD_B)
 #error "compile with -DQD_Q=<1..8> -DQD_L=<0|1> -DQD_B=<0 general|1 qubit|2 dense>"
@@ -31,7 +32,7 @@ constexpr bool variant_built() {
   constexpr long kMinDim = kLind ? (1L << (2 * QD_Q)) : (1L << QD_Q);
   constexpr bool fits0 = kMinDim <= 64, fits1 = kMinDim <= 256, fits2 = kMinDim <= 1024;
   if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4);
-  if (!kQubit) return (VAR == 0 && fits0) || (VAR == 1 && fits1) || (VAR == 2 && fits2) || VAR == 4 || (kLind && (VAR == 9 || VAR == 14));
+  if (!kQubit) return (VAR == 0 && fits0) || (VAR == 1 && fits1) || (VAR == 2 && fits2) || VAR == 4 || (kLind && (VAR == 9 || VAR == 14)) || VAR == 16;
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
   return VAR == 2;
@@ -46,7 +47,11 @@ static hipError_t set_lds(K kern, size_t bytes) {
 
 template <int VAR>
 static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (variant_built<VAR>()) {
+  if constexpr (VAR == 16 && variant_built<VAR>()) {
+    if (cfg.gmres) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_forward_big<QD_Q, kLind>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
+    return hipGetLastError();
+  } else if constexpr (variant_built<VAR>()) {
     auto kf = cfg.gmres ? k_forward<QD_Q, kLind, VAR, kQubit, true> : k_forward<QD_Q, kLind, VAR, kQubit, false>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
@@ -58,7 +63,11 @@ static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream
 }
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (variant_built<VAR>()) {
+  if constexpr (VAR == 16 && variant_built<VAR>()) {
+    if (cfg.gmres) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_adjoint_big<QD_Q, kLind>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
+    return hipGetLastError();
+  } else if constexpr (variant_built<VAR>()) {
     auto kf = cfg.gmres ? k_adjoint<QD_Q, kLind, VAR, kQubit, true> : k_adjoint<QD_Q, kLind, VAR, kQubit, false>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
@@ -71,7 +80,10 @@ static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream
 template <int VAR>
 static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                            const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (variant_built<VAR>()) {
+  if constexpr (VAR == 16 && variant_built<VAR>()) {
+    hipLaunchKernelGGL((k_apply_big<QD_Q, kLind>), dim3(nb), dim3(cfg.block), cfg.lds, st, S, ctlrow, transpose, x, y);
+    return hipGetLastError();
+  } else if constexpr (variant_built<VAR>()) {
     auto kf = k_apply<QD_Q, kLind, VAR, kQubit>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
@@ -100,6 +112,7 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
     case 13: return FN<13>(__VA_ARGS__);     \
     case 14: return FN<14>(__VA_ARGS__);     \
     case 15: return FN<15>(__VA_ARGS__);     \
+    case 16: return FN<16>(__VA_ARGS__);     \
     default: return hipErrorInvalidValue;    \
   }
 
@@ -113,5 +126,13 @@ hipError_t QD_NAME(inst_apply_, QD_Q, QD_L, QD_B)(const DevSys& S, const double*
                                                   int nb, const LaunchCfg& cfg, hipStream_t st) {
   QD_VAR_SWITCH(go_apply, S, ctlrow, transpose, x, y, nb, cfg, st)
 }
+
+#if QD_B == 0
+hipError_t QD_NAME(inst_bigtable_, QD_Q, QD_L, QD_B)(const DevSys& S, double* ecoef, unsigned* edig, hipStream_t st) {
+  hipLaunchKernelGGL((k_big_table<QD_Q, kLind>), dim3((S.dim + 255) / 256), dim3(256), 0, st, S, reinterpret_cast<double2*>(ecoef),
+                     reinterpret_cast<uint2*>(edig));
+  return hipGetLastError();
+}
+#endif
 
 }  // namespace qd

@@ -28,6 +28,10 @@ struct DevSys {
   const double* hcr;   // [Q][N*N] Re(Hc_k), row-major
   const double* hci;   // [Q][N*N] Im(Hc_k)
   const double* gtab;  // [rows][N*N] interleaved complex: G(t_row) = -i H(t_row), one row per control-table row
+  // states beyond one CU's LDS (dim > 4096, qd_big.h): per-element invariants and the per-state work vectors in global memory
+  const double* ecoef;   // [dim] (Delta, d)
+  const unsigned* edig;  // [dim] (packed bra digits, packed ket digits)
+  double* work;          // [nb][BIG_NV][dim] interleaved complex
 };
 
 // Control parameterisation on the device (src/oscillator.cpp:45-132, src/controlbasis.cpp:20-32,219-225)
@@ -127,6 +131,8 @@ hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st);
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false, bool adjoint = false);
 size_t krylov_doubles(const DevSys& S, int nb);
+size_t big_work_doubles(const DevSys& S, int nb);
+hipError_t launch_big_table(const DevSys& S, double* ecoef, unsigned* edig, hipStream_t st);
 int variant_max_block(int var);  // 0 for an unknown variant  // size of SweepArgs::kry for LaunchCfg::gmres == 2
 
 void set_error(const std::string& msg);

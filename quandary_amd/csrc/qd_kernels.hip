@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "qd_device.h"
+#include "qd_big.h"
 
 namespace qd {
 
@@ -332,7 +333,7 @@ constexpr VarInfo var_info() {
 static const VarInfo kVar[NVARIANTS] = {var_info<0>(), var_info<1>(), var_info<2>(),  var_info<3>(),  var_info<4>(),
                                         var_info<5>(), var_info<6>(), var_info<7>(),  var_info<8>(),  var_info<9>(),
                                         var_info<10>(), var_info<11>(), var_info<12>(), var_info<13>(), var_info<14>(),
-                                        var_info<15>()};
+                                        var_info<15>(), var_info<16>()};
 int variant_max_block(int var) { return (var >= 0 && var < NVARIANTS) ? kVar[var].maxb : 0; }
 
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
@@ -374,6 +375,16 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
     const int v = atoi(ev);
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
   }
+  // beyond one CU's LDS: work vectors in global memory (qd_big.h); general stencil whatever the level structure.
+  // QD_VAR=16 forces it onto small systems (parity tests of this path against everything the LDS kernels are tested on)
+  if (!S.dense && (dim > 4096 || (getenv("QD_VAR") && atoi(getenv("QD_VAR")) == 16))) {
+    c.var = 16;
+    c.qubit = 0;
+    c.block = BIG_BLOCK;
+    c.gmres = gm ? 2 : 0;
+    c.lds = BigTeam<1, false>::lds_bytes(S);
+    return c;
+  }
   const int epe = kVar[var].ept / kVar[var].icpb;
   c.var = var;
   c.block = kVar[var].col ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
@@ -393,6 +404,8 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   return c;
 }
 
+size_t big_work_doubles(const DevSys& S, int nb) { return (size_t)nb * BIG_NV * 2 * (size_t)S.dim; }
+
 size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G + 1) * 2 * (size_t)S.dim; }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,6 +421,19 @@ QD_DECL_Q(0, 0) QD_DECL_Q(1, 0) QD_DECL_Q(0, 1) QD_DECL_Q(1, 1)
 QD_DECL(6, 0, 0) QD_DECL(7, 0, 0) QD_DECL(8, 0, 0) QD_DECL(6, 0, 1) QD_DECL(7, 0, 1) QD_DECL(8, 0, 1)
 // dense user-Hamiltonian operator
 QD_DECL_Q(0, 2) QD_DECL_Q(1, 2)
+
+#define QD_DECLT(q, l) hipError_t inst_bigtable_##q##_##l##_0(const DevSys&, double*, unsigned*, hipStream_t);
+QD_DECLT(1, 0) QD_DECLT(2, 0) QD_DECLT(3, 0) QD_DECLT(4, 0) QD_DECLT(5, 0) QD_DECLT(6, 0) QD_DECLT(7, 0) QD_DECLT(8, 0)
+QD_DECLT(1, 1) QD_DECLT(2, 1) QD_DECLT(3, 1) QD_DECLT(4, 1) QD_DECLT(5, 1)
+typedef hipError_t (*table_fn)(const DevSys&, double*, unsigned*, hipStream_t);
+static const table_fn big_tab[2][8] = {{inst_bigtable_1_0_0, inst_bigtable_2_0_0, inst_bigtable_3_0_0, inst_bigtable_4_0_0, inst_bigtable_5_0_0,
+                                        inst_bigtable_6_0_0, inst_bigtable_7_0_0, inst_bigtable_8_0_0},
+                                       {inst_bigtable_1_1_0, inst_bigtable_2_1_0, inst_bigtable_3_1_0, inst_bigtable_4_1_0, inst_bigtable_5_1_0,
+                                        nullptr, nullptr, nullptr}};
+hipError_t launch_big_table(const DevSys& S, double* ecoef, unsigned* edig, hipStream_t st) {
+  if (S.Q < 1 || S.Q > 8 || !big_tab[S.lindblad ? 1 : 0][S.Q - 1]) return hipErrorInvalidValue;
+  return big_tab[S.lindblad ? 1 : 0][S.Q - 1](S, ecoef, edig, st);
+}
 
 typedef hipError_t (*sweep_fn)(const SweepArgs&, const LaunchCfg&, hipStream_t);
 typedef hipError_t (*apply_fn)(const DevSys&, const double*, int, const double*, double*, int, const LaunchCfg&, hipStream_t);

@@ -518,9 +518,66 @@ def test_largest_supported_state():
     opt.close(); h.close(); orc.close()
 
 
+BIG_SHAPES = [
+    # shapes the reference instantiates matrix-free templates for beyond dim 4096 (src/mastereq.cpp:3046, :3150): one initial condition
+    pytest.param(dict(nlevels=[9, 9], lindblad=True, nessential=[3, 3], target="pure", objective="Jmeasure", init="pure, 1, 2"), id="9x9-lindblad-dim6561"),
+    pytest.param(dict(nlevels=[3, 3, 3, 3], lindblad=True, nessential=[2, 2, 2, 2], jkl=0.002, detuned=True, init="pure, 1, 0, 1, 0"), id="3^4-lindblad-dim6561-Jkl-gate"),
+    pytest.param(dict(nlevels=[10, 10], lindblad=True, target="pure", objective="Jfrobenius", init="pure, 0, 1"), id="10x10-lindblad-dim10000"),
+    pytest.param(dict(nlevels=[4] * 6 + [2], lindblad=False, nessential=[2] * 7, jkl=0.001, detuned=True, target="pure", objective="Jmeasure", init="pure, 0, 1, 0, 1, 0, 1, 0"), id="4^6x2-schroedinger-dim8192"),
+]
+
+
+@pytest.mark.parametrize("kw", BIG_SHAPES)
+def test_states_beyond_lds_vs_oracle(kw):
+    """dim > 4096 (was QD_ERR_UNSUPPORTED in round 1): the work vectors of a step live in global memory (qd_big.h).
+    Operator, transpose, objective parts and gradient against the oracle, all penalties on."""
+    sp, h, orc = _pair(kw, ntime=4, nspline=5, penalties=True)
+    assert h.dim > 4096
+    rng = np.random.default_rng(21)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    x = rng.standard_normal((2, 2 * h.dim))
+    t = 0.37 * sp.time.ntime * sp.time.dt
+    for tr in (False, True):
+        yo = orc.apply_rhs(t, x, transpose=tr)
+        np.testing.assert_allclose(h.apply_rhs(t, x, transpose=tr), yo, rtol=1e-13, atol=1e-13 * np.abs(yo).max())
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7], SHAPES[8], COL_SHAPES[3]])
+@pytest.mark.parametrize("stepper", ["IMR", "IMR4"])
+def test_global_memory_variant_forced_onto_small_systems(kw, stepper, monkeypatch):
+    """The same kernels (QD_VAR=16) on the small shapes of the LDS kernels: guard levels, dipole-dipole coupling, gates,
+    every penalty (leakage, weighted-J incl. the Schroedinger Jtrace reduction, dpdm), several initial conditions."""
+    monkeypatch.setenv("QD_VAR", "16")
+    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
 def test_unsupported_sizes_fail_loudly():
-    sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0")  # dim 6561
-    with pytest.raises(capi.QuandaryAmdError, match="4096"):
+    sp = synthetic_spec([40, 60], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0")  # dim 5.76e6 > 2^22
+    with pytest.raises(capi.QuandaryAmdError, match="QD_MAX_DIM"):
+        capi.Handle(sp)
+    sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0", linsolve="gmres")
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    with pytest.raises(capi.QuandaryAmdError, match="Neumann"):  # large states: Neumann solver only
+        opt.evalF(sp.params0)
+    opt.close(); h.close()
+    sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0", stepper="EE")
+    with pytest.raises(capi.QuandaryAmdError, match="explicit-Euler"):
         capi.Handle(sp)
 
 
