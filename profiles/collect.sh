@@ -5,7 +5,7 @@
 # usage: profiles/collect.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:---steps 5 --warmup 2 --no-cpu-baseline}
+ARGS=${@:---steps 5 --warmup 2 --no-cpu-baseline --no-workloads}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -62,7 +62,7 @@ def main():
     # roofline.traffic); key = "<workload>_<mode>", taken from a tag like r1_c2_fwd
     parts = tag.split("_")
     if len(parts) >= 3:
-        key = "_".join(parts[-2:])
+        key = "_".join(parts[1:])  # r2_c5_f32_fwd -> c5_f32_fwd
         tot, names = 0.0, []
         for k, v in summary.items():
             if ("k_forward" in k or "k_adjoint" in k) and "hbm_bytes_per_launch_fetch_x2" in v:

@@ -478,6 +478,8 @@ def build_spec(cfg, cfg_dir="."):
     # user-supplied Hamiltonians (src/main.cpp:309-316, src/hamiltonianfilereader.cpp)
     fsys, fc = cfg.get("hamiltonian_file_Hsys", "none"), cfg.get("hamiltonian_file_Hc", "none")
     sp.hamiltonian = None
+    # arithmetic of the sweeps: f64 (reference) or f32mixed (extension of this build, include/quandary_amd.h: qd_set_precision)
+    sp.precision = cfg.get("precision", "f64")
     if fsys != "none" or fc != "none":
         sp.hamiltonian = read_hamiltonian_files(None if fsys == "none" else os.path.join(cfg_dir, fsys),
                                                 None if fc == "none" else os.path.join(cfg_dir, fc), N, Q)

@@ -1861,27 +1861,47 @@ struct Team {
     return napp;
   }
 
-  // The same GMRES for any number of elements per thread and any dimension: the Krylov basis lives in
-  // global memory (A.kry, [nb][GMRES_MR_G + 1][dim] interleaved complex; every thread only ever touches
-  // its own elements of the basis vectors), the vector the stencil reads is published in LDS like a
-  // Neumann iterate.  On exit y is in registers (NOT published).
+  // GMRES for any number of elements per thread and any dimension: the Krylov basis lives in global memory (A.kry,
+  // [nb][GMRES_MR_G + 2][dim] interleaved complex; every thread only ever touches its own elements of the basis
+  // vectors), the vector the stencil reads is published in LDS like a Neumann iterate.  On exit y is in registers (NOT
+  // published).
+  //
+  // A.gmres_poly = p > 1: right preconditioning with the Neumann polynomial P = sum_{i<p} (alpha M)^i, i.e. GMRES on
+  // (I - alpha M) P = I - (alpha M)^p, y = P u.  The residual of the preconditioned system IS the true residual
+  // b - (I - alpha M) y, so the stopping rule max(rtol ||b||, abstol) of the reference is unchanged; what changes is the
+  // path: p applications per Krylov vector, but only ~ (iterations of plain GMRES) / p Krylov vectors.  With the basis in
+  // HBM the cost of plain GMRES is its m^2 + 3m passes over 2 dim doubles per step (3x20 Lindblad: m = 11, 9.7 MB per
+  // step and initial condition); p = 4 needs m = 3.  The polynomial is only used where the Neumann series contracts
+  // (||alpha M v_0|| <= 1/2, decided per solve); otherwise, and with p = 1, this is KSPGMRES + PCNONE iteration for iteration.
   template <bool TRANS>
   __device__ __forceinline__ int gmres_g(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
     static_assert(ICPB == 1, "one initial condition per workgroup");
-    double2* __restrict__ Vg = reinterpret_cast<double2*>(A.kry) + (size_t)ic0 * (GMRES_MR_G + 1) * dim;
+    double2* __restrict__ Vg = reinterpret_cast<double2*>(A.kry) + (size_t)ic0 * (GMRES_MR_G + 2) * dim;
     double* hc = L.ksc;
     double* cs = hc + (GMRES_MR_G + 2);
     double* sn = cs + GMRES_MR_G;
     double* g = sn + GMRES_MR_G;
     double* R = g + (GMRES_MR_G + 2);
     double* yk = R + GMRES_MR_G * GMRES_MR_G;
+    int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;  // may fall back to 1 for this solve, see below
     double2 yy[EPT], r[EPT], v[EPT], w[EPT];
+    int napp = 0;
+    // z <- (alpha M) z, reading z from the published vector
+    auto amul = [&](double2(&z)[EPT]) {
+      double2 t2[EPT];
+      if (ST::NEEDS_SLOTS && !A.S.hasJ) apply_sweep<TRANS, false>(A.S, c, z, t2);
+      else apply_sweep<TRANS, true>(A.S, c, z, t2);
+      napp++;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) z[j] = make_double2(alpha * t2[j].x, alpha * t2[j].y);
+    };
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       yy[j] = make_double2(0.0, 0.0);
       r[j] = b[j];
     }
-    int its = 0, napp = 0;
+    int its = 0;
+    bool have_total = false;  // a restart has parked the accumulated solution in basis slot GMRES_MR_G + 1
     double ttol = 0.0;
     for (int cycle = 0;; cycle++) {
       double t1[1] = {0.0};
@@ -1890,7 +1910,11 @@ struct Team {
       sum<1>(t1);
       const double beta = sqrt(t1[0]);
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
-      if (beta <= ttol || its >= A.maxiter) break;
+      if (beta <= ttol || its >= A.maxiter) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) yy[j] = make_double2(0.0, 0.0);
+        break;
+      }
       const double ibeta = 1.0 / beta;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
@@ -1902,36 +1926,46 @@ struct Team {
       int jj = 0;
       bool conv = false;
       while (jj < GMRES_MR_G) {
-        double2 t2[EPT];
-        if (ST::NEEDS_SLOTS && !A.S.hasJ) apply_sweep<TRANS, false>(A.S, c, v, t2);
-        else apply_sweep<TRANS, true>(A.S, c, v, t2);
-        napp++;
+        // w = (I - (alpha M)^p) v_jj
 #pragma unroll
-        for (int j = 0; j < EPT; j++) w[j] = make_double2(v[j].x - alpha * t2[j].x, v[j].y - alpha * t2[j].y);
-        for (int k0 = 0; k0 <= jj; k0 += 4) {  // classical Gram-Schmidt, four projections per reduction
-          double h4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < EPT; j++) w[j] = v[j];
+        for (int i = 0; i < poly; i++) {
+          if (i > 0) publish(w);
+          amul(w);
+          if (i == 0 && poly > 1 && its == 0) {
+            // The Neumann polynomial only helps where the series contracts.  ||alpha M v_0|| > 1/2 (large time steps, the
+            // case GMRES exists for): plain GMRES for this solve (uniform decision, one extra reduction per solve).
+            double q2[1] = {0.0};
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int k = k0 + q;
-            if (k <= jj) {
-#pragma unroll
-              for (int j = 0; j < EPT; j++)
-                if (ok(j)) {
-                  const double2 vk = Vg[(size_t)k * dim + at_use<EPE>(st.it[j])];
-                  h4[q] += w[j].x * vk.x + w[j].y * vk.y;
-                }
-            }
+            for (int j = 0; j < EPT; j++) q2[0] += ok(j) ? w[j].x * w[j].x + w[j].y * w[j].y : 0.0;
+            sum<1>(q2);
+            if (q2[0] > 0.25) poly = 1;
           }
-          // as many values as there are projections in this block (the first iterations have 1, 2, 3)
-          switch (min(4, jj + 1 - k0)) {
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; j++) w[j] = make_double2(v[j].x - w[j].x, v[j].y - w[j].y);
+        // classical Gram-Schmidt: all projections against the un-updated w, four per block reduction.  (The squared norm of
+        // the orthogonalised vector is NOT taken from ||w||^2 - sum h_k^2: classical Gram-Schmidt loses orthogonality as
+        // the residual falls towards 1e-10 and that identity then misjudges h_{j+1,j} - measured: the recurrence residual
+        // stops tracking the true one and every solve runs to maxiter.)
+        for (int k0 = 0; k0 <= jj; k0 += 4) {
+          double h4[4] = {0.0, 0.0, 0.0, 0.0};
+          const int nk = min(4, jj + 1 - k0);
+          for (int q = 0; q < nk; q++) {
+#pragma unroll
+            for (int j = 0; j < EPT; j++)
+              if (ok(j)) {
+                const double2 vk = Vg[(size_t)(k0 + q) * dim + at_use<EPE>(st.it[j])];
+                h4[q] += w[j].x * vk.x + w[j].y * vk.y;
+              }
+          }
+          switch (nk) {  // as many values as there are projections in this block (the first iterations have 1, 2, 3)
             case 1: sum<1>(reinterpret_cast<double(&)[1]>(h4)); break;
             case 2: sum<2>(reinterpret_cast<double(&)[2]>(h4)); break;
             case 3: sum<3>(reinterpret_cast<double(&)[3]>(h4)); break;
             default: sum<4>(h4); break;
           }
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (k0 + q <= jj) hc[k0 + q] = h4[q];
+          for (int q = 0; q < nk; q++) hc[k0 + q] = h4[q];
         }
         for (int k = 0; k <= jj; k++) {
           const double h = hc[k];
@@ -1946,7 +1980,8 @@ struct Team {
 #pragma unroll
         for (int j = 0; j < EPT; j++) nn[0] += ok(j) ? w[j].x * w[j].x + w[j].y * w[j].y : 0.0;
         sum<1>(nn);
-        const double hn = sqrt(nn[0]);
+        const double hn2 = nn[0];
+        const double hn = sqrt(fmax(hn2, 0.0));
         hc[jj + 1] = hn;
         const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
 #pragma unroll
@@ -1981,6 +2016,8 @@ struct Team {
         for (int cc = rw + 1; cc < jj; cc++) sacc -= R[rw * GMRES_MR_G + cc] * yk[cc];
         yk[rw] = sacc / R[rw * GMRES_MR_G + rw];
       }
+#pragma unroll
+      for (int j = 0; j < EPT; j++) yy[j] = make_double2(0.0, 0.0);
       for (int cc = 0; cc < jj; cc++) {
         const double f = yk[cc];
 #pragma unroll
@@ -1990,8 +2027,33 @@ struct Team {
           yy[j].y += f * vk.y;
         }
       }
+      // this cycle's correction y = P u
+      if (poly > 1) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) w[j] = yy[j];
+        for (int i = 1; i < poly; i++) {
+          publish(w);
+          amul(w);
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            yy[j].x += w[j].x;
+            yy[j].y += w[j].y;
+          }
+        }
+      }
       if (conv || its >= A.maxiter) break;
-      // restart: r = b - (I - alpha M) y
+      // restart: park the accumulated solution, r = b - (I - alpha M) y_total
+      double2* Yt = Vg + (size_t)(GMRES_MR_G + 1) * dim;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        if (have_total) {
+          const double2 o = Yt[at_use<EPE>(st.it[j])];
+          yy[j].x += o.x;
+          yy[j].y += o.y;
+        }
+        if (ok(j)) Yt[at_use<EPE>(st.it[j])] = yy[j];
+      }
+      have_total = true;
       publish(yy);
       double2 t3[EPT];
       if (ST::NEEDS_SLOTS && !A.S.hasJ) apply_sweep<TRANS, false>(A.S, c, yy, t3);
@@ -2002,7 +2064,14 @@ struct Team {
       team_sync<V::ONEWAVE>();  // every thread has read the scalars of this cycle before the next one overwrites them
     }
 #pragma unroll
-    for (int j = 0; j < EPT; j++) y[j] = yy[j];
+    for (int j = 0; j < EPT; j++) {
+      y[j] = yy[j];
+      if (have_total) {
+        const double2 o = Vg[(size_t)(GMRES_MR_G + 1) * dim + at_use<EPE>(st.it[j])];
+        y[j].x += o.x;
+        y[j].y += o.y;
+      }
+    }
     return napp;
   }
 

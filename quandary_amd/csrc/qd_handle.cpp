@@ -1,6 +1,8 @@
 // Operator / stepper level of the C ABI (include/quandary_amd.h): qd_create ... qd_adjoint.
 // Host code only orchestrates: every state-sized operation runs in the HIP kernels of
 // qd_kernels.hip.  There is no CPU fallback: without a HIP device qd_create fails.
+#include <algorithm>
+
 #include "qd_handle.h"
 
 #include <cmath>
@@ -478,7 +480,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
     Sone.gtab = h->d_gone.p;
   }
   if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
-  else if (cfg.var != 16 && lean64_available(h->S) && h->sol.linsolve == QD_LINSOLVE_NEUMANN) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
+  else if (cfg.var != 16 && lean64_available(h->S)) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
   else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
@@ -543,6 +545,9 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.maxiter = h->sol.maxiter;
   a.abstol = h->sol.abstol;
   a.reltol = h->sol.reltol;
+  // global-memory GMRES of the several-elements-per-thread kernels: Neumann-polynomial right preconditioner of degree 4
+  // (QD_GMRES_POLY=1: plain KSPGMRES + PCNONE iteration for iteration; see Team::gmres_g)
+  a.gmres_poly = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : 4;
   // penalties that need target data are only active when a target has been set
   a.gamma_penalty = h->pen.gamma_penalty;
   a.penalty_param = tg ? h->pen.penalty_param : 0.0;
@@ -599,7 +604,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if ((r = check_cfg(cfg))) return r;
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
-  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
+  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
@@ -713,7 +718,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
-  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
+  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, stream));
   else QD_HIP(launch_adjoint(a, cfg, stream));

@@ -69,6 +69,7 @@ struct SweepArgs {
   int cs, nsub, nstages, ntime, nb;
   double dt, Tfinal;
   int stepper_ee, linsolve, maxiter;
+  int gmres_poly;  // degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (1 = none)
   int use_gmres;  // 0: Neumann; 1: in-kernel GMRES, Krylov basis in LDS (one element per thread, small dim); 2: basis in global memory (kry)
   double abstol, reltol;
   // penalties (src/timestepper.cpp:256-480)

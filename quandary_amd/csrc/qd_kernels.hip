@@ -406,7 +406,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
 
 size_t big_work_doubles(const DevSys& S, int nb) { return (size_t)nb * BIG_NV * 2 * (size_t)S.dim; }
 
-size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G + 1) * 2 * (size_t)S.dim; }
+size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G + 2) * 2 * (size_t)S.dim; }
 
 // ---------------------------------------------------------------------------------------------
 // dispatch to the per-(Q, Lindblad, qubit) translation units (qd_inst.hip)

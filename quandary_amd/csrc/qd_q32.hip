@@ -177,8 +177,8 @@ struct Q32 {
   }
 };
 
-// per-workgroup state of the sweeps: LDS exchange buffers, reduction scratch, the Neumann solver
-template <int Q, int SB, typename R>
+// per-workgroup state of the sweeps: LDS exchange buffers, reduction scratch, the Neumann solver (GM: + in-kernel GMRES)
+template <int Q, int SB, typename R, bool GM = false>
 struct Team32 {
   typedef Q32<Q, SB, R> ST;
   typedef typename ST::f2 f2;
@@ -189,6 +189,7 @@ struct Team32 {
   f2* buf;       // two exchange vectors of DIM elements
   double* red;   // two reduction slots of NRED * NW doubles
   double2* acc;  // the fp64 state accumulators, parked here while a linear solve runs (EPT > 1; only ever touched by the owning thread)
+  double* ksc;   // GMRES: wave-uniform scalars of the Hessenberg problem
   int cur, redslot;
   static constexpr bool PARK = EPT > 1;
 
@@ -196,11 +197,14 @@ struct Team32 {
     buf = reinterpret_cast<f2*>(smem);
     red = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM);
     acc = reinterpret_cast<double2*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW);
+    ksc = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0));
     cur = 0;
     redslot = 0;
     st.init(S);
   }
-  static size_t lds_bytes() { return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0); }
+  static size_t lds_bytes() {
+    return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0) + (GM ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
+  }
   __device__ __forceinline__ int elem(int j) const { return (int)(threadIdx.x | ((unsigned)j << ST::TB)); }
   __device__ __forceinline__ const f2* vec() const { return buf + cur * DIM; }
   __device__ __forceinline__ void park(const double2 (&v)[EPT]) const {
@@ -313,6 +317,156 @@ struct Team32 {
     }
     return iter;
   }
+
+  // GMRES for (I - alpha M^{(T)}) y = b, as Team::gmres_g of qd_device.h (KSPGMRES + PCNONE of the reference: zero initial
+  // guess, classical Gram-Schmidt, Givens rotations, restart 30, stop at max(rtol ||b||, abstol)); the Krylov basis lives in
+  // global memory (L2 / Infinity-Cache resident for the 2^5 system: ~5 vectors x 16 KB per initial condition), every thread
+  // only touches its own elements of it.  All projections of an iteration go through one block reduction.  Returns the
+  // number of RHS applications; y in registers.
+  template <bool TRANS>
+  __device__ __forceinline__ int gmres(const SweepArgs& A, R alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
+    constexpr int MR = GMRES_MR_G;
+    f2* __restrict__ Vg = reinterpret_cast<f2*>(A.kry) + (size_t)blockIdx.x * (MR + 2) * DIM;
+    double* hc = ksc;
+    double* cs = hc + (MR + 2);
+    double* sn = cs + MR;
+    double* g = sn + MR;
+    double* Rm = g + (MR + 2);
+    double* yk = Rm + MR * MR;
+    f2 yy[EPT], r[EPT], v[EPT], w[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      yy[j].x = yy[j].y = 0;
+      r[j] = b[j];
+    }
+    int its = 0, napp = 0;
+    double ttol = 0.0;
+    for (int cycle = 0;; cycle++) {
+      double t1[1] = {0.0};
+#pragma unroll
+      for (int j = 0; j < EPT; j++) t1[0] += (double)r[j].x * r[j].x + (double)r[j].y * r[j].y;
+      sum<1>(t1);
+      const double beta = sqrt(t1[0]);
+      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+      if (beta <= ttol || its >= A.maxiter) break;
+      const R ibeta = (R)(1.0 / beta);
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        v[j].x = r[j].x * ibeta;
+        v[j].y = r[j].y * ibeta;
+        Vg[opaque(elem(j))] = v[j];
+      }
+      publish(v);
+      double gcur = beta;
+      int jj = 0;
+      bool conv = false;
+      while (jj < MR) {
+        f2 t2[EPT];
+        apply_all<TRANS>(v, t2);
+        napp++;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          w[j].x = v[j].x - alpha * t2[j].x;
+          w[j].y = v[j].y - alpha * t2[j].y;
+        }
+        // projections, up to 8 per block reduction (the norm of the orthogonalised vector is reduced separately: the identity
+        // ||w - sum h_k v_k||^2 = ||w||^2 - sum h_k^2 breaks down with the orthogonality of classical Gram-Schmidt)
+        for (int k0 = 0; k0 <= jj; k0 += 8) {
+          double h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          const int nk = min(8, jj + 1 - k0);
+          for (int q = 0; q < nk; q++) {
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+              const f2 vk = Vg[(size_t)(k0 + q) * DIM + opaque(elem(j))];
+              h8[q] += (double)w[j].x * vk.x + (double)w[j].y * vk.y;
+            }
+          }
+          if (nk <= 2) sum<2>(reinterpret_cast<double(&)[2]>(h8));
+          else if (nk <= 4) sum<4>(reinterpret_cast<double(&)[4]>(h8));
+          else sum<8>(h8);
+          for (int q = 0; q < nk; q++) hc[k0 + q] = h8[q];
+        }
+        for (int k = 0; k <= jj; k++) {
+          const R h = (R)hc[k];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            const f2 vk = Vg[(size_t)k * DIM + opaque(elem(j))];
+            w[j].x -= h * vk.x;
+            w[j].y -= h * vk.y;
+          }
+        }
+        double nn[1] = {0.0};
+#pragma unroll
+        for (int j = 0; j < EPT; j++) nn[0] += (double)w[j].x * w[j].x + (double)w[j].y * w[j].y;
+        sum<1>(nn);
+        const double hn2 = nn[0];
+        const double hn = sqrt(fmax(hn2, 0.0));
+        hc[jj + 1] = hn;
+        const R ihn = (R)(hn > 0.0 ? 1.0 / hn : 0.0);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          v[j].x = w[j].x * ihn;
+          v[j].y = w[j].y * ihn;
+          Vg[(size_t)(jj + 1) * DIM + opaque(elem(j))] = v[j];
+        }
+        // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
+        double cur_h = hc[0];
+        for (int k = 0; k < jj; k++) {
+          const double a1 = hc[k + 1], ck = cs[k], sk = sn[k];
+          Rm[k * MR + jj] = ck * cur_h + sk * a1;
+          cur_h = -sk * cur_h + ck * a1;
+        }
+        const double a0 = cur_h, bb = hn;
+        const double rr = sqrt(a0 * a0 + bb * bb);
+        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
+        const double cj = rr == 0.0 ? 1.0 : a0 * irr, sj = bb * irr;
+        cs[jj] = cj;
+        sn[jj] = sj;
+        Rm[jj * MR + jj] = rr;
+        g[jj] = cj * gcur;
+        gcur = -sj * gcur;
+        its++;
+        jj++;
+        publish(v);  // v_{jj} becomes the stencil-readable vector; its barrier also orders the scalar writes
+        if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
+        if (its >= A.maxiter) break;
+      }
+      for (int rw = jj - 1; rw >= 0; rw--) {
+        double sacc = g[rw];
+        for (int cc = rw + 1; cc < jj; cc++) sacc -= Rm[rw * MR + cc] * yk[cc];
+        yk[rw] = sacc / Rm[rw * MR + rw];
+      }
+      for (int cc = 0; cc < jj; cc++) {
+        const R f = (R)yk[cc];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const f2 vk = Vg[(size_t)cc * DIM + opaque(elem(j))];
+          yy[j].x += f * vk.x;
+          yy[j].y += f * vk.y;
+        }
+      }
+      if (conv || its >= A.maxiter) break;
+      publish(yy);  // restart: r = b - (I - alpha M) y
+      f2 t3[EPT];
+      apply_all<TRANS>(yy, t3);
+      napp++;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        r[j].x = b[j].x - (yy[j].x - alpha * t3[j].x);
+        r[j].y = b[j].y - (yy[j].y - alpha * t3[j].y);
+      }
+      team_sync<ONEWAVE>();  // every thread has read the scalars of this cycle before the next one overwrites them
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = yy[j];
+    return napp;
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ int solve(const SweepArgs& A, R alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
+    if constexpr (GM) return gmres<TRANS>(A, alpha, b, y);
+    else return neumann<TRANS>(A, alpha, b, y);
+  }
 };
 
 template <typename R> __device__ __forceinline__ typename Vec2<R>::type to_r2(const double2 v);
@@ -339,10 +493,10 @@ template <> struct Traj<double> {
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int SB, typename R>
+template <int Q, int SB, typename R, bool GM = false>
 __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_forward_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB, R> TM;
+  typedef Team32<Q, SB, R, GM> TM;
   typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
@@ -376,7 +530,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
     tm.park(x);  // the fp64 accumulators are dead weight during the solve
     f2 rhs[EPT], k[EPT];
     tm.template apply_all<false>(xs, rhs);  // rhs = M x (ImplMidpoint::evolveFWD, timestepper.cpp:594)
-    napply += 1 + tm.template neumann<false>(A, (R)0.5 * hf, rhs, k);
+    napply += 1 + tm.template solve<false>(A, (R)0.5 * hf, rhs, k);
     tm.unpark(x);
     const double h = to_scalar(c.h);
 #pragma unroll
@@ -423,10 +577,10 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int SB, typename R>
+template <int Q, int SB, typename R, bool GM = false>
 __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_adjoint_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB, R> TM;
+  typedef Team32<Q, SB, R, GM> TM;
   typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
@@ -471,7 +625,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
     {
       f2 rhs[EPT];
       tm.template apply_all<false>(x, rhs);
-      tm.template neumann<false>(A, (R)0.5 * hf, rhs, z);
+      tm.template solve<false>(A, (R)0.5 * hf, rhs, z);
     }
     if (TM::PARK) {  // x is cheaper to re-read (L2) than to keep across the solve
 #pragma unroll
@@ -491,7 +645,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
 #pragma unroll
       for (int j = 0; j < EPT; j++) bb[j] = to_r2<R>(xb[j]);
     }
-    tm.template neumann<true>(A, (R)0.5 * hf, bb, kb);
+    tm.template solve<true>(A, (R)0.5 * hf, bb, kb);
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       kb[j].x *= hf;
@@ -711,21 +865,21 @@ static int q32_slot_bits(int Q) {
   return 0;
 }
 
-template <int Q, int SB, typename R>
+template <int Q, int SB, typename R, bool GM = false>
 static hipError_t go_fwd(const SweepArgs& a, hipStream_t st) {
   constexpr int nt = Q32<Q, SB, R>::NT;
-  const size_t lds = Team32<Q, SB, R>::lds_bytes();
-  auto kf = k_forward_q32<Q, SB, R>;
+  const size_t lds = Team32<Q, SB, R, GM>::lds_bytes();
+  auto kf = k_forward_q32<Q, SB, R, GM>;
   hipError_t e = set_lds32(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(a.nb), dim3(nt), lds, st, a);
   return hipGetLastError();
 }
-template <int Q, int SB, typename R>
+template <int Q, int SB, typename R, bool GM = false>
 static hipError_t go_adj(const SweepArgs& a, hipStream_t st) {
   constexpr int nt = Q32<Q, SB, R>::NT;
-  const size_t lds = Team32<Q, SB, R>::lds_bytes();
-  auto kf = k_adjoint_q32<Q, SB, R>;
+  const size_t lds = Team32<Q, SB, R, GM>::lds_bytes();
+  auto kf = k_adjoint_q32<Q, SB, R, GM>;
   hipError_t e = set_lds32(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(a.nb), dim3(nt), lds, st, a);
@@ -774,8 +928,8 @@ bool lean64_available(const DevSys& S) {
     if (S.n[k] != 2 || S.ness[k] != 2) return false;
   return !getenv("QD_NO_LEAN64");
 }
-hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st) { return go_fwd<5, 2, double>(a, st); }
-hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st) { return go_adj<5, 2, double>(a, st); }
+hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st) { return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st); }
+hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st) { return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st); }
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
   return go_app<5, 2, double>(S, ctlrow, transpose, x, y, nb, 1, st);
 }

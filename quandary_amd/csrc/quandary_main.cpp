@@ -752,6 +752,11 @@ int main(int argc, char** argv) {
     device = getenv("QD_DEVICE") ? atoi(getenv("QD_DEVICE")) : ev.rank % ndev;
   }
   QDCHK(qd_create(&P.sys, &P.ctl, &P.tg, &P.sol, device, &h));
+  {  // extension of this build: precision = f64 (default, like the reference) | f32mixed
+    const std::string prec = P.cfg.str("precision", "f64");
+    if (prec == "f32mixed") QDCHK(qd_set_precision(h, QD_PRECISION_F32MIXED));
+    else if (prec != "f64") die("precision must be f64 or f32mixed");
+  }
   if (qd_ndesign(h) != (int)P.params0.size()) die("internal: parameter count mismatch");
   {  // user-supplied Hamiltonians (src/main.cpp:309-316, src/hamiltonianfilereader.cpp)
     const std::string fsys = P.cfg.str("hamiltonian_file_Hsys", "none"), fc = P.cfg.str("hamiltonian_file_Hc", "none");

@@ -131,11 +131,38 @@ def test_gmres_solver_vs_oracle_gmres(kw):
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
     assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
-    # same Krylov method, same stopping rule: the mean number of RHS applications agrees closely
     orc.reset_stats()
     orc.evalF(sp.params0)
     opt.evalF(sp.params0)
+    # same Krylov method, same stopping rule: the mean number of RHS applications agrees closely (dt = 0.05 is far outside
+    # the contraction region of the Neumann series, so the global-memory GMRES runs without its polynomial preconditioner)
     assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("poly", ["1", "4"])
+def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
+    """The 3x20 system with the reference's AxC constants and time step (dt = 1e-4: the Neumann series contracts): the
+    global-memory GMRES of the column kernel right-preconditioned with the Neumann polynomial of degree 4 (default) and
+    plain (QD_GMRES_POLY=1 = KSPGMRES + PCNONE iteration for iteration: application counts of the oracle's GMRES).  Same
+    stopping rule on the same true residual, so objective and gradient agree with the oracle either way."""
+    from quandary_amd.workloads import workload_spec
+    monkeypatch.setenv("QD_GMRES_POLY", poly)
+    sp = workload_spec("c4", "gradient", {"ntime": 20, "linearsolver_type": "gmres", "initialcondition": "basis, 0"})
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    orc.reset_stats()
+    orc.evalF(sp.params0)
+    opt.evalF(sp.params0)
+    if poly == "1":
+        assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    else:
+        assert orc.mean_applies < h.mean_applies < 2.0 * orc.mean_applies  # 1 + 3 x 4 + 3 applications against ~10
     opt.close(); h.close(); orc.close()
 
 
