@@ -1871,8 +1871,9 @@ struct Team {
   // b - (I - alpha M) y, so the stopping rule max(rtol ||b||, abstol) of the reference is unchanged; what changes is the
   // path: p applications per Krylov vector, but only ~ (iterations of plain GMRES) / p Krylov vectors.  With the basis in
   // HBM the cost of plain GMRES is its m^2 + 3m passes over 2 dim doubles per step (3x20 Lindblad: m = 11, 9.7 MB per
-  // step and initial condition); p = 4 needs m = 3.  The polynomial is only used where the Neumann series contracts
-  // (||alpha M v_0|| <= 1/2, decided per solve); otherwise, and with p = 1, this is KSPGMRES + PCNONE iteration for iteration.
+  // step and initial condition); p = 4 needs m = 3.  The host only asks for p > 1 where the Neumann series provably
+  // contracts (a Gershgorin bound of ||alpha M||_inf <= 0.7 from the system constants and the current control
+  // parameters, qd_handle::gmres_poly_degree); otherwise, and with p = 1, this is KSPGMRES + PCNONE iteration for iteration.
   template <bool TRANS>
   __device__ __forceinline__ int gmres_g(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
     static_assert(ICPB == 1, "one initial condition per workgroup");
@@ -1883,7 +1884,7 @@ struct Team {
     double* g = sn + GMRES_MR_G;
     double* R = g + (GMRES_MR_G + 2);
     double* yk = R + GMRES_MR_G * GMRES_MR_G;
-    int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;  // may fall back to 1 for this solve, see below
+    const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
     double2 yy[EPT], r[EPT], v[EPT], w[EPT];
     int napp = 0;
     // z <- (alpha M) z, reading z from the published vector
@@ -1932,15 +1933,6 @@ struct Team {
         for (int i = 0; i < poly; i++) {
           if (i > 0) publish(w);
           amul(w);
-          if (i == 0 && poly > 1 && its == 0) {
-            // The Neumann polynomial only helps where the series contracts.  ||alpha M v_0|| > 1/2 (large time steps, the
-            // case GMRES exists for): plain GMRES for this solve (uniform decision, one extra reduction per solve).
-            double q2[1] = {0.0};
-#pragma unroll
-            for (int j = 0; j < EPT; j++) q2[0] += ok(j) ? w[j].x * w[j].x + w[j].y * w[j].y : 0.0;
-            sum<1>(q2);
-            if (q2[0] > 0.25) poly = 1;
-          }
         }
 #pragma unroll
         for (int j = 0; j < EPT; j++) w[j] = make_double2(v[j].x - w[j].x, v[j].y - w[j].y);

@@ -480,6 +480,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
     Sone.gtab = h->d_gone.p;
   }
   if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
+  else if (cfg.var != 16 && col_lean_available(h->S) && h->sol.linsolve == QD_LINSOLVE_NEUMANN) QD_HIP(launch_apply_col(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
   else if (cfg.var != 16 && lean64_available(h->S)) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
   else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
@@ -528,6 +529,62 @@ int qd_handle::traj_doubles(int nb, size_t* n) const {
   return QD_OK;
 }
 
+// Degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (Team::gmres_g): 4 where the series
+// provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
+// sub-step, from the system constants and the CURRENT control parameters (|p_k(t)|, |q_k(t)| <= sum over carriers of
+// max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
+// by their amplitude).  QD_GMRES_POLY overrides the degree (1 = never precondition).
+int qd_handle::gmres_poly_degree() const {
+  const int want = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : 4;
+  if (want <= 1 || S.dense) return 1;
+  // diagonal: |Delta| <= hmax (Schroedinger) or 2 hmax (Lindblad), hmax = max_I |h(I)|; |d| and the T1 off-diagonal row entry
+  double hmax = 0.0;
+  {
+    std::vector<int> dg(S.Q, 0);
+    for (long long I = 0; I < S.N; I++) {
+      long long r = I;
+      for (int k = 0; k < S.Q; k++) { dg[k] = (int)(r / S.post[k]); r %= S.post[k]; }
+      double hd = 0.0;
+      int pair = 0;
+      for (int k = 0; k < S.Q; k++) {
+        hd += S.detune[k] * dg[k] - S.xi[k] / 2.0 * dg[k] * (dg[k] - 1);
+        for (int l = k + 1; l < S.Q; l++) hd -= S.xikl[pair++] * dg[k] * dg[l];
+      }
+      hmax = std::max(hmax, fabs(hd));
+    }
+  }
+  double row = S.lindblad ? 2.0 * hmax : hmax;
+  for (int k = 0; k < S.Q; k++) {
+    const double nm = S.n[k] - 1.0;
+    if (S.lindblad) row += fabs(S.g2[k]) * nm * nm / 2.0 + fabs(S.g1[k]) * nm + fabs(S.g1off[k]) * nm;
+    // controls: each of the (2 or 4) ladder neighbours carries |q| + |p| times sqrt(level)
+    double amp = 0.0;
+    const DevOsc& o = oscs[k];
+    for (int b = 0; b < o.nseg; b++) {
+      const DevSeg& g = segs[o.seg_begin + b];
+      double a = 0.0;
+      for (int f = 0; f < o.ncar; f++) {
+        double m1 = 0.0, m2 = 0.0;
+        for (int l = 0; l < g.nsplines; l++) {
+          m1 = std::max(m1, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + l]));
+          m2 = std::max(m2, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + g.nsplines + l]));
+        }
+        a += m1 + m2;
+      }
+      amp = std::max(amp, a);
+    }
+    for (int i = 0; i < o.npulse; i++) amp = std::max(amp, fabs(pulses[(size_t)(o.pulse_begin + i) * 3 + 2]));
+    row += 2.0 * amp * (S.lindblad ? 2.0 : 1.0) * (sqrt(nm) + sqrt(std::max(nm - 1.0, 0.0)));
+  }
+  int pair = 0;
+  for (int k = 0; k < S.Q; k++)
+    for (int l = k + 1; l < S.Q; l++, pair++)
+      row += fabs(S.J[pair]) * (S.lindblad ? 4.0 : 2.0) * sqrt((S.n[k] - 1.0) * (S.n[l] - 1.0)) * 2.0;
+  double amax = 0.0;
+  for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
+  return amax * row <= 0.7 ? want : 1;
+}
+
 static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget* tg) {
   std::memset(&a, 0, sizeof a);
   a.S = h->S;
@@ -545,9 +602,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.maxiter = h->sol.maxiter;
   a.abstol = h->sol.abstol;
   a.reltol = h->sol.reltol;
-  // global-memory GMRES of the several-elements-per-thread kernels: Neumann-polynomial right preconditioner of degree 4
-  // (QD_GMRES_POLY=1: plain KSPGMRES + PCNONE iteration for iteration; see Team::gmres_g)
-  a.gmres_poly = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : 4;
+  a.gmres_poly = h->gmres_poly_degree();
   // penalties that need target data are only active when a target has been set
   a.gamma_penalty = h->pen.gamma_penalty;
   a.penalty_param = tg ? h->pen.penalty_param : 0.0;
@@ -605,8 +660,10 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
   const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
+  const bool collean = cfg.var != 16 && col_lean_available(S) && sol.linsolve == QD_LINSOLVE_NEUMANN && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
+  else if (collean) QD_HIP(launch_forward_col(a, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));

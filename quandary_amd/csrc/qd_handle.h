@@ -114,6 +114,7 @@ struct qd_handle {
 
   // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
   int refresh_tables();
+  int gmres_poly_degree() const;  // 4 where the Neumann series provably contracts for the current parameters, else 1
   int traj_doubles(int nb, size_t* n) const;
   // forward sweep on device-resident states; results stay on the device (d_pen, d_dpdm, d_xT, d_out4)
   int forward_dev(const double* dx0, int nb, bool store, const qd::DevTarget* tg, double* energy);
