@@ -47,7 +47,7 @@
  *
  * Supported sizes (QD_ERR_UNSUPPORTED beyond): state dimension dim <= QD_MAX_DIM = 2^22 (one
  * workgroup owns one initial condition; up to 4096 the state lives in the CU's LDS, above it the
- * vectors of a step live in global memory and are exchanged through L2 - Neumann solver, IMR family);
+ * vectors of a step live in global memory and are exchanged through L2; IMR family);
  * Lindblad 1..5 oscillators (like the
  * reference's matrix-free templates), Schroedinger 1..8; at most 256 / 64 / 32 / 16
  * levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied

@@ -59,7 +59,9 @@ struct BigTeam {
   const double2* coef;
   const uint2* dig;
 
-  static size_t lds_bytes(const DevSys& S) { return sizeof(double) * 2 * (size_t)table_len(S) + sizeof(double) * 2 * NRED * (BIG_BLOCK / 64); }
+  static size_t lds_bytes(const DevSys& S) {
+    return sizeof(double) * 2 * (size_t)table_len(S) + sizeof(double) * 2 * NRED * (BIG_BLOCK / 64) + sizeof(double) * gmres_nsc(GMRES_MR_G);
+  }
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
     dim = S.dim;
@@ -72,7 +74,8 @@ struct BigTeam {
     L.tup = reinterpret_cast<double*>(smem);
     L.tdn = L.tup + tl;
     L.red = L.tdn + tl;
-    L.bvec = nullptr; L.gmat = nullptr; L.coltab = nullptr; L.kry = nullptr; L.ksc = nullptr;
+    L.bvec = nullptr; L.gmat = nullptr; L.coltab = nullptr; L.kry = nullptr;
+    L.ksc = L.red + 2 * NRED * (BIG_BLOCK / 64);
     int o = 0;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
@@ -148,6 +151,144 @@ struct BigTeam {
     *iters = iter;
     return cur;
   }
+
+  // GMRES (KSPGMRES + PCNONE of the reference, as Team::gmres_g with p = 1): zero initial guess, classical Gram-Schmidt,
+  // Givens rotations, restart 30, stop at max(rtol ||b||, abstol).  Every vector lives in global memory; a thread only ever
+  // touches its own elements (e = tid + n blockDim) except in the operator application, which is fenced by a barrier.
+  // Krylov basis: A.kry, [nb][GMRES_MR_G + 2][dim]; Wv: scratch vector; the solution is written to Ysol.
+  template <bool TRANS>
+  __device__ __forceinline__ double2* gmres(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ysol,
+                                            double2* Wv, int* iters) {
+    constexpr int MR = GMRES_MR_G;
+    const int nt = blockDim.x, tid = threadIdx.x;
+    double2* Vg = reinterpret_cast<double2*>(A.kry) + (size_t)blockIdx.x * (MR + 2) * dim;
+    double* hc = L.ksc;
+    double* cs = hc + (MR + 2);
+    double* sn = cs + MR;
+    double* g = sn + MR;
+    double* Rm = g + (MR + 2);
+    double* yk = Rm + MR * MR;
+    for (int e = tid; e < dim; e += nt) Ysol[e] = make_double2(0.0, 0.0);
+    int its = 0, napp = 0;
+    double ttol = 0.0;
+    for (int cycle = 0;; cycle++) {
+      // residual: b on the first cycle, b - (I - alpha M) y afterwards (left in Wv by the restart code below)
+      const double2* r = cycle == 0 ? Bv : Wv;
+      double t1[1] = {0.0};
+      for (int e = tid; e < dim; e += nt) {
+        const double2 v = r[e];
+        t1[0] += v.x * v.x + v.y * v.y;
+      }
+      sum<1>(t1);
+      const double beta = sqrt(t1[0]);
+      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+      if (beta <= ttol || its >= A.maxiter) break;
+      const double ibeta = 1.0 / beta;
+      for (int e = tid; e < dim; e += nt) {
+        const double2 v = r[e];
+        Vg[e] = make_double2(v.x * ibeta, v.y * ibeta);
+      }
+      __syncthreads();
+      double gcur = beta;
+      int jj = 0;
+      bool conv = false;
+      while (jj < MR) {
+        const double2* vj = Vg + (size_t)jj * dim;
+        for (int e = tid; e < dim; e += nt) {
+          const double2 t = apply<TRANS>(A.S, c, vj, e);
+          const double2 v = vj[e];
+          Wv[e] = make_double2(v.x - alpha * t.x, v.y - alpha * t.y);
+        }
+        napp++;
+        for (int k0 = 0; k0 <= jj; k0 += 4) {  // classical Gram-Schmidt, four projections per pass and reduction
+          double h4[4] = {0.0, 0.0, 0.0, 0.0};
+          const int nk = min(4, jj + 1 - k0);
+          for (int e = tid; e < dim; e += nt) {
+            const double2 w = Wv[e];
+            for (int q = 0; q < nk; q++) {
+              const double2 vk = Vg[(size_t)(k0 + q) * dim + e];
+              h4[q] += w.x * vk.x + w.y * vk.y;
+            }
+          }
+          sum<4>(h4);
+          for (int q = 0; q < nk; q++) hc[k0 + q] = h4[q];
+        }
+        double nn[1] = {0.0};
+        for (int e = tid; e < dim; e += nt) {
+          double2 w = Wv[e];
+          for (int k = 0; k <= jj; k++) {
+            const double h = hc[k];
+            const double2 vk = Vg[(size_t)k * dim + e];
+            w.x -= h * vk.x;
+            w.y -= h * vk.y;
+          }
+          Wv[e] = w;
+          nn[0] += w.x * w.x + w.y * w.y;
+        }
+        sum<1>(nn);
+        const double hn = sqrt(nn[0]);
+        hc[jj + 1] = hn;
+        const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
+        for (int e = tid; e < dim; e += nt) {
+          const double2 w = Wv[e];
+          Vg[(size_t)(jj + 1) * dim + e] = make_double2(w.x * ihn, w.y * ihn);
+        }
+        double cur_h = hc[0];  // Givens rotations: redundantly by every thread on uniform values, idempotent LDS writes only
+        for (int k = 0; k < jj; k++) {
+          const double a1 = hc[k + 1], ck = cs[k], sk = sn[k];
+          Rm[k * MR + jj] = ck * cur_h + sk * a1;
+          cur_h = -sk * cur_h + ck * a1;
+        }
+        const double a0 = cur_h, bb = hn;
+        const double rr = sqrt(a0 * a0 + bb * bb);
+        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
+        const double cj = rr == 0.0 ? 1.0 : a0 * irr, sj = bb * irr;
+        cs[jj] = cj;
+        sn[jj] = sj;
+        Rm[jj * MR + jj] = rr;
+        g[jj] = cj * gcur;
+        gcur = -sj * gcur;
+        its++;
+        jj++;
+        __syncthreads();  // v_{jj} complete (next application reads neighbours), scalars ordered
+        if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
+        if (its >= A.maxiter) break;
+      }
+      for (int rw = jj - 1; rw >= 0; rw--) {
+        double sacc = g[rw];
+        for (int cc = rw + 1; cc < jj; cc++) sacc -= Rm[rw * MR + cc] * yk[cc];
+        yk[rw] = sacc / Rm[rw * MR + rw];
+      }
+      for (int e = tid; e < dim; e += nt) {
+        double2 y = Ysol[e];
+        for (int cc = 0; cc < jj; cc++) {
+          const double f = yk[cc];
+          const double2 vk = Vg[(size_t)cc * dim + e];
+          y.x += f * vk.x;
+          y.y += f * vk.y;
+        }
+        Ysol[e] = y;
+      }
+      __syncthreads();
+      if (conv || its >= A.maxiter) break;
+      for (int e = tid; e < dim; e += nt) {  // restart: r = b - (I - alpha M) y
+        const double2 t = apply<TRANS>(A.S, c, Ysol, e);
+        const double2 y = Ysol[e], b = Bv[e];
+        Wv[e] = make_double2(b.x - (y.x - alpha * t.x), b.y - (y.y - alpha * t.y));
+      }
+      napp++;
+      __syncthreads();
+    }
+    *iters = napp;
+    return Ysol;
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ double2* solve(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
+                                            double2* Yb, int* iters) {
+    if (A.use_gmres) return gmres<TRANS>(A, c, alpha, Bv, Ya, Yb, iters);
+    return neumann<TRANS>(A, c, alpha, Bv, Ya, Yb, iters);
+  }
 };
 
 template <int Q, bool LIND>
@@ -203,7 +344,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       }
     } else {
       int its;
-      const double2* K = tm.template neumann<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
+      const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
       napply += its;
       for (int e = tid; e < dim; e += nt) {
         const double2 k = K[e];
@@ -372,7 +513,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     __syncthreads();
     int its;
     {
-      const double2* K = tm.template neumann<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
+      const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
       for (int e = tid; e < dim; e += nt) {
         const double2 k = K[e], x = X[e];
         Z[e] = make_double2(fma(0.5 * c.h, k.x, x.x), fma(0.5 * c.h, k.y, x.y));
@@ -380,7 +521,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     }
     __syncthreads();
     {
-      const double2* K = tm.template neumann<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
+      const double2* K = tm.template solve<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
       for (int e = tid; e < dim; e += nt) {
         const double2 k = K[e];
         KB[e] = make_double2(c.h * k.x, c.h * k.y);

@@ -555,10 +555,11 @@ BIG_SHAPES = [
 
 
 @pytest.mark.parametrize("kw", BIG_SHAPES)
-def test_states_beyond_lds_vs_oracle(kw):
+@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
+def test_states_beyond_lds_vs_oracle(kw, linsolve):
     """dim > 4096 (was QD_ERR_UNSUPPORTED in round 1): the work vectors of a step live in global memory (qd_big.h).
-    Operator, transpose, objective parts and gradient against the oracle, all penalties on."""
-    sp, h, orc = _pair(kw, ntime=4, nspline=5, penalties=True)
+    Operator, transpose, objective parts and gradient against the oracle, all penalties on, both linear solvers."""
+    sp, h, orc = _pair(kw, ntime=4, nspline=5, penalties=True, linsolve=linsolve)
     assert h.dim > 4096
     rng = np.random.default_rng(21)
     h.set_params(sp.params0)
@@ -578,18 +579,23 @@ def test_states_beyond_lds_vs_oracle(kw):
 
 
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7], SHAPES[8], COL_SHAPES[3]])
-@pytest.mark.parametrize("stepper", ["IMR", "IMR4"])
-def test_global_memory_variant_forced_onto_small_systems(kw, stepper, monkeypatch):
+@pytest.mark.parametrize("stepper,linsolve", [("IMR", "neumann"), ("IMR4", "neumann"), ("IMR", "gmres")])
+def test_global_memory_variant_forced_onto_small_systems(kw, stepper, linsolve, monkeypatch):
     """The same kernels (QD_VAR=16) on the small shapes of the LDS kernels: guard levels, dipole-dipole coupling, gates,
     every penalty (leakage, weighted-J incl. the Schroedinger Jtrace reduction, dpdm), several initial conditions."""
     monkeypatch.setenv("QD_VAR", "16")
-    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper)
+    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     oval, og = orc.evalGradF(sp.params0)
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
     assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    if linsolve == "gmres":  # KSPGMRES + PCNONE iteration for iteration
+        orc.reset_stats()
+        orc.evalF(sp.params0)
+        opt.evalF(sp.params0)
+        assert abs(h.mean_applies - orc.mean_applies) < 0.25
     opt.close(); h.close(); orc.close()
 
 
@@ -597,12 +603,6 @@ def test_unsupported_sizes_fail_loudly():
     sp = synthetic_spec([40, 60], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0")  # dim 5.76e6 > 2^22
     with pytest.raises(capi.QuandaryAmdError, match="QD_MAX_DIM"):
         capi.Handle(sp)
-    sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0", linsolve="gmres")
-    h = capi.Handle(sp)
-    opt = capi.Optim(h, sp)
-    with pytest.raises(capi.QuandaryAmdError, match="Neumann"):  # large states: Neumann solver only
-        opt.evalF(sp.params0)
-    opt.close(); h.close()
     sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0", stepper="EE")
     with pytest.raises(capi.QuandaryAmdError, match="explicit-Euler"):
         capi.Handle(sp)
@@ -694,3 +694,36 @@ def test_bench_two_ranks_matches_one_rank():
     assert res[2]["config"]["ninit_per_gpu"] * 2 == res[1]["config"]["ninit"]
     assert res[2]["config"]["objective"] == pytest.approx(res[1]["config"]["objective"], rel=1e-12)
     assert set(res[2]["allreduce_ms_per_step"]) == {"objective_sums", "gradient"}
+
+
+@pytest.mark.parametrize("name,ninit", [("c4", 3600), ("c5", 1024)])
+def test_full_batch_properties_at_baseline_size(name, ninit):
+    """BASELINE configs 4 and 5 at their FULL batch (3600 / 1024 basis initial conditions, ntime 20): size-independent
+    properties of every final state - trace 1 (the Lindblad generator is trace preserving: column sums of M vanish on the
+    diagonal block) and hermiticity (u symmetric, v antisymmetric under I <-> I') - and the seven partial sums of 16
+    sampled initial conditions against the oracle (each sample = one shard of qd_optim_create(rank, nranks = ninit))."""
+    from quandary_amd.workloads import workload_spec
+    sp = workload_spec(name, "simulation", {"ntime": 20})
+    assert sp.ninit == ninit
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    N, dim = h.dim_rho, h.dim
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(ninit)])
+    h.set_params(sp.params0)
+    fin = h.forward(x0)["final_states"].reshape(ninit, 2, N, N)  # [ic][re/im][col I'][row I]
+    u, v = fin[:, 0], fin[:, 1]
+    tr0 = np.trace(x0.reshape(ninit, 2, N, N)[:, 0], axis1=1, axis2=2)
+    np.testing.assert_allclose(np.trace(u, axis1=1, axis2=2), tr0, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.trace(v, axis1=1, axis2=2), 0.0, rtol=0, atol=1e-10)
+    assert np.abs(u - u.transpose(0, 2, 1)).max() < 1e-10
+    assert np.abs(v + v.transpose(0, 2, 1)).max() < 1e-10
+    opt.close()
+    orc = Oracle(sp)
+    rng = np.random.default_rng(99)
+    for r in sorted(rng.choice(ninit, 16, replace=False)):
+        shard = capi.Optim(h, sp, rank=int(r), nranks=ninit)
+        part = shard.forward_local(sp.params0)
+        shard.close()
+        po = orc.forward_local(sp.params0, int(r), ninit)
+        np.testing.assert_allclose(part, po, rtol=0, atol=1e-9 * np.maximum(1.0, np.abs(po)).max())
+    h.close(); orc.close()
