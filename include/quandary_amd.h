@@ -211,6 +211,17 @@ int qd_apply_rhs(qd_handle* h, double t, int transpose, const double* x, double*
  * (0..ntime) of every local initial condition, [nb][2*dim]. */
 int qd_get_state(qd_handle* h, int timestep, double* x);
 
+/* Observables of the stored trajectory, reduced on the device (Oscillator::expectedEnergy / population
+ * src/oscillator.cpp:430-566, MasterEq::expectedEnergy / population src/mastereq.cpp:2897-2974; what
+ * Output::writeTrajectoryDataFiles prints, src/output.cpp:203-273) for the time steps 0, stride, 2 stride, ... <= ntime
+ * (nout = ntime / stride + 1 of them) of every local initial condition.  Any output pointer may be NULL.
+ *   expected             [nout][nb][nosc]              expected energy level of oscillator k
+ *   population           [nout][nb][sum_k nlevels[k]]  level populations, oscillator k's block after those of 0..k-1
+ *   expected_composite   [nout][nb]                    sum_I I P(I)
+ *   population_composite [nout][nb][N]                 P(I) = rho_II or |psi_I|^2 */
+int qd_get_observables(qd_handle* h, int stride, double* expected, double* population, double* expected_composite,
+                       double* population_composite);
+
 int qd_set_target(qd_handle* h, const qd_target* tgt, int nb);
 int qd_set_penalty(qd_handle* h, const qd_penalty* pen);
 

@@ -175,7 +175,7 @@ EXPORTS = [
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
     "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
-    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32",
+    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables",
 ]
 COMM_ID_BYTES = 128
 PRECISION = {"f64": 0, "f32mixed": 1}
@@ -249,6 +249,7 @@ def load_library(path=None):
     lib.qd_optim_evalGradF_dist.argtypes = [vp, vp, c_dp, C.POINTER(qd_objective_value), c_dp, c_dp]
     lib.qd_set_precision.argtypes = [vp, C.c_int]
     lib.qd_get_precision.argtypes = [vp]
+    lib.qd_get_observables.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_dp]
     lib.qd_bench_apply_f32.argtypes = [vp, C.c_double, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     if path is None:
         _lib = lib
@@ -374,6 +375,15 @@ class Handle:
             setattr(out, k, dptr(v))
         _check(self.lib, self.lib.qd_forward(self._h, dptr(x0), nb, int(bool(store_trajectory)), C.byref(out)), "qd_forward")
         return res
+
+    def observables(self, nb, stride=1):
+        """Expected energies, level populations and composite observables of the stored trajectory (device-side)."""
+        sy = self.spec.system
+        nout = self.spec.time.ntime // stride + 1
+        nlev = sum(sy.nlevels[k] for k in range(sy.nosc))
+        e = np.zeros((nout, nb, sy.nosc)); p = np.zeros((nout, nb, nlev)); ec = np.zeros((nout, nb)); pc = np.zeros((nout, nb, self.dim_rho))
+        _check(self.lib, self.lib.qd_get_observables(self._h, int(stride), dptr(e), dptr(p), dptr(ec), dptr(pc)), "qd_get_observables")
+        return {"expected": e, "population": p, "expected_composite": ec, "population_composite": pc}
 
     def get_state(self, timestep, nb):
         x = np.zeros((nb, 2 * self.dim))

@@ -740,6 +740,38 @@ extern "C" int qd_get_state(qd_handle* h, int timestep, double* x) {
   return QD_OK;
 }
 
+extern "C" int qd_get_observables(qd_handle* h, int stride, double* expected, double* population, double* expected_composite,
+                                  double* population_composite) {
+  if (!h || stride < 1) return fail(QD_ERR_INVALID, "qd_get_observables: bad argument");
+  if (!h->traj_valid) return fail(QD_ERR_STATE, "qd_get_observables: no stored trajectory (forward sweep with store_trajectory=1 first)");
+  QD_HIP(hipSetDevice(h->device));
+  const DevSys& S = h->S;
+  const int nb = h->last_nb, nout = h->tg.ntime / stride + 1;
+  int nlev = 0;
+  for (int k = 0; k < S.Q; k++) nlev += S.n[k];
+  const size_t per = (size_t)nout * nb;
+  const size_t ne = expected ? per * S.Q : 0, np = population ? per * nlev : 0, nc = expected_composite ? per : 0,
+               npc = population_composite ? per * S.N : 0;
+  DBuf d;
+  int r;
+  if ((r = d.ensure(ne + np + nc + npc + 1))) return r;
+  double *de = d.p, *dp = de + ne, *dc = dp + np, *dpc = dc + nc;
+  hipError_t e = launch_observables(S, h->d_traj.p, h->precision == QD_PRECISION_F32MIXED, nb, h->nstages, stride, nout, nlev,
+                                    expected ? de : nullptr, population ? dp : nullptr, expected_composite ? dc : nullptr,
+                                    population_composite ? dpc : nullptr, h->stream);
+  if (e == hipSuccess && ne) e = hipMemcpyAsync(expected, de, sizeof(double) * ne, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && np) e = hipMemcpyAsync(population, dp, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && nc) e = hipMemcpyAsync(expected_composite, dc, sizeof(double) * nc, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && npc) e = hipMemcpyAsync(population_composite, dpc, sizeof(double) * npc, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  d.release();
+  if (e != hipSuccess) {
+    set_error(std::string("qd_get_observables: ") + hipGetErrorString(e));
+    return QD_ERR_DEVICE;
+  }
+  return QD_OK;
+}
+
 int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, const DevTarget* tgp, bool accumulate) {
   int r;
   if ((r = adjoint_launch(dxbarT, djbar, nb, tgp, accumulate))) return r;

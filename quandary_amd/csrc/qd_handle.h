@@ -21,6 +21,9 @@
 
 namespace qd {
 
+hipError_t launch_observables(const DevSys& S, const double* traj, int f32, int nb, int nstages, int stride, int nout, int nlev_total,
+                              double* expected, double* population, double* expcomp, double* popcomp, hipStream_t st);
+
 // growable device buffer of doubles
 struct DBuf {
   double* p = nullptr;

@@ -6,10 +6,11 @@
 #include "qd_big.h"
 
 #if !defined(QD_Q) || !defined(QD_L) || !defined(QD_B) || !defined(QD_PART)
-#error "compile with -DQD_Q=<1..8> -DQD_L=<0|1> -DQD_B=<0 general|1 qubit|2 dense> -DQD_PART=<0 forward + apply|1 adjoint>"
+#error "compile with -DQD_Q=<1..8> -DQD_L=<0|1> -DQD_B=<0 general|1 qubit|2 dense> -DQD_PART=<0 forward + apply|1 adjoint|2 forward, GMRES kernels|3 adjoint, GMRES kernels>"
 #endif
-// (two objects per case: the forward and the adjoint kernels of one case compile side by side - the five-oscillator
-// Lindblad unit alone took 13 minutes as one translation unit)
+// (four objects per case: forward / adjoint x Neumann / GMRES kernels compile side by side - the five-oscillator Lindblad
+// case alone took 13 minutes as one translation unit)
+constexpr bool kGmPart = (QD_PART >= 2);
 
 namespace qd {
 
@@ -47,14 +48,14 @@ static hipError_t set_lds(K kern, size_t bytes) {
   return hipSuccess;
 }
 
-#if QD_PART == 0
+#if QD_PART == 0 || QD_PART == 2
 template <int VAR>
 static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (VAR == 16 && variant_built<VAR>()) {
+  if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
     hipLaunchKernelGGL((k_forward_big<QD_Q, kLind>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
     return hipGetLastError();
-  } else if constexpr (variant_built<VAR>()) {
-    auto kf = cfg.gmres ? k_forward<QD_Q, kLind, VAR, kQubit, true> : k_forward<QD_Q, kLind, VAR, kQubit, false>;
+  } else if constexpr (VAR != 16 && variant_built<VAR>()) {
+    auto kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3((a.nb + Variant<VAR>::ICPB - 1) / Variant<VAR>::ICPB), dim3(cfg.block), cfg.lds, st, a);
@@ -63,6 +64,8 @@ static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream
     return hipErrorInvalidValue;
   }
 }
+#endif
+#if QD_PART == 0
 template <int VAR>
 static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                            const LaunchCfg& cfg, hipStream_t st) {
@@ -80,14 +83,15 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
   }
 }
 
-#else
+#endif
+#if QD_PART == 1 || QD_PART == 3
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (VAR == 16 && variant_built<VAR>()) {
+  if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
     hipLaunchKernelGGL((k_adjoint_big<QD_Q, kLind>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
     return hipGetLastError();
-  } else if constexpr (variant_built<VAR>()) {
-    auto kf = cfg.gmres ? k_adjoint<QD_Q, kLind, VAR, kQubit, true> : k_adjoint<QD_Q, kLind, VAR, kQubit, false>;
+  } else if constexpr (VAR != 16 && variant_built<VAR>()) {
+    auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3((a.nb + Variant<VAR>::ICPB - 1) / Variant<VAR>::ICPB), dim3(cfg.block), cfg.lds, st, a);
@@ -121,19 +125,30 @@ static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream
   }
 
 #if QD_PART == 0
+hipError_t QD_NAME(inst_forwardgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
 hipError_t QD_NAME(inst_forward_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  if (cfg.gmres && cfg.var != 16) return QD_NAME(inst_forwardgm_, QD_Q, QD_L, QD_B)(a, cfg, st);  // GMRES kernels: another object
   QD_VAR_SWITCH(go_forward, a, cfg, st)
 }
 hipError_t QD_NAME(inst_apply_, QD_Q, QD_L, QD_B)(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y,
                                                   int nb, const LaunchCfg& cfg, hipStream_t st) {
   QD_VAR_SWITCH(go_apply, S, ctlrow, transpose, x, y, nb, cfg, st)
 }
-#else
+#elif QD_PART == 1
+hipError_t QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
 hipError_t QD_NAME(inst_adjoint_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  if (cfg.gmres && cfg.var != 16) return QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(a, cfg, st);
+  QD_VAR_SWITCH(go_adjoint, a, cfg, st)
+}
+#elif QD_PART == 2
+hipError_t QD_NAME(inst_forwardgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  QD_VAR_SWITCH(go_forward, a, cfg, st)
+}
+#else
+hipError_t QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   QD_VAR_SWITCH(go_adjoint, a, cfg, st)
 }
 #endif
-
 #if QD_B == 0 && QD_PART == 0
 hipError_t QD_NAME(inst_bigtable_, QD_Q, QD_L, QD_B)(const DevSys& S, double* ecoef, unsigned* edig, hipStream_t st) {
   hipLaunchKernelGGL((k_big_table<QD_Q, kLind>), dim3((S.dim + 255) / 256), dim3(256), 0, st, S, reinterpret_cast<double2*>(ecoef),

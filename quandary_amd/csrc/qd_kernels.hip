@@ -227,6 +227,61 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// observables of the stored trajectory (Oscillator::expectedEnergy / population src/oscillator.cpp:430-566,
+// MasterEq::expectedEnergy / population src/mastereq.cpp:2897-2974): one workgroup per (output step, initial condition).
+// P(I) = rho_II (Lindblad) or |psi_I|^2; population_k[l] = sum over I with digit_k(I) = l (one thread per (k, l), ascending I:
+// the summation order of the reference's loop), expected_k = sum_I digit_k(I) P(I); composite: sum_I I P(I) and P itself.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_observables(const DevSys S, const double* __restrict__ traj, int f32, int nb, int nstages, int stride,
+                                                     int nlev_total, double* __restrict__ expected, double* __restrict__ population,
+                                                     double* __restrict__ expcomp, double* __restrict__ popcomp) {
+  __shared__ double red[2 * NRED * 4];
+  const int o = blockIdx.y, b = blockIdx.x, N = S.N, dim = S.dim;
+  const size_t state = (size_t)o * stride * nstages * nb + b;
+  auto prob = [&](int I) -> double {
+    const int e = S.lindblad ? I + I * N : I;
+    if (f32) {
+      const float2 v = reinterpret_cast<const float2*>(traj)[state * dim + e];
+      return S.lindblad ? (double)v.x : (double)v.x * v.x + (double)v.y * v.y;
+    }
+    const double u = traj[state * 2 * dim + e];
+    if (S.lindblad) return u;
+    const double v = traj[state * 2 * dim + dim + e];
+    return u * u + v * v;
+  };
+  const size_t ob = (size_t)o * nb + b;
+  if (popcomp)
+    for (int I = threadIdx.x; I < N; I += blockDim.x) popcomp[ob * N + I] = prob(I);
+  if (population || expected) {
+    for (int t = threadIdx.x; t < nlev_total; t += blockDim.x) {  // thread -> (oscillator k, level l)
+      int k = 0, l = t;
+      while (l >= S.n[k]) { l -= S.n[k]; k++; }
+      const int post = S.post[k], nk = S.n[k];
+      double s = 0.0;
+      for (int hi = 0; hi < N / (nk * post); hi++)       // I = hi nk post + l post + lo, ascending
+        for (int lo = 0; lo < post; lo++) s += prob((hi * nk + l) * post + lo);
+      if (population) population[ob * nlev_total + t] = s;
+    }
+  }
+  if (expected || expcomp) {
+    double v[NRED];
+#pragma unroll
+    for (int i = 0; i < NRED; i++) v[i] = 0.0;
+    for (int I = threadIdx.x; I < N; I += blockDim.x) {
+      const double p = prob(I);
+      for (int k = 0; k < S.Q; k++) v[k] += ((I / S.post[k]) % S.n[k]) * p;
+      v[QD_MAX_OSC] += I * p;
+    }
+    block_sum<NRED, false>(v, red);
+    if (threadIdx.x == 0) {
+      if (expected)
+        for (int k = 0; k < S.Q; k++) expected[ob * S.Q + k] = v[k];
+      if (expcomp) expcomp[ob] = v[QD_MAX_OSC];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // objective level on the device (multi-GPU path: nothing returns to the host between the sweeps and the collectives)
 // ---------------------------------------------------------------------------------------------
 // The seven partial sums the reference all-reduces over comm_init (src/optimproblem.cpp:258-298) from the per-state
@@ -496,6 +551,13 @@ hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, co
                        hipStream_t st) {
   if (S.lindblad) hipLaunchKernelGGL(k_seed<true>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
   else hipLaunchKernelGGL(k_seed<false>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
+  return hipGetLastError();
+}
+
+hipError_t launch_observables(const DevSys& S, const double* traj, int f32, int nb, int nstages, int stride, int nout, int nlev_total,
+                              double* expected, double* population, double* expcomp, double* popcomp, hipStream_t st) {
+  hipLaunchKernelGGL(k_observables, dim3(nb, nout), dim3(256), 0, st, S, traj, f32, nb, nstages, stride, nlev_total, expected, population,
+                     expcomp, popcomp);
   return hipGetLastError();
 }
 

@@ -399,27 +399,6 @@ static void build(Problem& P) {
   o.gamma_penalty_variation = cfg.dbl("optim_penalty_variation", 0.01);
 }
 
-// ---- observables for the trajectory files (src/oscillator.cpp:430-566, src/mastereq.cpp:2897-2974) ----
-static double expected_energy(const Problem& P, int k, const double* x) {
-  int post = 1;
-  for (int j = k + 1; j < P.Q; j++) post *= P.nlevels[j];
-  double e = 0.0;
-  for (int i = 0; i < P.N; i++) {
-    const int num = (i % (P.nlevels[k] * post)) / post;
-    e += P.lindblad ? num * x[i + (size_t)i * P.N] : num * (x[i] * x[i] + x[i + P.dim] * x[i + P.dim]);
-  }
-  return e;
-}
-static void population(const Problem& P, int k, const double* x, std::vector<double>& pop) {
-  int post = 1;
-  for (int j = k + 1; j < P.Q; j++) post *= P.nlevels[j];
-  pop.assign(P.nlevels[k], 0.0);
-  for (int i = 0; i < P.N; i++) {
-    const int num = (i % (P.nlevels[k] * post)) / post;
-    pop[num] += P.lindblad ? x[i + (size_t)i * P.N] : x[i] * x[i] + x[i + P.dim] * x[i + P.dim];
-  }
-}
-
 static void write_trajectories(const Problem& P, Output& out, qd_handle* h, qd_optim* o) {
   const int nl = qd_optim_ninit_local(o);
   const size_t n2 = (size_t)2 * P.dim;
@@ -461,30 +440,39 @@ static void write_trajectories(const Problem& P, Output& out, qd_handle* h, qd_o
       F[i].v = fopen(fn, "w");
     }
   }
-  std::vector<double> states((size_t)nl * n2), pop;
+  // observables are reduced on the device from the stored trajectory (one launch, one download); full states only travel
+  // to the host when `fullstate` output is requested
+  bool any_e = false, any_p = false;
+  for (int k = 0; k < P.Q; k++) { any_e = any_e || out.wexp[k]; any_p = any_p || out.wpop[k]; }
+  int nlev = 0;
+  std::vector<int> lev0(P.Q, 0);
+  for (int k = 0; k < P.Q; k++) { lev0[k] = nlev; nlev += P.nlevels[k]; }
+  const int nout = P.ntime / out.output_frequency + 1;
+  std::vector<double> oe(any_e ? (size_t)nout * nl * P.Q : 0), op(any_p ? (size_t)nout * nl * nlev : 0), oec(out.ecomp ? (size_t)nout * nl : 0),
+      opc(out.pcomp ? (size_t)nout * nl * P.N : 0);
+  if (any_e || any_p || out.ecomp || out.pcomp)
+    QDCHK(qd_get_observables(h, out.output_frequency, any_e ? oe.data() : nullptr, any_p ? op.data() : nullptr, out.ecomp ? oec.data() : nullptr,
+                             out.pcomp ? opc.data() : nullptr));
+  std::vector<double> states(out.full ? (size_t)nl * n2 : 0);
   for (int n = 0; n <= P.ntime; n++) {  // Output::writeTrajectoryDataFiles (src/output.cpp:203-273)
     if (n % out.output_frequency) continue;
-    QDCHK(qd_get_state(h, n, states.data()));
+    if (out.full) QDCHK(qd_get_state(h, n, states.data()));
     const double time = n * P.dt;
+    const size_t io = (size_t)(n / out.output_frequency) * nl;
     for (int i = 0; i < nl; i++) {
-      const double* x = states.data() + (size_t)i * n2;
+      const double* x = out.full ? states.data() + (size_t)i * n2 : nullptr;
       for (int k = 0; k < P.Q; k++) {
-        if (F[i].e[k]) fprintf(F[i].e[k], "%.8f %1.14e\n", time, expected_energy(P, k, x));
+        if (F[i].e[k]) fprintf(F[i].e[k], "%.8f %1.14e\n", time, oe[(io + i) * P.Q + k]);
         if (F[i].p[k]) {
-          population(P, k, x, pop);
           fprintf(F[i].p[k], "%.8f ", time);
-          for (double v : pop) fprintf(F[i].p[k], " %1.14e", v);
+          for (int l = 0; l < P.nlevels[k]; l++) fprintf(F[i].p[k], " %1.14e", op[(io + i) * nlev + lev0[k] + l]);
           fprintf(F[i].p[k], "\n");
         }
       }
-      if (F[i].ec) {
-        double e = 0.0;
-        for (int r = 0; r < P.N; r++) e += P.lindblad ? r * x[r + (size_t)r * P.N] : r * (x[r] * x[r] + x[r + P.dim] * x[r + P.dim]);
-        fprintf(F[i].ec, "%.8f %1.14e\n", time, e);
-      }
+      if (F[i].ec) fprintf(F[i].ec, "%.8f %1.14e\n", time, oec[io + i]);
       if (F[i].pc) {
         fprintf(F[i].pc, "%.8f  ", time);
-        for (int r = 0; r < P.N; r++) fprintf(F[i].pc, "%1.14e  ", P.lindblad ? x[r + (size_t)r * P.N] : x[r] * x[r] + x[r + P.dim] * x[r + P.dim]);
+        for (int r = 0; r < P.N; r++) fprintf(F[i].pc, "%1.14e  ", opc[(io + i) * P.N + r]);
         fprintf(F[i].pc, "\n");
       }
       if (F[i].u) {

@@ -727,3 +727,36 @@ def test_full_batch_properties_at_baseline_size(name, ninit):
         po = orc.forward_local(sp.params0, int(r), ninit)
         np.testing.assert_allclose(part, po, rtol=0, atol=1e-9 * np.maximum(1.0, np.abs(po)).max())
     h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [SHAPES[1], SHAPES[6], SHAPES[7],
+                                pytest.param(dict(nlevels=[2] * 4, lindblad=True, init="diagonal, 0, 1", precision="f32mixed"), id="2^4-lindblad-f32mixed")])
+def test_device_side_observables(kw):
+    """qd_get_observables: expected energies, level populations and the composite observables of the stored trajectory,
+    reduced on the device, against the oracle's Oscillator::expectedEnergy / population on the same states."""
+    kw = dict(kw)
+    prec = kw.pop("precision", "f64")
+    sp, h, orc = _pair(kw, ntime=12)
+    if prec != "f64":
+        h.close()
+        sp.precision = prec
+        h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    nb = opt.ninit_local
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(nb)])
+    h.set_params(sp.params0)
+    h.forward(x0, store_trajectory=True)
+    obs = h.observables(nb, stride=4)
+    Q, N = sp.system.nosc, h.dim_rho
+    lev0 = np.cumsum([0] + [sp.system.nlevels[k] for k in range(Q)])
+    tol = 1e-12 if prec == "f64" else 1e-6
+    for o, n in enumerate((0, 4, 8, 12)):
+        st = h.get_state(n, nb)
+        for b in range(nb):
+            for k in range(Q):
+                assert obs["expected"][o, b, k] == pytest.approx(orc.expected_energy(k, st[b]), abs=tol)
+                np.testing.assert_allclose(obs["population"][o, b, lev0[k]:lev0[k + 1]], orc.population(k, st[b]), rtol=0, atol=tol)
+            diag = st[b][:h.dim].reshape(N, N).diagonal() if sp.system.lindblad_type else st[b][:N] ** 2 + st[b][h.dim:h.dim + N] ** 2
+            np.testing.assert_allclose(obs["population_composite"][o, b], diag, rtol=0, atol=tol)
+            assert obs["expected_composite"][o, b] == pytest.approx(float(np.sum(np.arange(N) * diag)), abs=tol * N)
+    opt.close(); h.close(); orc.close()
