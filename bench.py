@@ -273,7 +273,8 @@ class Runner:
         valu_achieved = f_step * units_per_launch / kern_s / 1e12
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else ""), self.mode, units_per_launch),
+            "traffic": pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_gmres" if spec.solver.linsolve == 0 else ""),
+                                   self.mode, units_per_launch),
             "kernel": "k_forward" if self.mode == "fwd" else "k_forward+k_adjoint",
             "kernel_ms_per_launch": kern_s * 1e3,
             "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": units_per_launch,

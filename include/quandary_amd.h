@@ -51,7 +51,7 @@
  * Lindblad 1..5 oscillators (like the
  * reference's matrix-free templates), Schroedinger 1..8; at most 256 / 64 / 32 / 16
  * levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied
- * Hamiltonians dim <= 1024.  Control segments: "spline", "spline0" (the reference's
+ * Hamiltonians: 1..5 oscillators, table of G(t) <= 16 GB.  Control segments: "spline", "spline0" (the reference's
  * "step" and "spline_amplitude" are rejected).  There is no CPU fallback.
  */
 #ifndef QUANDARY_AMD_H
@@ -197,8 +197,7 @@ int qd_ndesign(const qd_handle* h);    /* number of control parameters         *
  * (NULL = no control Hamiltonians, the reference's "none").  They REPLACE the standard Hamiltonian model of
  * the qd_system description - detuning, Kerr terms, dipole coupling, ladder-operator controls:
  *     H(t) = Hsys + sum_k p_k(t) Re(Hc_k) + i q_k(t) Im(Hc_k),
- * the T1/T2 dissipators of qd_system stay.  Supported for state dimensions up to 1024.  Call before the
- * first sweep. */
+ * the T1/T2 dissipators of qd_system stay.  Call before the first sweep. */
 int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const double* hsys_im, const double* hc_re, const double* hc_im);
 
 int qd_set_params(qd_handle* h, const double* alpha, int ndesign);

@@ -7,6 +7,8 @@
 // system (k_big_table) instead of registers.  The stencil itself is GenStencil::apply / ::ladder of qd_device.h with the
 // element's invariants loaded into the (one-slot) stencil object - the same code that the LDS kernels run.
 #pragma once
+#include <type_traits>
+
 #include "qd_device.h"
 
 namespace qd {
@@ -50,9 +52,10 @@ __global__ void k_big_table(const DevSys S, double2* __restrict__ coef, uint2* _
   dig[e] = make_uint2(dbra, dket);
 }
 
-template <int Q, bool LIND>
+template <int Q, bool LIND, bool DENSE = false>
 struct BigTeam {
-  typedef GenStencil<Q, LIND, 1, 2> ST;  // one slot, table-driven (non-hoisted) formulation
+  // one slot, table-driven (non-hoisted) formulation; DENSE: user-supplied Hamiltonians, G(t) read from the table in global memory
+  typedef typename std::conditional<DENSE, DenseStencil<Q, LIND, 1, 2>, GenStencil<Q, LIND, 1, 2>>::type ST;
   ST st;
   Lds L;
   int dim, redslot;
@@ -291,10 +294,10 @@ struct BigTeam {
   }
 };
 
-template <int Q, bool LIND>
+template <int Q, bool LIND, bool DENSE = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef BigTeam<Q, LIND> TM;
+  typedef BigTeam<Q, LIND, DENSE> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     scalarize<Q>(c, jpairs);
-    c.g = nullptr;
+    c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     if (A.traj) {
       double* dst = A.traj + ((size_t)s * A.nb + ic) * 2 * dim;
       for (int e = tid; e < dim; e += nt) {
@@ -424,10 +427,10 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   }
 }
 
-template <int Q, bool LIND>
+template <int Q, bool LIND, bool DENSE = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef BigTeam<Q, LIND> TM;
+  typedef BigTeam<Q, LIND, DENSE> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     scalarize<Q>(c, jpairs);
-    c.g = nullptr;
+    c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     for (int e = tid; e < dim; e += nt) X[e] = state(s, e);
     __syncthreads();
     double cf[2 * Q];
@@ -563,11 +566,11 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   }
 }
 
-template <int Q, bool LIND>
+template <int Q, bool LIND, bool DENSE = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_apply_big(const DevSys S, const double* __restrict__ ctlrow, int transpose,
                                                          const double* __restrict__ xin, double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  BigTeam<Q, LIND> tm;
+  BigTeam<Q, LIND, DENSE> tm;
   tm.init(S, smem);
   const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
   double2* X = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_apply_big(const DevSys S, const d
   StepC<Q> c;
   load_step<Q>(ctlrow, c, S.npairs > 0);
   scalarize<Q>(c, S.npairs > 0);
-  c.g = nullptr;
+  c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) : nullptr;  // one-row table of the test hook
   double* yo = yout + (size_t)ic * 2 * dim;
   for (int e = tid; e < dim; e += nt) {
     const double2 y = transpose ? tm.template apply<true>(S, c, X, e) : tm.template apply<false>(S, c, X, e);

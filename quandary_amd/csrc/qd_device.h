@@ -1738,7 +1738,8 @@ struct Team {
 
   // GMRES for (I - alpha M^{(T)}) y = b: stands in for KSPSolve / KSPSolveTranspose with KSPGMRES +
   // PCNONE (src/timestepper.cpp:541-550, call sites :602,:652,:674): zero initial guess, classical
-  // Gram-Schmidt (PETSc's default orthogonalisation), Givens rotations, stop when the recurrence
+  // Gram-Schmidt (PETSc's default orthogonalisation; the CPU oracle restates Saad-Schultz with the modified
+  // variant - same method in exact arithmetic, the tests pin the application counts against it), Givens rotations, stop when the recurrence
   // residual <= max(rtol ||b||, abstol) or after maxiter iterations; restarted every GMRES_MR
   // iterations.  One element per thread: the Krylov basis lives in LDS (the stencil reads v_j in
   // place), the small Hessenberg problem is solved redundantly by every thread on wave-uniform

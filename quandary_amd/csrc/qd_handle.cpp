@@ -316,7 +316,7 @@ extern "C" int qd_ndesign(const qd_handle* h) { return h ? h->ndesign : QD_ERR_I
 extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const double* hsys_im, const double* hc_re, const double* hc_im) {
   if (!h || !hsys_re || !hsys_im) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: null system Hamiltonian");
   if ((hc_re == nullptr) != (hc_im == nullptr)) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: give both parts of the control Hamiltonians or neither");
-  if (h->S.dim > 1024) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: user Hamiltonians are supported for state dimensions up to 1024");
+  // (dim <= 1024: the LDS kernels V11-V13 / V15; beyond: the global-memory sweeps of qd_big.h with the dense operator)
   if (h->S.Q > 5) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: the dense-operator kernels are instantiated for 1..5 oscillators");
   QD_HIP(hipSetDevice(h->device));
   const size_t nn = (size_t)h->S.N * h->S.N;

@@ -34,7 +34,7 @@ constexpr bool variant_built() {
   // least two levels: dim >= 2^Q, or 4^Q for Lindblad) - the five-oscillator Lindblad unit alone took 6 minutes
   constexpr long kMinDim = kLind ? (1L << (2 * QD_Q)) : (1L << QD_Q);
   constexpr bool fits0 = kMinDim <= 64, fits1 = kMinDim <= 256, fits2 = kMinDim <= 1024;
-  if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4);
+  if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4) || VAR == 16;
   if (!kQubit) return (VAR == 0 && fits0) || (VAR == 1 && fits1) || (VAR == 2 && fits2) || VAR == 4 || (kLind && (VAR == 9 || VAR == 14)) || VAR == 16;
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
@@ -52,7 +52,7 @@ static hipError_t set_lds(K kern, size_t bytes) {
 template <int VAR>
 static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
-    hipLaunchKernelGGL((k_forward_big<QD_Q, kLind>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
+    hipLaunchKernelGGL((k_forward_big<QD_Q, kLind, kDense>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
     return hipGetLastError();
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart>;
@@ -70,7 +70,7 @@ template <int VAR>
 static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                            const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>()) {
-    hipLaunchKernelGGL((k_apply_big<QD_Q, kLind>), dim3(nb), dim3(cfg.block), cfg.lds, st, S, ctlrow, transpose, x, y);
+    hipLaunchKernelGGL((k_apply_big<QD_Q, kLind, kDense>), dim3(nb), dim3(cfg.block), cfg.lds, st, S, ctlrow, transpose, x, y);
     return hipGetLastError();
   } else if constexpr (variant_built<VAR>()) {
     auto kf = k_apply<QD_Q, kLind, VAR, kQubit>;
@@ -88,7 +88,7 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
-    hipLaunchKernelGGL((k_adjoint_big<QD_Q, kLind>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
+    hipLaunchKernelGGL((k_adjoint_big<QD_Q, kLind, kDense>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
     return hipGetLastError();
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;

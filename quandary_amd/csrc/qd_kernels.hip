@@ -432,9 +432,9 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   }
   // beyond one CU's LDS: work vectors in global memory (qd_big.h); general stencil whatever the level structure.
   // QD_VAR=16 forces it onto small systems (parity tests of this path against everything the LDS kernels are tested on)
-  if (!S.dense && (dim > 4096 || (getenv("QD_VAR") && atoi(getenv("QD_VAR")) == 16))) {
+  if ((S.dense ? dim > 1024 : dim > 4096) || (getenv("QD_VAR") && atoi(getenv("QD_VAR")) == 16)) {
     c.var = 16;
-    c.qubit = 0;
+    c.qubit = S.dense ? 2 : 0;
     c.block = BIG_BLOCK;
     c.gmres = gm ? 2 : 0;
     c.lds = BigTeam<1, false>::lds_bytes(S);

@@ -41,7 +41,8 @@ class TorchComm:
         return self.dist.get_world_size()
 
     def describe(self):
-        return f"torch.distributed/{self.backend} on {self.device} buffers"
+        extra = f" (fallback: {self.fallback_reason})" if getattr(self, "fallback_reason", "") else ""
+        return f"torch.distributed/{self.backend} on {self.device} buffers" + extra
 
     def _reduce(self, arr, op):
         import torch
@@ -120,7 +121,25 @@ class RcclComm(TorchComm):
 
 def make_comm(backend, rank, world, local_rank=0):
     if backend == "nccl":
-        return RcclComm(rank, world, local_rank)
+        # RCCL inside the library.  Should its bootstrap fail on ANY rank (decided collectively over gloo, so that every rank
+        # takes the same branch), the run continues with host-staged gloo reductions and says so in `describe()`.
+        comm, err = None, ""
+        try:
+            comm = RcclComm(rank, world, local_rank)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        import torch
+        import torch.distributed as dist
+
+        ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() > 0.5:
+            return comm
+        if comm is not None:
+            comm.lib.qd_comm_destroy(comm.comm)
+        fb = TorchComm("gloo", rank, world, "cpu")
+        fb.fallback_reason = err or "RCCL bootstrap failed on another rank"
+        return fb
     return TorchComm(backend, rank, world, "cpu")
 
 

@@ -234,6 +234,13 @@ DENSE_SHAPES = [
 ]
 
 
+DENSE_SHAPES += [
+    # beyond dim 1024 (QD_ERR_UNSUPPORTED in round 1): the dense operator inside the global-memory sweeps of qd_big.h
+    pytest.param(dict(nlevels=[6, 6], lindblad=True, nessential=[3, 3], target="pure", objective="Jfrobenius", init="diagonal, 0"), id="dense-6x6-lindblad-dim1296"),
+    pytest.param(dict(nlevels=[40, 30], lindblad=False, target="pure", objective="Jmeasure", init="pure, 1, 2"), id="dense-1200-schroedinger"),
+]
+
+
 @pytest.mark.parametrize("kw", DENSE_SHAPES)
 @pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
 def test_user_hamiltonian_operator_vs_oracle(kw, linsolve):
