@@ -51,8 +51,9 @@
  * Lindblad 1..5 oscillators (like the
  * reference's matrix-free templates), Schroedinger 1..8; at most 256 / 64 / 32 / 16
  * levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied
- * Hamiltonians: 1..5 oscillators, table of G(t) <= 16 GB.  Control segments: "spline", "spline0" (the reference's
- * "step" and "spline_amplitude" are rejected).  There is no CPU fallback.
+ * Hamiltonians: 1..5 oscillators, table of G(t) <= 16 GB.  Control segments: "spline", "spline0", "step" and
+ * "spline_amplitude" (the last one forward only, as in the reference: src/oscillator.cpp:350-356).  There is no CPU
+ * fallback.
  */
 #ifndef QUANDARY_AMD_H
 #define QUANDARY_AMD_H
@@ -78,8 +79,9 @@ extern "C" {
 
 /* LindbladType, include/defs.hpp */
 enum { QD_LINDBLAD_NONE = 0, QD_LINDBLAD_DECAY = 1, QD_LINDBLAD_DEPHASE = 2, QD_LINDBLAD_BOTH = 3 };
-/* ControlType, include/defs.hpp; only BSPLINE and BSPLINE0 carry a gradient in the reference */
-enum { QD_CTRL_NONE = 0, QD_CTRL_BSPLINE = 1, QD_CTRL_BSPLINE0 = 2 };
+/* ControlType, include/defs.hpp.  BSPLINEAMP carries no gradient in the reference (src/oscillator.cpp:350-356):
+ * the gradient entry points return QD_ERR_UNSUPPORTED for it. */
+enum { QD_CTRL_NONE = 0, QD_CTRL_BSPLINE = 1, QD_CTRL_BSPLINE0 = 2, QD_CTRL_STEP = 3, QD_CTRL_BSPLINEAMP = 4 };
 /* timestepper = IMR | IMR4 | IMR8 | EE, src/main.cpp:357-366 */
 enum { QD_STEPPER_IMR = 0, QD_STEPPER_IMR4 = 1, QD_STEPPER_IMR8 = 2, QD_STEPPER_EE = 3 };
 /* linearsolver_type = gmres | neumann, src/main.cpp:342-350 */
@@ -112,7 +114,10 @@ typedef struct qd_system {
 
 /* Control parameterisation (src/oscillator.cpp:45-132, src/controlbasis.cpp).
  * Segments are listed oscillator by oscillator; design vector layout per
- * oscillator is [segment][carrier][2*nsplines] (src/controlbasis.cpp:58-59). */
+ * oscillator is [segment][carrier][2*nsplines] for spline / spline0 (src/controlbasis.cpp:58-59),
+ * [segment][carrier][nsplines amplitudes, phase] for spline_amplitude (:127-140) and one parameter
+ * (the relative width of the step) for step (:195-206; one carrier: the reference's index
+ * skip + 2*carrier runs past the segment's single parameter for more). */
 typedef struct qd_controls {
   int32_t enforce_bc;                  /* control_enforceBC                  */
   int32_t nseg_total;
@@ -129,6 +134,8 @@ typedef struct qd_controls {
   const double* pipulse_tstart;        /* [npipulse]                         */
   const double* pipulse_tstop;         /* [npipulse]                         */
   const double* pipulse_amp;           /* [npipulse] (0 for non-target osc)  */
+  const double* seg_param;             /* [nseg_total][3] or NULL.  step: amp1, amp2 (rad/ns, as given in the
+                                          config), tramp (ns); spline_amplitude: scaling, -, -         */
 } qd_controls;
 
 typedef struct qd_time {
@@ -237,6 +244,9 @@ double qd_last_mean_applies(const qd_handle* h);
  * (hipEvent bracket on the handle's stream). */
 double qd_last_forward_ms(const qd_handle* h);
 double qd_last_adjoint_ms(const qd_handle* h);
+/* Workgroups per initial condition in the last sweep: 1, or the team size when a large state (dim > 4096) with few
+ * initial conditions was spread over several CUs. */
+int qd_last_team(const qd_handle* h);
 /* Measurement hook for the secondary (fp64 vector) roofline: runs a register-only
  * v_fma_f64 micro-benchmark on the device and returns the sustained TFLOP/s in
  * *tflops (the fp64 peak is to be measured, not quoted). */

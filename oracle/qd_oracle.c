@@ -48,8 +48,9 @@ typedef struct {
 } osys;
 
 typedef struct {
-  int type, nsplines, skip;
+  int type, nsplines, skip, npc; /* npc = parameters per carrier wave */
   double tstart, tstop, dtknot, width;
+  double a1, a2, a3; /* step: amp1, amp2, tramp; spline_amplitude: scaling */
   double* tcenter;
 } oseg;
 
@@ -63,7 +64,7 @@ typedef struct {
 typedef struct qo_ctx {
   osys s;
   oosc osc[QO_MAXQ];
-  int enforce_bc, ndesign;
+  int enforce_bc, ndesign, has_ampbasis;
   int ntime;
   double dt, Tfinal;
   qd_solver sol;
@@ -150,8 +151,43 @@ static double bspline2_basis(const oseg* g, int id, double t) { /* controlbasis.
   return val;
 }
 
+/* getRampFactor / getRampFactor_diff, src/util.cpp:92-147 */
+static double ramp_factor(double time, double tstart, double tstop, double tramp) {
+  double r = 0.0;
+  if (time <= tstart + tramp) r = 1.0 / tramp * time - tstart / tramp;
+  else if (tstart + tramp <= time && time <= tstop - tramp) r = 1.0;
+  else if (time >= tstop - tramp && time <= tstop) r = -1.0 / tramp * time + tstop / tramp;
+  if (tstop < tstart + 2 * tramp) r = 0.0;
+  return r;
+}
+static double ramp_factor_diff(double time, double tstart, double tstop, double tramp) {
+  double d = 0.0;
+  if (time <= tstart + tramp) d = 0.0;
+  else if (tstart + tramp <= time && time <= tstop - tramp) d = 0.0;
+  else if (time >= tstop - tramp && time <= tstop) d = 1.0 / tramp;
+  if (tstop < tstart + 2 * tramp) d = 0.0;
+  return d;
+}
+
+/* The reference holds no golden file or test for "step" and "spline_amplitude": these two branches restate
+ * src/controlbasis.cpp:127-141 and :195-216 and are checked by properties only (tests/test_control_bases.py). */
 static void seg_evaluate(const qo_ctx* c, const oseg* g, const double* coeff, int f, double t, double* b1, double* b2) {
-  if (g->type == QD_CTRL_BSPLINE) { /* controlbasis.cpp:48-66 */
+  if (g->type == QD_CTRL_STEP) { /* Step::evaluate, controlbasis.cpp:195-206 */
+    double alpha = coeff[g->skip + f * 2];
+    double tstepend = g->tstart + alpha * (g->tstop - g->tstart);
+    double ramp = 1.0;
+    if (g->a3 > 1e-13) ramp = ramp_factor(t, g->tstart, tstepend, g->a3);
+    *b1 = ramp * g->a1;
+    *b2 = ramp * g->a2;
+  } else if (g->type == QD_CTRL_BSPLINEAMP) { /* BSpline2ndAmplitude::evaluate, controlbasis.cpp:127-141: b2 = phase */
+    double s1 = 0.0;
+    for (int l = 0; l < g->nsplines; l++) {
+      if (c->enforce_bc && (l <= 1 || l >= g->nsplines - 2)) continue;
+      s1 += coeff[g->skip + f * (g->nsplines + 1) + l] * bspline2_basis(g, l, t);
+    }
+    *b1 = s1;
+    *b2 = g->a1 * coeff[g->skip + f * (g->nsplines + 1) + g->nsplines];
+  } else if (g->type == QD_CTRL_BSPLINE) { /* controlbasis.cpp:48-66 */
     double s1 = 0.0, s2 = 0.0;
     for (int l = 0; l < g->nsplines; l++) {
       if (c->enforce_bc && (l <= 1 || l >= g->nsplines - 2)) continue;
@@ -173,8 +209,14 @@ static void seg_evaluate(const qo_ctx* c, const oseg* g, const double* coeff, in
   }
 }
 
-static void seg_derivative(const qo_ctx* c, const oseg* g, double* cd, double v1, double v2, int f, double t) {
-  if (g->type == QD_CTRL_BSPLINE) { /* controlbasis.cpp:68-79 */
+static void seg_derivative(const qo_ctx* c, const oseg* g, const double* coeff, double* cd, double v1, double v2, int f, double t) {
+  if (g->type == QD_CTRL_STEP) { /* Step::derivative, controlbasis.cpp:208-216 */
+    double alpha = coeff[g->skip + f * 2];
+    double tstepend = g->tstart + alpha * (g->tstop - g->tstart);
+    double dramp = ramp_factor_diff(t, g->tstart, tstepend, g->a3);
+    cd[g->skip + f * 2] += g->a1 * v1 * dramp * (g->tstop - g->tstart);
+    cd[g->skip + f * 2] += g->a2 * v2 * dramp * (g->tstop - g->tstart);
+  } else if (g->type == QD_CTRL_BSPLINE) { /* controlbasis.cpp:68-79 */
     for (int l = 0; l < g->nsplines; l++) {
       if (c->enforce_bc && (l <= 1 || l >= g->nsplines - 2)) continue;
       double B = bspline2_basis(g, l, t);
@@ -205,6 +247,11 @@ static int eval_control(const qo_ctx* c, int k, double t, double* p, double* q) 
         for (int f = 0; f < o->ncar; f++) {
           double b1, b2;
           seg_evaluate(c, g, coeff, f, t, &b1, &b2);
+          if (g->type == QD_CTRL_BSPLINEAMP) { /* oscillator.cpp:308-312: b2 is the phase */
+            sp += cos(o->car[f] * t + b2) * b1;
+            sqv += sin(o->car[f] * t + b2) * b1;
+            continue;
+          }
           double co = cos(o->car[f] * t), si = sin(o->car[f] * t);
           sp += co * b1 - si * b2;
           sqv += si * b1 + co * b2;
@@ -235,7 +282,7 @@ static void eval_control_diff(const qo_ctx* c, int k, double t, double* grad, do
           double co = cos(o->car[f] * t), si = sin(o->car[f] * t);
           double b1 = si * qbar + co * pbar;
           double b2 = co * qbar - si * pbar;
-          seg_derivative(c, g, grad, b1, b2, f, t);
+          seg_derivative(c, g, c->params + o->offset, grad, b1, b2, f, t);
         }
         break;
       }
@@ -1650,11 +1697,32 @@ int qo_create(const qd_system* sys, const qd_controls* ctl, const qd_time* tg, c
       } else if (sg->type == QD_CTRL_BSPLINE0) {
         sg->dtknot = (sg->tstop - sg->tstart) / (sg->nsplines - 1.0);
         sg->width = sg->dtknot;
+      } else if (sg->type == QD_CTRL_STEP) { /* controlbasis.cpp:186-191; one parameter, read at skip + 2*carrier (:197) */
+        if (!ctl->seg_param || o->ncar != 1) {
+          qo_destroy(c);
+          return fail("step segment: needs seg_param and exactly one carrier wave");
+        }
+        sg->nsplines = 1;
+        sg->a1 = ctl->seg_param[3 * g];
+        sg->a2 = ctl->seg_param[3 * g + 1];
+        sg->a3 = ctl->seg_param[3 * g + 2];
+      } else if (sg->type == QD_CTRL_BSPLINEAMP) { /* controlbasis.cpp:99-112 */
+        if (!ctl->seg_param) {
+          qo_destroy(c);
+          return fail("spline_amplitude segment: needs seg_param");
+        }
+        sg->dtknot = (sg->tstop - sg->tstart) / (double)(sg->nsplines - 2);
+        sg->width = 3.0 * sg->dtknot;
+        sg->tcenter = (double*)malloc(sizeof(double) * sg->nsplines);
+        for (int i = 0; i < sg->nsplines; i++) sg->tcenter[i] = sg->tstart + sg->dtknot * ((i + 1) - 1.5);
+        sg->a1 = ctl->seg_param[3 * g];
+        c->has_ampbasis = 1;
       } else {
         qo_destroy(c);
         return fail("unsupported control segment type");
       }
-      skip += 2 * sg->nsplines * o->ncar;
+      sg->npc = sg->type == QD_CTRL_STEP ? 1 : sg->type == QD_CTRL_BSPLINEAMP ? sg->nsplines + 1 : 2 * sg->nsplines;
+      skip += sg->npc * o->ncar;
     }
     o->nparams = skip;
     o->offset = off;
@@ -1773,6 +1841,7 @@ int qo_drhs_coeffs(qo_ctx* c, const double* z, const double* xbar, double* coeff
 /* one evolveFWD / evolveBWD step on explicit states (for stepper-level parity tests) */
 int qo_step_fwd(qo_ctx* c, double tstart, double tstop, double* x) { return evolve_fwd(c, tstart, tstop, x); }
 int qo_step_bwd(qo_ctx* c, double tstop, double tstart, const double* x, double* xadj, double* grad) {
+  if (c->has_ampbasis) return fail("spline_amplitude has no gradient in the reference (src/oscillator.cpp:350-356)");
   double* xstage = (double*)malloc(sizeof(double) * 2 * c->s.dim * 15);
   int rc = evolve_bwd(c, tstop, tstart, x, xadj, grad, xstage);
   free(xstage);
@@ -1914,6 +1983,7 @@ int qo_optim_evalF(qo_optim* o, const double* alpha, qd_objective_value* val, in
 /* OptimProblem::evalGradF, src/optimproblem.cpp:342-538 */
 int qo_optim_evalGradF(qo_optim* o, const double* alpha, qd_objective_value* val, double* G) {
   qo_ctx* c = o->c;
+  if (c->has_ampbasis) return fail("spline_amplitude has no gradient in the reference (src/oscillator.cpp:350-356)");
   const int n2 = 2 * c->s.dim, nd = c->ndesign;
   if (qo_set_params(c, alpha, nd)) return -1;
   osweep w;
@@ -2023,6 +2093,7 @@ int qo_optim_finalize(qo_optim* o, const double* alpha, const double* sums, qd_o
  * restatement keeps no state between the two calls). */
 int qo_optim_adjoint_local(qo_optim* o, const double* alpha, int rank, int nranks, const double* sums, double* G) {
   qo_ctx* c = o->c;
+  if (c->has_ampbasis) return fail("spline_amplitude has no gradient in the reference (src/oscillator.cpp:350-356)");
   const int n2 = 2 * c->s.dim, nd = c->ndesign;
   if (o->ninit % nranks) return fail("nranks must divide ninit");
   const int nl = o->ninit / nranks, first = rank * nl;

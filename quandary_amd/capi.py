@@ -19,7 +19,7 @@ QD_MAX_PAIRS = QD_MAX_OSC * (QD_MAX_OSC - 1) // 2
 
 # enums (include/quandary_amd.h)
 LINDBLAD = {"none": 0, "decay": 1, "dephase": 2, "both": 3}
-CTRL_BSPLINE, CTRL_BSPLINE0 = 1, 2
+CTRL_BSPLINE, CTRL_BSPLINE0, CTRL_STEP, CTRL_BSPLINEAMP = 1, 2, 3, 4
 STEPPER = {"IMR": 0, "IMR4": 1, "IMR8": 2, "EE": 3}
 LINSOLVE = {"gmres": 0, "neumann": 1}
 INIT = {"file": 0, "pure": 1, "ensemble": 2, "diagonal": 3, "basis": 4, "3states": 5, "Nplus1": 6, "performance": 7}
@@ -63,6 +63,7 @@ class qd_controls(C.Structure):
         ("pipulse_tstart", c_dp),
         ("pipulse_tstop", c_dp),
         ("pipulse_amp", c_dp),
+        ("seg_param", c_dp),
     ]
 
 
@@ -171,7 +172,7 @@ EXPORTS = [
     "qd_last_error", "qd_version", "qd_device_count", "qd_create", "qd_destroy", "qd_dim", "qd_dim_rho",
     "qd_dim_ess", "qd_ndesign", "qd_set_hamiltonian", "qd_set_params", "qd_eval_controls", "qd_apply_rhs", "qd_get_state",
     "qd_set_target", "qd_set_penalty", "qd_forward", "qd_adjoint", "qd_last_mean_applies",
-    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
+    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_last_team", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
     "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
@@ -223,6 +224,7 @@ def load_library(path=None):
     for f in ("qd_last_mean_applies", "qd_last_forward_ms", "qd_last_adjoint_ms"):
         getattr(lib, f).argtypes = [vp]
         getattr(lib, f).restype = C.c_double
+    lib.qd_last_team.argtypes = [vp]
     lib.qd_measure_fp64_peak.argtypes = [C.c_int, C.POINTER(C.c_double)]
     lib.qd_optim_create.argtypes = [vp, C.POINTER(qd_objective), C.c_int, C.c_int, C.POINTER(vp)]
     lib.qd_optim_destroy.argtypes = [vp]
@@ -400,6 +402,11 @@ class Handle:
     @property
     def mean_applies(self):
         return self.lib.qd_last_mean_applies(self._h)
+
+    @property
+    def last_team(self):
+        """Workgroups per initial condition in the last sweep (1 unless a large state with few initial conditions ran as a team)."""
+        return self.lib.qd_last_team(self._h)
 
     @property
     def forward_ms(self):

@@ -285,7 +285,7 @@ def build_spec(cfg, cfg_dir="."):
         seed = int.from_bytes(os.urandom(4), "little") & 0x7FFFFFFF
     default_seg = "spline, 10, 0.0, " + f"{total_time:f}"
     default_init = "constant, 0.0"
-    seg_osc, seg_type, seg_ns, seg_t0, seg_t1, ncar, cars = [], [], [], [], [], [], []
+    seg_osc, seg_type, seg_ns, seg_t0, seg_t1, ncar, cars, seg_par = [], [], [], [], [], [], [], []
     params, bounds = [], []
     for i in range(Q):
         carrier = _vec_double(cfg, f"carrier_frequency{i}", 0.0)
@@ -295,6 +295,7 @@ def build_spec(cfg, cfg_dir="."):
         ncar.append(len(carrier))
         cars += carrier
         my = []  # (type, nsplines, t0, t1, skip)
+        seg_par_my = []
         idx, skip = 0, 0
         while idx < len(segs):
             tok = segs[idx]  # exact compare, as std::string::compare in the reference
@@ -311,9 +312,37 @@ def build_spec(cfg, cfg_dir="."):
                     t1_ = _atof(segs[idx + 1])
                     idx += 2
                 my.append((typ, ns, t0, t1_, skip))
+                seg_par_my.append((0.0, 0.0, 0.0))
                 skip += 2 * ns * len(carrier)
-            elif tok in ("step", "spline_amplitude"):
-                raise NotImplementedError(f"control type '{tok}' carries no gradient in the reference and is not built here")
+            elif tok == "step":  # step, amp1, amp2, tramp [, tstart, tstop]: oscillator.cpp:50-70
+                idx += 1
+                if len(segs) <= idx + 2:
+                    raise ValueError("control segment: step amplitudes or tramp not found")
+                a1, a2, tramp = _atof(segs[idx]), _atof(segs[idx + 1]), _atof(segs[idx + 2])
+                idx += 3
+                t0, t1_ = 0.0, total_time
+                if len(segs) >= idx + 2:
+                    t0 = _atof(segs[idx])
+                    t1_ = _atof(segs[idx + 1])
+                    idx += 2
+                my.append((capi.CTRL_STEP, 1, t0, t1_, skip))
+                seg_par_my.append((a1, a2, tramp))
+                skip += 1 * len(carrier)
+            elif tok == "spline_amplitude":  # spline_amplitude, nsplines, scaling [, tstart, tstop]: oscillator.cpp:109-127
+                idx += 1
+                if idx >= len(segs):
+                    raise ValueError("control segment: number of splines not found")
+                ns = _atoi(segs[idx])
+                scaling = _atof(segs[idx + 1])
+                idx += 2
+                t0, t1_ = 0.0, total_time
+                if len(segs) >= idx + 2:
+                    t0 = _atof(segs[idx])
+                    t1_ = _atof(segs[idx + 1])
+                    idx += 2
+                my.append((capi.CTRL_BSPLINEAMP, ns, t0, t1_, skip))
+                seg_par_my.append((scaling, 0.0, 0.0))
+                skip += (ns + 1) * len(carrier)
             else:
                 idx += 1
         # parameter initialisation, oscillator.cpp:134-205
@@ -321,18 +350,31 @@ def build_spec(cfg, cfg_dir="."):
         idini = 0
         inits = list(inits)
         rng = MT19937(seed)  # the engine is passed BY VALUE: every oscillator restarts the stream
+        def npc_of(typ, ns):  # parameters per carrier wave: ControlBasis::nparams
+            return 1 if typ == capi.CTRL_STEP else ns + 1 if typ == capi.CTRL_BSPLINEAMP else 2 * ns
+
         for (typ, ns, t0, t1_, skp) in my:
             if len(inits) < idini + 2:
-                inits += ["constant", "0.0"]
+                inits += ["constant", "1.0" if typ == capi.CTRL_STEP else "0.0"]
             initval = _atof(inits[idini + 1]) * 2.0 * math.pi
             kind = inits[idini].strip()
-            npar = 2 * ns
+            npar = npc_of(typ, ns)
+            phase = _atof(inits[idini + 2]) if len(inits) > idini + 2 else 0.0  # spline_amplitude only, oscillator.cpp:159-162
             if kind == "constant":
-                p += [initval] * (npar * len(carrier))
+                if typ == capi.CTRL_STEP:
+                    initval = min(1.0, max(0.0, initval))
+                for _f in range(len(carrier)):
+                    p += [initval] * npar
+                    if typ == capi.CTRL_BSPLINEAMP:
+                        p[-1] = phase
             elif kind == "random":
                 for _f in range(len(carrier)):
                     for _i in range(npar):
-                        p.append(2 * (initval * rng.uniform01()) - initval)
+                        val = initval * rng.uniform01()
+                        val = min(1.0, max(0.0, val)) if typ == capi.CTRL_STEP else 2 * val - initval
+                        p.append(val)
+                    if typ == capi.CTRL_BSPLINEAMP:
+                        p[-1] = phase
             else:
                 p += [0.0] * (npar * len(carrier))
             idini += 2
@@ -345,7 +387,11 @@ def build_spec(cfg, cfg_dir="."):
                             if l <= 1 or l >= ns - 2:
                                 p[skp + f * ns * 2 + l] = 0.0
                                 p[skp + f * ns * 2 + l + ns] = 0.0
-                    else:
+                    elif typ == capi.CTRL_BSPLINEAMP:  # controlbasis.cpp:118-125
+                        for l in range(ns):
+                            if l <= 1 or l >= ns - 2:
+                                p[skp + f * (ns + 1) + l] = 0.0
+                    elif typ == capi.CTRL_BSPLINE0:
                         p[skp + 2 * f * ns] = 0.0
                         p[skp + 2 * f * ns + ns - 1] = 0.0
                         p[skp + (2 * f + 1) * ns] = 0.0
@@ -355,7 +401,15 @@ def build_spec(cfg, cfg_dir="."):
         for iseg, (typ, ns, t0, t1_, skp) in enumerate(my):
             bv = _atof(bnd[iseg] if iseg < len(bnd) else bnd[-1])
             bv = bv / (math.sqrt(2) * len(carrier)) * 2.0 * math.pi
-            bounds += [bv] * (2 * ns * len(carrier))
+            nsp = npc_of(typ, ns) * len(carrier)
+            bseg = [bv] * nsp
+            if my[0][0] == capi.CTRL_BSPLINEAMP:  # no bound on the phase, optimproblem.cpp:152-159 (first segment decides)
+                for f in range(len(carrier)):
+                    j = f * (my[0][1] + 1) + my[0][1]
+                    if j < nsp:
+                        bseg[j] = 1e10
+            bounds += bseg
+            seg_par += list(seg_par_my[iseg])
             seg_osc.append(i)
             seg_type.append(typ)
             seg_ns.append(ns)
@@ -398,6 +452,7 @@ def build_spec(cfg, cfg_dir="."):
     c.pipulse_tstart = capi.dptr(sp._buf("pi_t0", pi_t0, np.float64))
     c.pipulse_tstop = capi.dptr(sp._buf("pi_t1", pi_t1, np.float64))
     c.pipulse_amp = capi.dptr(sp._buf("pi_amp", pi_amp, np.float64))
+    c.seg_param = capi.dptr(sp._buf("seg_par", seg_par, np.float64))
 
     # ---- objective: main.cpp:89-128, optimproblem.cpp:61-131, optimtarget.cpp:22-316
     o = sp.objective

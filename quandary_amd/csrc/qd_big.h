@@ -1,11 +1,21 @@
 // qd_big.h — sweeps for states that do not fit one CU's LDS (dim > 4096): the reference's matrix-free templates go up to
 // <20,20> (Lindblad dim 160 000), <4,4,4,4> (65 536) and <3,3,3,3,3> (59 049) (src/mastereq.cpp:3046-3047, :3150-3151, :3202).
-// One workgroup (1024 threads) still owns one initial condition for the whole time loop, but the vectors of the step
+// A team of G workgroups (1024 threads each; G = 1 when the batch alone fills the chip) owns one initial condition for the whole
+// time loop; the vectors of the step
 // (state, right-hand side, solver iterates, adjoint state, ...) live in a per-state work area in global memory and
 // are exchanged through L2 (4 MiB per XCD; workgroup-scope visibility through the fences of __syncthreads()).  Each
 // thread loops over its elements; the per-element invariants (digits, Delta, d) come from a table built once per
 // system (k_big_table) instead of registers.  The stencil itself is GenStencil::apply / ::ladder of qd_device.h with the
 // element's invariants loaded into the (one-slot) stencil object - the same code that the LDS kernels run.
+//
+// Teams (G > 1, few initial conditions of a large system - e.g. one pure state of <20,20>): the elements are dealt out over
+// G x 1024 threads, every workgroup barrier of the sweep becomes a team barrier (a monotone counter in global memory,
+// agent-scope release / acquire: L2 write-back and invalidate, so the exchange is correct across XCDs) and every reduction
+// goes through per-workgroup partial sums that all members add up in the same order (bit-identical scalars in all members:
+// the solver's control flow stays uniform over the team).  By default the members of a team sit on ONE XCD (blockIdx -> XCD
+// round robin: member j of team t is block 8 (G (t / 8) + j) + t % 8), so the vectors are exchanged through that XCD's L2;
+// S.team_spread deals the members over all XCDs instead.  The kernel is launched cooperatively (co-residency is checked by the
+// runtime: a team that cannot be resident is an error, never a hang).
 #pragma once
 #include <type_traits>
 
@@ -61,14 +71,39 @@ struct BigTeam {
   int dim, redslot;
   const double2* coef;
   const uint2* dig;
+  // team of G workgroups on one initial condition: element loops run e = gtid, gtid + gnt, ...
+  int G, member, ic, gtid, gnt, gslot;
+  unsigned long long* bar;
+  unsigned long long bar_target;
+  double* gred;
 
   static size_t lds_bytes(const DevSys& S) {
     return sizeof(double) * 2 * (size_t)table_len(S) + sizeof(double) * 2 * NRED * (BIG_BLOCK / 64) + sizeof(double) * gmres_nsc(GMRES_MR_G);
   }
 
-  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
+  // false: this workgroup belongs to no team (padding of the XCD-aware grid) and must leave the kernel
+  __device__ __forceinline__ bool init(const DevSys& S, unsigned char* smem, int nb) {
     dim = S.dim;
     redslot = 0;
+    G = S.team > 1 ? S.team : 1;
+    if (G == 1) {
+      ic = blockIdx.x;
+      member = 0;
+    } else if (S.team_spread) {
+      ic = blockIdx.x / G;
+      member = blockIdx.x % G;
+    } else {
+      const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+      ic = (r / G) * 8 + xcd;
+      member = r % G;
+    }
+    if (ic >= nb) return false;
+    gtid = member * blockDim.x + threadIdx.x;
+    gnt = G * blockDim.x;
+    gslot = 0;
+    bar = S.tbar + (size_t)ic * BIG_BAR_STRIDE;
+    bar_target = 0;
+    gred = S.tred + (size_t)ic * 2 * BIG_TEAM_MAX * BIG_RED_NV;
     coef = reinterpret_cast<const double2*>(S.ecoef);
     dig = reinterpret_cast<const uint2*>(S.edig);
     const int tl = table_len(S);
@@ -92,6 +127,25 @@ struct BigTeam {
       }
     st.valid[0] = true;
     __syncthreads();
+    return true;
+  }
+  // Barrier over the team.  G = 1: the workgroup barrier (workgroup-scope fences).  G > 1: every wave releases its stores at
+  // agent scope, one thread per workgroup arrives at the team's counter and waits for the G arrivals of this round (acquire:
+  // L1 / L2 invalidate for the whole CU), the workgroup barrier hands the result to the other waves.
+  __device__ __forceinline__ void tsync() {
+    if (G == 1) {
+      __syncthreads();
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    bar_target += (unsigned long long)G;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < bar_target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   // make element e the stencil's slot
   __device__ __forceinline__ void at(int e) {
@@ -110,10 +164,34 @@ struct BigTeam {
   }
   template <int NV>
   __device__ __forceinline__ void sum(double (&v)[NV]) {
+    static_assert(NV <= BIG_RED_NV, "team reduction buffer too small");
     block_sum<NV, false>(v, L.red + redslot * NRED * (BIG_BLOCK / 64));
     redslot ^= 1;
+    if (G > 1) {  // partial sums of the members, added up by everybody in member order (two buffers: see tsync's ordering)
+      double* slot = gred + (size_t)gslot * BIG_TEAM_MAX * BIG_RED_NV;
+      gslot ^= 1;
+      if (threadIdx.x < NV) {
+        double mine = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+          if ((int)threadIdx.x == i) mine = v[i];
+        slot[member * BIG_RED_NV + threadIdx.x] = mine;
+      }
+      tsync();
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        double t = 0.0;
+        for (int m = 0; m < G; m++) t += __builtin_nontemporal_load(slot + m * BIG_RED_NV + i);
+        v[i] = t;
+      }
+    }
   }
   __device__ __forceinline__ float sum_f32(float v) {
+    if (G > 1) {
+      double t[1] = {(double)v};
+      sum<1>(t);
+      return (float)t[0];
+    }
     double* red = L.red + redslot * NRED * (BIG_BLOCK / 64);
     redslot ^= 1;
     return block_sum_f32<false>(v, red);
@@ -124,8 +202,8 @@ struct BigTeam {
   template <bool TRANS>
   __device__ __forceinline__ double2* neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
                                               double2* Yb, int* iters) {
-    for (int e = threadIdx.x; e < dim; e += blockDim.x) Ya[e] = Bv[e];
-    __syncthreads();
+    for (int e = gtid; e < dim; e += gnt) Ya[e] = Bv[e];
+    tsync();
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
     const float rel2 = (float)(A.reltol * A.reltol);
     float d0 = 1.f;
@@ -133,7 +211,7 @@ struct BigTeam {
     double2 *cur = Ya, *nxt = Yb;
     for (iter = 0; iter < A.maxiter; iter++) {
       double dl = 0.0;
-      for (int e = threadIdx.x; e < dim; e += blockDim.x) {
+      for (int e = gtid; e < dim; e += gnt) {
         const double2 t = apply<TRANS>(A.S, c, cur, e);
         const double2 bj = Bv[e], yo = cur[e];
         double2 w;
@@ -143,7 +221,7 @@ struct BigTeam {
         dl += dx * dx + dy * dy;
         nxt[e] = w;
       }
-      const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier (and its workgroup-scope fences)
+      const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the (team) barrier and its fences
       double2* t2 = cur;
       cur = nxt;
       nxt = t2;
@@ -163,8 +241,8 @@ struct BigTeam {
   __device__ __forceinline__ double2* gmres(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ysol,
                                             double2* Wv, int* iters) {
     constexpr int MR = GMRES_MR_G;
-    const int nt = blockDim.x, tid = threadIdx.x;
-    double2* Vg = reinterpret_cast<double2*>(A.kry) + (size_t)blockIdx.x * (MR + 2) * dim;
+    const int nt = gnt, tid = gtid;
+    double2* Vg = reinterpret_cast<double2*>(A.kry) + (size_t)ic * (MR + 2) * dim;
     double* hc = L.ksc;
     double* cs = hc + (MR + 2);
     double* sn = cs + MR;
@@ -191,7 +269,7 @@ struct BigTeam {
         const double2 v = r[e];
         Vg[e] = make_double2(v.x * ibeta, v.y * ibeta);
       }
-      __syncthreads();
+      tsync();
       double gcur = beta;
       int jj = 0;
       bool conv = false;
@@ -253,7 +331,7 @@ struct BigTeam {
         gcur = -sj * gcur;
         its++;
         jj++;
-        __syncthreads();  // v_{jj} complete (next application reads neighbours), scalars ordered
+        tsync();  // v_{jj} complete (next application reads neighbours), scalars ordered
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter) break;
       }
@@ -272,7 +350,7 @@ struct BigTeam {
         }
         Ysol[e] = y;
       }
-      __syncthreads();
+      tsync();
       if (conv || its >= A.maxiter) break;
       for (int e = tid; e < dim; e += nt) {  // restart: r = b - (I - alpha M) y
         const double2 t = apply<TRANS>(A.S, c, Ysol, e);
@@ -280,7 +358,7 @@ struct BigTeam {
         Wv[e] = make_double2(b.x - (y.x - alpha * t.x), b.y - (y.y - alpha * t.y));
       }
       napp++;
-      __syncthreads();
+      tsync();
     }
     *iters = napp;
     return Ysol;
@@ -300,8 +378,8 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   typedef BigTeam<Q, LIND, DENSE> TM;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem);
-  const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+  if (!tm.init(S, smem, A.nb)) return;
+  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
   double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
   double2 *X = W, *B = W + dim, *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *XM1 = W + 4 * (size_t)dim, *XM2 = W + 5 * (size_t)dim;
   const bool pen_on = A.gamma_penalty > 1e-13;
@@ -317,7 +395,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       if (dpdm_on) XM1[e] = XM2[e] = v;
     }
   }
-  __syncthreads();
+  tm.tsync();
   double pen_local = 0.0, dpdm_local = 0.0, pen_uniform = 0.0;
   unsigned long long napply = 0;
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
@@ -336,7 +414,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
     }
     for (int e = tid; e < dim; e += nt) B[e] = tm.template apply<false>(S, c, X, e);  // rhs = M x
     napply++;
-    __syncthreads();
+    tm.tsync();
     if (A.stepper_ee) {
       for (int e = tid; e < dim; e += nt) {
         const double2 r = B[e];
@@ -357,7 +435,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
         X[e] = v;
       }
     }
-    __syncthreads();
+    tm.tsync();
     // in-loop penalties at the end of a FULL time step (timestepper.cpp:141-154)
     if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
       const int n = (s + 1) / A.nstages - 1;
@@ -433,8 +511,8 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   typedef BigTeam<Q, LIND, DENSE> TM;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem);
-  const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+  if (!tm.init(S, smem, A.nb)) return;
+  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
   double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
   double2 *X = W, *B = W + dim, *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *Z = W + 6 * (size_t)dim, *KB = W + 7 * (size_t)dim,
           *XB = W + 8 * (size_t)dim;
@@ -455,7 +533,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   const bool jpairs = S.npairs > 0;
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
   const int ntime = A.ntime;
-  __syncthreads();
+  tm.tsync();
   for (int s = A.nsub - 1; s >= 0; s--) {
     // ---- penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227)
     if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
@@ -507,13 +585,13 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     scalarize<Q>(c, jpairs);
     c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     for (int e = tid; e < dim; e += nt) X[e] = state(s, e);
-    __syncthreads();
+    tm.tsync();
     double cf[2 * Q];
 #pragma unroll
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694)
     for (int e = tid; e < dim; e += nt) B[e] = tm.template apply<false>(S, c, X, e);
-    __syncthreads();
+    tm.tsync();
     int its;
     {
       const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
@@ -522,7 +600,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
         Z[e] = make_double2(fma(0.5 * c.h, k.x, x.x), fma(0.5 * c.h, k.y, x.y));
       }
     }
-    __syncthreads();
+    tm.tsync();
     {
       const double2* K = tm.template solve<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
       for (int e = tid; e < dim; e += nt) {
@@ -530,7 +608,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
         KB[e] = make_double2(c.h * k.x, c.h * k.y);
       }
     }
-    __syncthreads();
+    tm.tsync();
     for (int e = tid; e < dim; e += nt) {  // gradient coefficients (mastereq.hpp:553-604) and xbar += M^T kbar
       tm.at(e);
       const double2 kb = KB[e];
@@ -554,7 +632,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
       for (int i = 0; i < 2 * Q; i++)
         if (tid == i) co[i] = cf[i];
     }
-    __syncthreads();
+    tm.tsync();
   }
   if (A.xbar0) {
     double* d0 = A.xbar0 + (size_t)ic * 2 * dim;
@@ -568,15 +646,15 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
 
 template <int Q, bool LIND, bool DENSE = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_apply_big(const DevSys S, const double* __restrict__ ctlrow, int transpose,
-                                                         const double* __restrict__ xin, double* __restrict__ yout) {
+                                                         const double* __restrict__ xin, double* __restrict__ yout, int nb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BigTeam<Q, LIND, DENSE> tm;
-  tm.init(S, smem);
-  const int dim = S.dim, ic = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+  if (!tm.init(S, smem, nb)) return;
+  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
   double2* X = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
   const double* x0 = xin + (size_t)ic * 2 * dim;
   for (int e = tid; e < dim; e += nt) X[e] = make_double2(x0[e], x0[dim + e]);
-  __syncthreads();
+  tm.tsync();
   StepC<Q> c;
   load_step<Q>(ctlrow, c, S.npairs > 0);
   scalarize<Q>(c, S.npairs > 0);

@@ -63,7 +63,7 @@ static int upload(T** dst, const std::vector<T>& v) {
 extern "C" void qd_destroy(qd_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  for (DBuf* b : {&h->d_params, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
+  for (DBuf* b : {&h->d_params, &h->d_tbar, &h->d_tred, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_res,
                   &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_ecoef, &h->d_edig, &h->d_work, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
     b->release();
@@ -190,11 +190,31 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
         if (sg.nsplines < 2) { delete h; return fail(QD_ERR_INVALID, "qd_create: spline0 segment needs >= 2 splines"); }
         sg.dtknot = (sg.tstop - sg.tstart) / (sg.nsplines - 1.0);
         sg.width = sg.dtknot;
+      } else if (sg.type == QD_CTRL_STEP) {  // Step ctor, controlbasis.cpp:186-191: one parameter, index skip + 2*carrier (:197)
+        if (!ctl->seg_param) { delete h; return fail(QD_ERR_INVALID, "qd_create: step segment without seg_param"); }
+        if (o.ncar != 1) {
+          delete h;
+          return fail(QD_ERR_UNSUPPORTED, "qd_create: step segment with more than one carrier wave (the reference indexes past the segment's parameter)");
+        }
+        sg.nsplines = 1;
+        sg.npc = 1;
+        sg.a1 = ctl->seg_param[3 * g];
+        sg.a2 = ctl->seg_param[3 * g + 1];
+        sg.a3 = ctl->seg_param[3 * g + 2];
+      } else if (sg.type == QD_CTRL_BSPLINEAMP) {  // BSpline2ndAmplitude ctor, controlbasis.cpp:99-112
+        if (!ctl->seg_param) { delete h; return fail(QD_ERR_INVALID, "qd_create: spline_amplitude segment without seg_param"); }
+        if (sg.nsplines < 3) { delete h; return fail(QD_ERR_INVALID, "qd_create: spline_amplitude segment needs >= 3 splines"); }
+        sg.dtknot = (sg.tstop - sg.tstart) / (double)(sg.nsplines - 2);
+        sg.width = 3.0 * sg.dtknot;
+        sg.npc = sg.nsplines + 1;
+        sg.a1 = ctl->seg_param[3 * g];
+        h->has_ampbasis = true;
       } else {
         delete h;
-        return fail(QD_ERR_UNSUPPORTED, "qd_create: control segment type without a gradient in the reference (step / spline_amplitude)");
+        return fail(QD_ERR_INVALID, "qd_create: unknown control segment type");
       }
-      skip += 2 * sg.nsplines * o.ncar;
+      if (sg.type == QD_CTRL_BSPLINE || sg.type == QD_CTRL_BSPLINE0) sg.npc = 2 * sg.nsplines;
+      skip += sg.npc * o.ncar;
       h->segs.push_back(sg);
       o.nseg++;
     }
@@ -448,6 +468,10 @@ int qd_handle::ensure_big(int nb) {
   }
   if ((r = d_work.ensure(big_work_doubles(S, nb)))) return r;
   S.work = d_work.p;
+  // teams of workgroups: barrier counters and partial-sum buffers (sized for the largest team; zeroed at every launch)
+  if ((r = d_tbar.ensure((size_t)nb * BIG_BAR_STRIDE)) || (r = d_tred.ensure((size_t)nb * 2 * BIG_TEAM_MAX * BIG_RED_NV))) return r;
+  S.tbar = reinterpret_cast<unsigned long long*>(d_tbar.p);
+  S.tred = d_tred.p;
   return QD_OK;
 }
 
@@ -565,9 +589,17 @@ int qd_handle::gmres_poly_degree() const {
       double a = 0.0;
       for (int f = 0; f < o.ncar; f++) {
         double m1 = 0.0, m2 = 0.0;
-        for (int l = 0; l < g.nsplines; l++) {
-          m1 = std::max(m1, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + l]));
-          m2 = std::max(m2, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + g.nsplines + l]));
+        if (g.type == QD_CTRL_STEP) {
+          m1 = fabs(g.a1);
+          m2 = fabs(g.a2);
+        } else if (g.type == QD_CTRL_BSPLINEAMP) {
+          for (int l = 0; l < g.nsplines; l++) m1 = std::max(m1, fabs(params[o.offset + g.skip + f * g.npc + l]));
+          m2 = m1;
+        } else {
+          for (int l = 0; l < g.nsplines; l++) {
+            m1 = std::max(m1, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + l]));
+            m2 = std::max(m2, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + g.nsplines + l]));
+          }
         }
         a += m1 + m2;
       }
@@ -651,6 +683,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   a.dpdm_out = d_dpdm;
   a.napply = d_napply;
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+  last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
   if (cfg.gmres == 2) {
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
@@ -782,6 +815,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   QD_HIP(hipSetDevice(device));
   if (!(traj_valid || pending_store) || last_nb != nb) return fail(QD_ERR_STATE, "qd_adjoint: needs a forward sweep of the same batch with store_trajectory=1");
   if (has_pipulse) return fail(QD_ERR_UNSUPPORTED, "qd_adjoint: derivative of pi-pulses is not implemented in the reference (src/oscillator.cpp:373-378)");
+  if (has_ampbasis) return fail(QD_ERR_UNSUPPORTED, "qd_adjoint: the spline_amplitude parameterisation has no gradient in the reference (src/oscillator.cpp:350-356)");
   int r;
   const size_t ncol = (size_t)nsub * 2 * S.Q;
   if ((r = d_coeff.ensure((size_t)nb * ncol)) || (r = d_coeffsum.ensure(ncol))) return r;
@@ -798,6 +832,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   a.jbar = djbar;
   a.coeff = d_coeff.p;
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
+  last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
   if (cfg.gmres == 2) {
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
@@ -829,7 +864,7 @@ int qd_handle::gradient_launch(double ebar, double* dgrad) {
   QD_HIP(hipSetDevice(device));
   if (ndesign == 0) return QD_OK;
   const int nsub_flag = sol.stepper == QD_STEPPER_EE ? -nsub : nsub;
-  QD_HIP(launch_grad(dctl, d_table.p, cs, nsub_flag, d_coeffsum.p, d_etable.p, tg.ntime, ebar, dgrad, ndesign, stream));
+  QD_HIP(launch_grad(dctl, d_params.p, d_table.p, cs, nsub_flag, d_coeffsum.p, d_etable.p, tg.ntime, ebar, dgrad, ndesign, stream));
   return QD_OK;
 }
 
@@ -862,6 +897,7 @@ extern "C" int qd_adjoint(qd_handle* h, const double* xbarT, const double* jbar,
 extern "C" double qd_last_mean_applies(const qd_handle* h) { return h ? h->last_mean_applies : 0.0; }
 extern "C" double qd_last_forward_ms(const qd_handle* h) { return h ? h->last_fwd_ms : 0.0; }
 extern "C" double qd_last_adjoint_ms(const qd_handle* h) { return h ? h->last_adj_ms : 0.0; }
+extern "C" int qd_last_team(const qd_handle* h) { return h ? h->last_team : QD_ERR_INVALID; }
 
 // Measurement hook ("settle the MFMA question"): nrep chained applications of the forward operator
 // to nb copies... of a batch of states with the fp32 stencil kernel (mfma = 0) or with the dense Kronecker-factor

@@ -85,9 +85,12 @@ struct qd_handle {
   qd::DevOsc* d_oscs = nullptr;
   double *d_carriers = nullptr, *d_pulses = nullptr;
   int ndesign = 0, dim_ess = 1;
+  int last_team = 1;  // workgroups per initial condition of the last sweep (qd_big.h)
   bool has_pipulse = false;
+  bool has_ampbasis = false;  // a spline_amplitude segment: forward only (src/oscillator.cpp:350-356)
   std::vector<double> params;
   qd::DBuf d_params;
+  qd::DBuf d_tbar, d_tred;  // team barrier counters / partial sums of the global-memory sweeps (qd_big.h)
   bool params_dirty = true;
   bool napply_zeroed = false;  // the control kernel of this parameter update has already reset d_napply
   // step schedule

@@ -48,12 +48,26 @@ static hipError_t set_lds(K kern, size_t bytes) {
   return hipSuccess;
 }
 
+// Sweeps of the global-memory kernels (qd_big.h).  One workgroup per initial condition: a plain launch.  Teams: the grid is
+// padded to whole rounds of the 8 XCDs (the members of a team share an XCD), the team barriers spin, so the launch is cooperative -
+// the runtime refuses a grid that cannot be resident instead of letting it hang.
+[[maybe_unused]] static hipError_t launch_big(const void* kern, const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
+  SweepArgs b = a;
+  b.S.team = cfg.team > 1 ? cfg.team : 1;
+  b.S.team_spread = cfg.spread;
+  void* args[] = {&b};
+  if (b.S.team == 1) return hipLaunchKernel(kern, dim3(a.nb), dim3(cfg.block), args, cfg.lds, st);
+  hipError_t e = hipMemsetAsync(b.S.tbar, 0, sizeof(unsigned long long) * BIG_BAR_STRIDE * (size_t)a.nb, st);
+  if (e != hipSuccess) return e;
+  const int teams = cfg.spread ? a.nb : (a.nb + 7) / 8 * 8;
+  return hipLaunchCooperativeKernel(kern, dim3(teams * b.S.team), dim3(cfg.block), args, (unsigned)cfg.lds, st);
+}
+
 #if QD_PART == 0 || QD_PART == 2
 template <int VAR>
 static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
-    hipLaunchKernelGGL((k_forward_big<QD_Q, kLind, kDense>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
-    return hipGetLastError();
+    return launch_big(reinterpret_cast<const void*>(k_forward_big<QD_Q, kLind, kDense>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);
@@ -70,7 +84,9 @@ template <int VAR>
 static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb,
                            const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>()) {
-    hipLaunchKernelGGL((k_apply_big<QD_Q, kLind, kDense>), dim3(nb), dim3(cfg.block), cfg.lds, st, S, ctlrow, transpose, x, y);
+    DevSys S1 = S;  // one operator application: no exchange between workgroups after the load, no team needed
+    S1.team = 1;
+    hipLaunchKernelGGL((k_apply_big<QD_Q, kLind, kDense>), dim3(nb), dim3(cfg.block), cfg.lds, st, S1, ctlrow, transpose, x, y, nb);
     return hipGetLastError();
   } else if constexpr (variant_built<VAR>()) {
     auto kf = k_apply<QD_Q, kLind, VAR, kQubit>;
@@ -88,8 +104,7 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
-    hipLaunchKernelGGL((k_adjoint_big<QD_Q, kLind, kDense>), dim3(a.nb), dim3(cfg.block), cfg.lds, st, a);
-    return hipGetLastError();
+    return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);

@@ -32,12 +32,18 @@ struct DevSys {
   const double* ecoef;   // [dim] (Delta, d)
   const unsigned* edig;  // [dim] (packed bra digits, packed ket digits)
   double* work;          // [nb][BIG_NV][dim] interleaved complex
+  // teams of workgroups on one large state (qd_big.h): workgroups per initial condition, members dealt over all XCDs (1) or kept
+  // on one (0), barrier counters [nb][BIG_BAR_STRIDE], partial sums [nb][2][BIG_TEAM_MAX][BIG_RED_NV]
+  int team, team_spread;
+  unsigned long long* tbar;
+  double* tred;
 };
 
 // Control parameterisation on the device (src/oscillator.cpp:45-132, src/controlbasis.cpp:20-32,219-225)
 struct DevSeg {
-  int type, nsplines, skip, pad;
+  int type, nsplines, skip, npc;  // npc = parameters per carrier wave
   double tstart, tstop, dtknot, width;
+  double a1, a2, a3;              // step: amp1, amp2, tramp; spline_amplitude: scaling
 };
 struct DevOsc {
   int seg_begin, nseg, car_begin, ncar, offset, nparams, pulse_begin, npulse;
@@ -92,11 +98,18 @@ struct SweepArgs {
                         // parked in L2/HBM while a linear solve runs, instead of compiler-chosen scratch spills)
 };
 
+// teams of workgroups in the global-memory sweeps (qd_big.h)
+constexpr int BIG_TEAM_MAX = 256;   // workgroups per initial condition
+constexpr int BIG_RED_NV = 16;      // doubles per member in the team reduction buffer
+constexpr int BIG_BAR_STRIDE = 16;  // 128 B between the barrier counters of two teams
+
 struct LaunchCfg {
   int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)
   int qubit;  // stencil family: 0 general (runtime level counts), 1 all-qubit bit tricks, 2 dense user Hamiltonians
   int block;  // threads per block (one block per initial condition)
   int gmres;  // 0 Neumann, 1 GMRES with the Krylov basis in LDS, 2 GMRES with the basis in global memory
+  int team;   // workgroups per initial condition (qd_big.h; 1 everywhere else)
+  int spread; // team members dealt over all XCDs instead of one
   size_t lds;
 };
 
@@ -118,7 +131,7 @@ hipError_t launch_partial_sums(const double* res, int nb, const double* w, doubl
                                int cs, int Q, int nstep, double* sums, hipStream_t st);
 hipError_t launch_seed_weights(const double* sums, const double* w, int nb, int objective_type, int lindblad, double* rbib, hipStream_t st);
 hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* sum, int accumulate, hipStream_t st);
-hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum,
+hipError_t launch_grad(const DevCtlDesc& d, const double* params, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
 // fp32-mixed sweeps of all-qubit Lindblad systems (qd_q32.hip); the trajectory is [nsub+1][nb][dim] float2
 hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st);

@@ -33,6 +33,25 @@ __device__ inline double bspline2(const DevSeg& g, int id, double t) {  // contr
   return 9. / 8. - 9. / 2. * tau + 9. / 2. * tau * tau;
 }
 
+// getRampFactor / getRampFactor_diff, src/util.cpp:92-147 (piecewise-linear ramp up / plateau / ramp down; the branch order of
+// the reference decides the value where the pieces meet)
+__device__ inline double ramp_factor(double t, double t0, double t1, double tramp) {
+  double r = 0.0;
+  if (t <= t0 + tramp) r = 1.0 / tramp * t - t0 / tramp;
+  else if (t0 + tramp <= t && t <= t1 - tramp) r = 1.0;
+  else if (t >= t1 - tramp && t <= t1) r = -1.0 / tramp * t + t1 / tramp;
+  if (t1 < t0 + 2 * tramp) r = 0.0;
+  return r;
+}
+__device__ inline double ramp_factor_diff(double t, double t0, double t1, double tramp) {
+  double d = 0.0;
+  if (t <= t0 + tramp) d = 0.0;
+  else if (t0 + tramp <= t && t <= t1 - tramp) d = 0.0;
+  else if (t >= t1 - tramp && t <= t1) d = 1.0 / tramp;
+  if (t1 < t0 + 2 * tramp) d = 0.0;
+  return d;
+}
+
 __device__ inline void eval_control_dev(const DevCtlDesc& d, const double* __restrict__ params, int k, double t, double& p, double& q) {
   const DevOsc o = d.oscs[k];
   p = 0.0;
@@ -45,8 +64,25 @@ __device__ inline void eval_control_dev(const DevCtlDesc& d, const double* __res
         double sp = 0.0, sq = 0.0;
         for (int f = 0; f < o.ncar; f++) {
           double b1 = 0.0, b2 = 0.0;
-          const double* cf = coeff + g.skip + f * g.nsplines * 2;
-          if (g.type == QD_CTRL_BSPLINE) {
+          const double* cf = coeff + g.skip + f * g.npc;
+          const double om = d.carriers[o.car_begin + f];
+          if (g.type == QD_CTRL_STEP) {  // Step::evaluate, controlbasis.cpp:195-206 (index skip + 2*carrier, one carrier)
+            const double tend = g.tstart + coeff[g.skip + 2 * f] * (g.tstop - g.tstart);
+            const double ramp = g.a3 > 1e-13 ? ramp_factor(t, g.tstart, tend, g.a3) : 1.0;
+            b1 = ramp * g.a1;
+            b2 = ramp * g.a2;
+          } else if (g.type == QD_CTRL_BSPLINEAMP) {  // BSpline2ndAmplitude::evaluate :127-141, oscillator.cpp:308-312
+            const int lc = (int)floor((t - g.tstart) / g.dtknot);
+            const int l0 = max(0, lc - 1), l1 = min(g.nsplines - 1, lc + 3);
+            for (int l = l0; l <= l1; l++) {
+              if (d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) continue;
+              b1 += cf[l] * bspline2(g, l, t);
+            }
+            const double ph = g.a1 * cf[g.nsplines];
+            sp += cos(om * t + ph) * b1;
+            sq += sin(om * t + ph) * b1;
+            continue;
+          } else if (g.type == QD_CTRL_BSPLINE) {
             // only the splines whose support can contain t (the reference loops over all of them, the others
             // contribute exact zeros: controlbasis.cpp:48-66, :81-96); one spline of margin on each side
             const int lc = (int)floor((t - g.tstart) / g.dtknot);
@@ -64,7 +100,6 @@ __device__ inline void eval_control_dev(const DevCtlDesc& d, const double* __res
               b2 = cf[id + g.nsplines];
             }
           }
-          const double om = d.carriers[o.car_begin + f];
           const double co = cos(om * t), si = sin(om * t);
           sp += co * b1 - si * b2;
           sq += si * b1 + co * b2;
@@ -162,7 +197,7 @@ __global__ void k_reduce_coeff(const double* __restrict__ coeff, int nb, int nco
 // grad[d] = sum_s B_d(t_s) * {Blt1bar | Blt2bar}(s) + energy-penalty terms
 // (Oscillator::evalControl_diff oscillator.cpp:339-381, BSpline2nd::derivative controlbasis.cpp:68-79,
 //  BSpline0::derivative :245-254, energyPenaltyIntegral_diff timestepper.cpp:458-480)
-__global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* __restrict__ table, int cs, int nsub, int ee,
+__global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* __restrict__ params, const double* __restrict__ table, int cs, int nsub, int ee,
                                              const double* __restrict__ coeffsum, const double* __restrict__ etable, int nstep,
                                              double ebar, double* __restrict__ grad, int ndesign) {
   // one wave per design parameter; lanes stride over the sub-steps, fixed-order wave reduction
@@ -176,15 +211,18 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
   int gs = 0;
   for (int bs = 0; bs < o.nseg; bs++) {
     const DevSeg g = d.segs[o.seg_begin + bs];
-    if (loc >= g.skip && loc < g.skip + 2 * g.nsplines * o.ncar) gs = bs;
+    if (loc >= g.skip && loc < g.skip + g.npc * o.ncar) gs = bs;
   }
   const DevSeg g = d.segs[o.seg_begin + gs];
   const int r = loc - g.skip;
-  const int f = r / (2 * g.nsplines), l = (r % (2 * g.nsplines)) % g.nsplines, part = (r % (2 * g.nsplines)) / g.nsplines;
-  if (g.type == QD_CTRL_BSPLINE && d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) {
-    if (lane == 0) grad[idx] = 0.0;
+  const int f = r / g.npc, l = (r % g.npc) % g.nsplines, part = (r % g.npc) / g.nsplines;
+  if ((g.type == QD_CTRL_BSPLINE && d.enforce_bc && (l <= 1 || l >= g.nsplines - 2)) || g.type == QD_CTRL_BSPLINEAMP) {
+    if (lane == 0) grad[idx] = 0.0;  // (spline_amplitude: no gradient in the reference, rejected before this launch)
     return;
   }
+  const bool step = g.type == QD_CTRL_STEP;
+  // Step::derivative, controlbasis.cpp:208-216: d ramp / d t_stepend * (tstop - tstart), t_stepend = tstart + alpha (tstop - tstart)
+  const double tend = step ? g.tstart + params[o.offset + g.skip + 2 * f] * (g.tstop - g.tstart) : 0.0;
   const double om = d.carriers[o.car_begin + f];
   auto active = [&](double t) {  // this segment is the FIRST one containing t (oscillator.cpp:344-346 + break)
     if (!(g.tstart <= t && g.tstop >= t)) return false;
@@ -195,6 +233,7 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
     return true;
   };
   auto basis = [&](double t) {
+    if (step) return ramp_factor_diff(t, g.tstart, tend, g.a3) * (g.tstop - g.tstart);
     if (g.type == QD_CTRL_BSPLINE) return bspline2(g, l, t);
     const int id = (int)ceil((t - g.tstart) / g.dtknot - 0.5);
     return id == l ? 1.0 : 0.0;
@@ -208,7 +247,8 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
     if (B == 0.0) continue;
     const double pbar = coeffsum[(size_t)s * 2 * d.Q + 2 * k], qbar = coeffsum[(size_t)s * 2 * d.Q + 2 * k + 1];
     const double co = cos(om * t), si = sin(om * t);
-    acc += B * (part == 0 ? si * qbar + co * pbar : co * qbar - si * pbar);
+    const double b1bar = si * qbar + co * pbar, b2bar = co * qbar - si * pbar;
+    acc += B * (step ? g.a1 * b1bar + g.a2 * b2bar : part == 0 ? b1bar : b2bar);
   }
   if (ebar != 0.0) {
     for (int n = lane; n < nstep; n += 64) {
@@ -219,7 +259,8 @@ __global__ void __launch_bounds__(64) k_grad(const DevCtlDesc d, const double* _
       if (B == 0.0) continue;
       const double pbar = ebar / nstep * 2.0 * row[2 + k], qbar = ebar / nstep * 2.0 * row[2 + d.Q + k];
       const double co = cos(om * t), si = sin(om * t);
-      acc += B * (part == 0 ? si * qbar + co * pbar : co * qbar - si * pbar);
+      const double b1bar = si * qbar + co * pbar, b2bar = co * qbar - si * pbar;
+      acc += B * (step ? g.a1 * b1bar + g.a2 * b2bar : part == 0 ? b1bar : b2bar);
     }
   }
   acc = wave_sum(acc);
@@ -391,6 +432,7 @@ static const VarInfo kVar[NVARIANTS] = {var_info<0>(), var_info<1>(), var_info<2
                                         var_info<15>(), var_info<16>()};
 int variant_max_block(int var) { return (var >= 0 && var < NVARIANTS) ? kVar[var].maxb : 0; }
 
+void big_team(const DevSys& S, int nb, int& team, int& spread);
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   LaunchCfg c{};
   const int dim = S.dim;
@@ -438,6 +480,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
     c.block = BIG_BLOCK;
     c.gmres = gm ? 2 : 0;
     c.lds = BigTeam<1, false>::lds_bytes(S);
+    big_team(S, nb, c.team, c.spread);
     return c;
   }
   const int epe = kVar[var].ept / kVar[var].icpb;
@@ -457,6 +500,30 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
     }
   }
   return c;
+}
+
+// Workgroups per initial condition of the global-memory sweeps: as many as keep every team resident (one 1024-thread workgroup
+// per CU is what the register budget of these kernels allows for sure) and leave each thread four elements per pass.  Members of
+// a team on one XCD (32 CUs) by default; QD_BIG_TEAM / QD_BIG_SPREAD override (tests, measurements).
+void big_team(const DevSys& S, int nb, int& team, int& spread) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  const char* es = getenv("QD_BIG_SPREAD");
+  spread = es ? atoi(es) != 0 : 0;
+  const int gmax = spread ? BIG_TEAM_MAX : 32;
+  const int slots = spread ? nb : (nb + 7) / 8 * 8;
+  int g = 1;
+  while (g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)S.dim >= (size_t)4 * BIG_BLOCK * (g * 2)) g *= 2;
+  if (const char* et = getenv("QD_BIG_TEAM")) {
+    const int v = atoi(et);
+    if (v >= 1 && v <= gmax && (v & (v - 1)) == 0 && (long)slots * v <= ncu) g = v;
+  }
+  team = g;
 }
 
 size_t big_work_doubles(const DevSys& S, int nb) { return (size_t)nb * BIG_NV * 2 * (size_t)S.dim; }
@@ -577,12 +644,12 @@ hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* su
   return hipGetLastError();
 }
 
-hipError_t launch_grad(const DevCtlDesc& d, const double* table, int cs, int nsub, const double* coeffsum, const double* etable,
+hipError_t launch_grad(const DevCtlDesc& d, const double* params, const double* table, int cs, int nsub, const double* coeffsum, const double* etable,
                        int nstep, double ebar, double* grad, int ndesign, hipStream_t st) {
   if (ndesign == 0) return hipSuccess;
   const int ee = nsub < 0;  // negative nsub flags the explicit-Euler gradient time (t_stop)
   const int ns = ee ? -nsub : nsub;
-  hipLaunchKernelGGL(k_grad, dim3(ndesign), dim3(64), 0, st, d, table, cs, ns, ee, coeffsum, etable, nstep, ebar, grad,
+  hipLaunchKernelGGL(k_grad, dim3(ndesign), dim3(64), 0, st, d, params, table, cs, ns, ee, coeffsum, etable, nstep, ebar, grad,
                      ndesign);
   return hipGetLastError();
 }

@@ -196,7 +196,7 @@ struct Problem {
   qd_objective obj{};
   // storage behind the pointers
   std::vector<int32_t> seg_osc, seg_type, seg_ns, ncar, pi_osc;
-  std::vector<double> seg_t0, seg_t1, cars, pi_t0, pi_t1, pi_amp, gate_re, gate_im, weights, init_data, target_data;
+  std::vector<double> seg_t0, seg_t1, seg_par, cars, pi_t0, pi_t1, pi_amp, gate_re, gate_im, weights, init_data, target_data;
   std::vector<double> params0, bounds, transfreq;
 };
 
@@ -260,37 +260,73 @@ static void build(Problem& P) {
     strvec bnd = cfg.vstr("control_bounds" + std::to_string(i), "10000.0");
     P.ncar.push_back((int)carrier.size());
     for (double c : carrier) P.cars.push_back(c);
-    struct Seg { int type, ns; double t0, t1; int skip; };
+    struct Seg { int type, ns; double t0, t1; int skip; double par[3]; };
+    auto npc_of = [](const Seg& g) { return g.type == QD_CTRL_STEP ? 1 : g.type == QD_CTRL_BSPLINEAMP ? g.ns + 1 : 2 * g.ns; };
     std::vector<Seg> my;
     size_t idx = 0;
     int skip = 0;
+    auto window = [&](double& t0, double& t1s) {
+      t0 = 0.0; t1s = total_time;
+      if (segs.size() >= idx + 2) { t0 = atof(segs[idx].c_str()); t1s = atof(segs[idx + 1].c_str()); idx += 2; }
+    };
     while (idx < segs.size()) {
       if (segs[idx] == "spline" || segs[idx] == "spline0") {
         const int type = segs[idx] == "spline" ? QD_CTRL_BSPLINE : QD_CTRL_BSPLINE0;
         idx++;
         if (idx >= segs.size()) die("Wrong setting for control segments: Number of splines not found.");
         const int ns = atoi(segs[idx++].c_str());
-        double t0 = 0.0, t1s = total_time;
-        if (segs.size() >= idx + 2) { t0 = atof(segs[idx].c_str()); t1s = atof(segs[idx + 1].c_str()); idx += 2; }
-        my.push_back({type, ns, t0, t1s, skip});
-        skip += 2 * ns * (int)carrier.size();
-      } else if (segs[idx] == "step" || segs[idx] == "spline_amplitude") {
-        die("control type '" + segs[idx] + "' has no gradient in the reference and is not supported by the MI355X path");
-      } else idx++;
+        double t0, t1s;
+        window(t0, t1s);
+        my.push_back({type, ns, t0, t1s, skip, {0.0, 0.0, 0.0}});
+      } else if (segs[idx] == "step") {  // step, amp1, amp2, tramp [, tstart, tstop]: src/oscillator.cpp:50-70
+        idx++;
+        if (segs.size() <= idx + 2) die("Wrong setting for control segments: Step Amplitudes or tramp not found.");
+        const double a1 = atof(segs[idx].c_str()), a2 = atof(segs[idx + 1].c_str()), tramp = atof(segs[idx + 2].c_str());
+        idx += 3;
+        double t0, t1s;
+        window(t0, t1s);
+        my.push_back({QD_CTRL_STEP, 1, t0, t1s, skip, {a1, a2, tramp}});
+      } else if (segs[idx] == "spline_amplitude") {  // spline_amplitude, nsplines, scaling [, tstart, tstop]: :109-127
+        idx++;
+        if (idx + 1 >= segs.size()) die("Wrong setting for control segments: Number of splines not found.");
+        const int ns = atoi(segs[idx].c_str());
+        const double scaling = atof(segs[idx + 1].c_str());
+        idx += 2;
+        double t0, t1s;
+        window(t0, t1s);
+        my.push_back({QD_CTRL_BSPLINEAMP, ns, t0, t1s, skip, {scaling, 0.0, 0.0}});
+      } else {
+        idx++;
+        continue;
+      }
+      skip += npc_of(my.back()) * (int)carrier.size();
     }
     std::vector<double> p;
     std::mt19937 rng;  // passed BY VALUE to every oscillator in the reference: each restarts the stream
     rng.seed(seed);
     size_t idini = 0;
-    for (auto& sg : my) {
-      if (inits.size() < idini + 2) { inits.push_back("constant"); inits.push_back("0.0"); }
-      const double initval = atof(inits[idini + 1].c_str()) * 2.0 * M_PI;
-      const size_t npar = (size_t)2 * sg.ns * carrier.size();
-      if (inits[idini] == "constant") p.insert(p.end(), npar, initval);
-      else if (inits[idini] == "random") {
+    for (auto& sg : my) {  // src/oscillator.cpp:134-196
+      if (inits.size() < idini + 2) { inits.push_back("constant"); inits.push_back(sg.type == QD_CTRL_STEP ? "1.0" : "0.0"); }
+      double initval = atof(inits[idini + 1].c_str()) * 2.0 * M_PI;
+      const int npc = npc_of(sg);
+      const double phase = inits.size() > idini + 2 ? atof(inits[idini + 2].c_str()) : 0.0;  // spline_amplitude only (:159-162)
+      if (inits[idini] == "constant") {
+        if (sg.type == QD_CTRL_STEP) initval = std::min(1.0, std::max(0.0, initval));
+        for (size_t f = 0; f < carrier.size(); f++) {
+          p.insert(p.end(), npc, initval);
+          if (sg.type == QD_CTRL_BSPLINEAMP) p.back() = phase;
+        }
+      } else if (inits[idini] == "random") {
         std::uniform_real_distribution<double> unit(0.0, 1.0);
-        for (size_t k = 0; k < npar; k++) p.push_back(2 * (initval * unit(rng)) - initval);
-      } else p.insert(p.end(), npar, 0.0);
+        for (size_t f = 0; f < carrier.size(); f++) {
+          for (int k = 0; k < npc; k++) {
+            double val = initval * unit(rng);
+            val = sg.type == QD_CTRL_STEP ? std::min(1.0, std::max(0.0, val)) : 2 * val - initval;
+            p.push_back(val);
+          }
+          if (sg.type == QD_CTRL_BSPLINEAMP) p.back() = phase;
+        }
+      } else p.insert(p.end(), (size_t)npc * carrier.size(), 0.0);
       idini += 2;
     }
     if (!p.empty() && bc)
@@ -299,7 +335,10 @@ static void build(Problem& P) {
           if (sg.type == QD_CTRL_BSPLINE) {
             for (int l = 0; l < sg.ns; l++)
               if (l <= 1 || l >= sg.ns - 2) p[sg.skip + f * sg.ns * 2 + l] = p[sg.skip + f * sg.ns * 2 + l + sg.ns] = 0.0;
-          } else {
+          } else if (sg.type == QD_CTRL_BSPLINEAMP) {  // src/controlbasis.cpp:118-125
+            for (int l = 0; l < sg.ns; l++)
+              if (l <= 1 || l >= sg.ns - 2) p[sg.skip + f * (sg.ns + 1) + l] = 0.0;
+          } else if (sg.type == QD_CTRL_BSPLINE0) {
             p[sg.skip + 2 * f * sg.ns] = p[sg.skip + 2 * f * sg.ns + sg.ns - 1] = 0.0;
             p[sg.skip + (2 * f + 1) * sg.ns] = p[sg.skip + (2 * f + 1) * sg.ns + sg.ns - 1] = 0.0;
           }
@@ -308,7 +347,14 @@ static void build(Problem& P) {
     for (size_t iseg = 0; iseg < my.size(); iseg++) {  // bounds, src/optimproblem.cpp:137-163
       double bv = atof((iseg < bnd.size() ? bnd[iseg] : bnd.back()).c_str());
       bv = bv / (sqrt(2.0) * carrier.size()) * 2.0 * M_PI;
-      P.bounds.insert(P.bounds.end(), (size_t)2 * my[iseg].ns * carrier.size(), bv);
+      const size_t nsp = (size_t)npc_of(my[iseg]) * carrier.size(), b0 = P.bounds.size();
+      P.bounds.insert(P.bounds.end(), nsp, bv);
+      if (my[0].type == QD_CTRL_BSPLINEAMP)  // no bound on the phase (the first segment decides, :152-159)
+        for (size_t f = 0; f < carrier.size(); f++) {
+          const size_t j = f * (my[0].ns + 1) + my[0].ns;
+          if (j < nsp) P.bounds[b0 + j] = 1e10;
+        }
+      for (double v : my[iseg].par) P.seg_par.push_back(v);
       P.seg_osc.push_back(i); P.seg_type.push_back(my[iseg].type); P.seg_ns.push_back(my[iseg].ns);
       P.seg_t0.push_back(my[iseg].t0); P.seg_t1.push_back(my[iseg].t1);
     }
@@ -335,6 +381,7 @@ static void build(Problem& P) {
   c.nseg_total = (int)P.seg_osc.size();
   c.seg_osc = P.seg_osc.data(); c.seg_type = P.seg_type.data(); c.seg_nsplines = P.seg_ns.data();
   c.seg_tstart = P.seg_t0.data(); c.seg_tstop = P.seg_t1.data();
+  c.seg_param = P.seg_par.data();
   c.ncarrier = P.ncar.data(); c.carrier_freq = P.cars.data();
   c.npipulse = (int)P.pi_osc.size();
   c.pipulse_osc = P.pi_osc.data(); c.pipulse_tstart = P.pi_t0.data(); c.pipulse_tstop = P.pi_t1.data(); c.pipulse_amp = P.pi_amp.data();

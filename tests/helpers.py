@@ -46,7 +46,7 @@ def golden_rows(case, fname):
 
 def synthetic_cfg(nlevels, lindblad=True, ntime=20, dt=0.01, nspline=10, jkl=0.0, linsolve="neumann", stepper="IMR",
                   init="basis", target="gate", objective="Jtrace", nessential=None, maxiter=20, penalties=False,
-                  detuned=False, gate=None):
+                  detuned=False, gate=None, segments=None, carrier="0.0, -0.2", ctrl_init="random, 0.005", enforce_bc=False):
     """Synthetic systems in the style of SURVEY 8(d) / tests/performance/configs of the reference."""
     Q = len(nlevels)
     lines = [
@@ -59,7 +59,7 @@ def synthetic_cfg(nlevels, lindblad=True, ntime=20, dt=0.01, nspline=10, jkl=0.0
         "collapse_type = " + ("both" if lindblad else "none"),
         "decay_time = " + ",".join(["80.0"] * Q), "dephase_time = " + ",".join(["26.0"] * Q),
         f"initialcondition = {init}",
-        "control_enforceBC = false",
+        "control_enforceBC = " + ("true" if enforce_bc else "false"),
         f"optim_objective = {objective}", "optim_regul = 1e-4",
         f"linearsolver_type = {linsolve}", f"linearsolver_maxiter = {maxiter}", f"timestepper = {stepper}",
         "rand_seed = 1234", "usematfree = true", "runtype = gradient",
@@ -67,8 +67,9 @@ def synthetic_cfg(nlevels, lindblad=True, ntime=20, dt=0.01, nspline=10, jkl=0.0
     if nessential:
         lines.append("nessential = " + ",".join(str(n) for n in nessential))
     for k in range(Q):
-        lines += [f"control_segments{k} = spline, {nspline}", f"control_initialization{k} = random, 0.005",
-                  f"carrier_frequency{k} = 0.0, -0.2"]
+        seg = f"spline, {nspline}" if segments is None else segments if isinstance(segments, str) else segments[k]
+        ini = ctrl_init if isinstance(ctrl_init, str) else ctrl_init[k]
+        lines += [f"control_segments{k} = {seg}", f"control_initialization{k} = {ini}", f"carrier_frequency{k} = {carrier}"]
     if target == "gate":
         dim_ess = int(np.prod(nessential if nessential else nlevels))
         lines.append("optim_target = gate, " + (gate if gate else "cnot" if dim_ess == 4 else ("xgate" if dim_ess == 2 else "qft")))

@@ -767,3 +767,113 @@ def test_device_side_observables(kw):
             np.testing.assert_allclose(obs["population_composite"][o, b], diag, rtol=0, atol=tol)
             assert obs["expected_composite"][o, b] == pytest.approx(float(np.sum(np.arange(N) * diag)), abs=tol * N)
     opt.close(); h.close(); orc.close()
+
+
+CTRL_CASES = [
+    pytest.param(dict(nlevels=[2, 2], lindblad=False, segments=["step, 0.6, 0.2, 0.05", "spline, 6"], carrier="0.0",
+                      ctrl_init=["constant, 0.11", "random, 0.01"]), id="step+spline-schroedinger"),
+    pytest.param(dict(nlevels=[3, 2], lindblad=True, segments=["step, 0.5, -0.3, 0.04", "step, 0.2, 0.4, 0.08, 0.05, 0.35"], carrier="-0.1",
+                      ctrl_init="constant, 0.12", target="pure", objective="Jmeasure"), id="step-step-lindblad"),
+    pytest.param(dict(nlevels=[2, 3], lindblad=False, segments="spline, 6, 0.0, 0.2, step, 0.4, 0.1, 0.03, 0.2, 0.4", carrier="0.05",
+                      ctrl_init="random, 0.01, constant, 0.1", target="pure", objective="Jfrobenius"), id="spline-then-step-segments"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=True, segments="spline0, 5, 0.0, 0.25, step, 0.4, 0.1, 0.02, 0.25, 0.4", carrier="0.0",
+                      ctrl_init="random, 0.01, constant, 0.1"), id="spline0-then-step-lindblad"),
+]
+
+
+@pytest.mark.parametrize("kw", CTRL_CASES)
+@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
+def test_step_control_basis_vs_oracle(kw, linsolve):
+    """Step parameterisation (src/controlbasis.cpp:186-216): controls, objective and the gradient with respect to the step width."""
+    sp, h, orc = _pair(kw, ntime=40, penalties=True, linsolve=linsolve)
+    a = sp.params0.copy()
+    h.set_params(a)
+    orc.set_params(a)
+    times = np.linspace(0.0, sp.time.ntime * sp.time.dt, 83)
+    np.testing.assert_allclose(h.eval_controls(times), orc.eval_controls(times), rtol=1e-13, atol=1e-16)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(a)
+    oval, og = orc.evalGradF(a)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(og) > 0 and np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    widths = [i for i in range(sp.ndesign) if a[i] > 0.5]  # the step widths (constant, 0.1x: 2 pi x 0.1x; the splines are ~0.06)
+    assert widths and all(abs(og[i]) > 1e-6 and g[i] == pytest.approx(og[i], rel=1e-7) for i in widths)
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("lindblad", [False, True])
+def test_spline_amplitude_control_basis_forward_only(lindblad):
+    """Amplitude/phase splines (src/controlbasis.cpp:99-141, src/oscillator.cpp:308-312): forward parity; the gradient is refused as in the
+    reference (src/oscillator.cpp:350-356)."""
+    sp, h, orc = _pair(dict(nlevels=[2, 3], lindblad=lindblad, segments="spline_amplitude, 8, 0.7", ctrl_init="random, 0.01, 0.4",
+                            target="pure", objective="Jmeasure"), ntime=40, penalties=True)
+    a = sp.params0.copy()
+    h.set_params(a)
+    orc.set_params(a)
+    times = np.linspace(0.0, sp.time.ntime * sp.time.dt, 83)
+    np.testing.assert_allclose(h.eval_controls(times), orc.eval_controls(times), rtol=1e-13, atol=1e-16)
+    opt = capi.Optim(h, sp)
+    val = opt.evalF(a)
+    oval = orc.evalF(a)[0]
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    with pytest.raises(capi.QuandaryAmdError, match="no gradient in the reference"):
+        opt.evalGradF(a)
+    opt.close(); h.close(); orc.close()
+
+
+TEAM_CASES = [
+    pytest.param(dict(nlevels=[2, 2], lindblad=False), id="2x2-schroedinger-gate-4ic"),
+    pytest.param(dict(nlevels=[3, 4], lindblad=True, jkl=0.01, detuned=True, target="pure", objective="Jfrobenius", init="diagonal, 0"), id="3x4-lindblad-Jkl-3ic"),
+    pytest.param(dict(nlevels=[4], lindblad=True, nessential=[3], target="pure", objective="Jtrace"), id="4-lindblad-guard-9ic"),
+    pytest.param(dict(nlevels=[3, 3, 3], lindblad=True, nessential=[2, 3, 2], jkl=0.004, detuned=True, init="diagonal, 1"), id="3x3x3-lindblad-3ic"),
+    pytest.param(dict(nlevels=[2, 3, 2], lindblad=False, jkl=0.01, detuned=True, target="pure", objective="Jmeasure", init="pure, 1, 0, 1"), id="2x3x2-schroedinger-1ic"),
+]
+
+
+@pytest.mark.parametrize("kw", TEAM_CASES)
+@pytest.mark.parametrize("team,spread", [(2, 0), (8, 0), (32, 0), (4, 1), (64, 1)])
+@pytest.mark.parametrize("stepper,linsolve", [("IMR", "neumann"), ("IMR4", "gmres")])
+def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper, linsolve, monkeypatch):
+    """Several workgroups per initial condition (qd_big.h: team barriers and team reductions through global memory, members on one
+    XCD or dealt over all of them), forced onto small systems so that every penalty, guard levels, couplings and both solvers run
+    through the team path; compared with the oracle like every other kernel."""
+    monkeypatch.setenv("QD_VAR", "16")
+    monkeypatch.setenv("QD_BIG_TEAM", str(team))
+    monkeypatch.setenv("QD_BIG_SPREAD", str(spread))
+    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
+    opt = capi.Optim(h, sp)
+    nb = opt.ninit
+    if (nb if spread else (nb + 7) // 8 * 8) * team > 256:
+        pytest.skip("these teams would not be resident together")
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_team == team
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    if linsolve == "gmres":
+        orc.reset_stats()
+        orc.evalF(sp.params0)
+        opt.evalF(sp.params0)
+        assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    # same result as one workgroup per initial condition, up to the summation order of the reductions
+    monkeypatch.setenv("QD_BIG_TEAM", "1")
+    val1, g1 = opt.evalGradF(sp.params0)
+    assert h.last_team == 1
+    assert val1["objective"] == pytest.approx(val["objective"], rel=1e-11)
+    assert np.linalg.norm(g - g1) / np.linalg.norm(g1) < 1e-9
+    opt.close(); h.close(); orc.close()
+
+
+def test_team_size_follows_batch_and_dimension():
+    """The selection rule: one pure initial condition of the 10x10 Lindblad system (dim 10 000 >= 2 x 4096 elements) runs on two
+    workgroups; a 9x9 system (dim 6561) stays on one."""
+    for nl, want in (([10, 10], 2), ([9, 9], 1)):
+        sp = synthetic_spec(nl, lindblad=True, ntime=2, nspline=5, target="pure", objective="Jfrobenius", init="pure, 0, 1")
+        h = capi.Handle(sp)
+        opt = capi.Optim(h, sp)
+        opt.evalF(sp.params0)
+        assert h.last_team == want
+        opt.close(); h.close()
