@@ -8,7 +8,9 @@
  *   MasterEq RHS  ->  TimeStepper (IMR/IMR4/IMR8/EE)  ->  OptimProblem evalF/evalGradF
  * to check the HIP path against.  Parity status: PINNED — checked against the
  * reference's own golden regression files (tests/regression/<case>/base, copied as numbers
- * into tests/golden/) by tests/test_oracle_golden.py.
+ * into tests/golden/) by tests/test_oracle_golden.py.  Exception: the "step" and "spline_amplitude" control
+ * parameterisations (seg_evaluate / seg_derivative below) appear in no golden file or test of the reference; those two
+ * branches are PARITY UNPINNED against reference output and are checked by properties only (tests/test_control_bases.py).
  *
  * Each function cites the reference file:line it follows (paths relative to
  * the reference repository).  PETSc itself (Vec container, KSPGMRES) is a

@@ -12,6 +12,8 @@ byte-identical descriptions.
 import ctypes as C
 import os
 
+import weakref
+
 import numpy as np
 
 QD_MAX_OSC = 8
@@ -325,6 +327,12 @@ class Handle:
         _check(self.lib, rc, "qd_set_hamiltonian")
 
     def close(self):
+        # objects created on this handle go first (the garbage collector finalises unreachable objects in no particular order)
+        for ref in getattr(self, "_children", []):
+            child = ref()
+            if child is not None:
+                child.close()
+        self._children = []
         if self._h:
             self.lib.qd_destroy(self._h)
             self._h = C.c_void_p()
@@ -422,6 +430,9 @@ class Optim:
 
     def __init__(self, handle, spec, rank=0, nranks=1):
         self.h = handle
+        if not hasattr(handle, "_children"):
+            handle._children = []
+        handle._children.append(weakref.ref(self))
         self.lib = handle.lib
         self.spec = spec
         self._o = C.c_void_p()

@@ -12,9 +12,10 @@
 // G x 1024 threads, every workgroup barrier of the sweep becomes a team barrier (a monotone counter in global memory,
 // agent-scope release / acquire: L2 write-back and invalidate, so the exchange is correct across XCDs) and every reduction
 // goes through per-workgroup partial sums that all members add up in the same order (bit-identical scalars in all members:
-// the solver's control flow stays uniform over the team).  By default the members of a team sit on ONE XCD (blockIdx -> XCD
-// round robin: member j of team t is block 8 (G (t / 8) + j) + t % 8), so the vectors are exchanged through that XCD's L2;
-// S.team_spread deals the members over all XCDs instead.  The kernel is launched cooperatively (co-residency is checked by the
+// the solver's control flow stays uniform over the team).  The members of a team are consecutive blocks, i.e. dealt over all
+// eight XCDs (measured 2-3x faster than a team kept on ONE XCD - member j of team t = block 8 (G (t / 8) + j) + t % 8, selected
+// with S.team_spread = 0 - which shares one L2 but also one XCD's share of the fabric: profiles/r2_big_probe.jsonl).  The kernel
+// is launched cooperatively (co-residency is checked by the
 // runtime: a team that cannot be resident is an error, never a hang).
 #pragma once
 #include <type_traits>
@@ -74,7 +75,7 @@ struct BigTeam {
   // team of G workgroups on one initial condition: element loops run e = gtid, gtid + gnt, ...
   int G, member, ic, gtid, gnt, gslot;
   unsigned long long* bar;
-  unsigned long long bar_target;
+  unsigned long long bar_target, sub_target;  // (thread 0 only)
   double* gred;
 
   static size_t lds_bytes(const DevSys& S) {
@@ -103,6 +104,7 @@ struct BigTeam {
     gslot = 0;
     bar = S.tbar + (size_t)ic * BIG_BAR_STRIDE;
     bar_target = 0;
+    sub_target = 0;
     gred = S.tred + (size_t)ic * 2 * BIG_TEAM_MAX * BIG_RED_NV;
     coef = reinterpret_cast<const double2*>(S.ecoef);
     dig = reinterpret_cast<const uint2*>(S.edig);
@@ -129,23 +131,35 @@ struct BigTeam {
     __syncthreads();
     return true;
   }
-  // Barrier over the team.  G = 1: the workgroup barrier (workgroup-scope fences).  G > 1: every wave releases its stores at
-  // agent scope, one thread per workgroup arrives at the team's counter and waits for the G arrivals of this round (acquire:
-  // L1 / L2 invalidate for the whole CU), the workgroup barrier hands the result to the other waves.
+  // Barrier over the team.  G = 1: the workgroup barrier (workgroup-scope fences).  G > 1: every wave waits until L2 has
+  // acknowledged its stores, then ONE thread per workgroup releases at agent scope (L2 write-back: the other XCDs can see the
+  // data), arrives at the team's counter, waits for the G arrivals of this round and acquires (L1 / L2 invalidate, which holds for
+  // the whole CU / XCD); the workgroup barrier hands the result to the other waves.  Fences issued by all 16 waves instead cost
+  // 4-8x more (profiles/r2_barrier_probe.jsonl: 2.5 us against 10 us per barrier at G = 32).  From 64 members on the arrivals go
+  // through eight first-level counters (members with equal blockIdx % 8, i.e. one XCD under round-robin dispatch), the last
+  // arrival of a group reports to the team's counter: 5.9 us instead of 8.2 us at G = 256.
   __device__ __forceinline__ void tsync() {
     if (G == 1) {
       __syncthreads();
       return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    bar_target += (unsigned long long)G;
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < bar_target) __builtin_amdgcn_s_sleep(1);
+      if (G >= 64) {
+        bar_target += 8ull;
+        sub_target += (unsigned long long)(G / 8);
+        unsigned long long* sub = bar + 16 * (1 + (member & 7));
+        const unsigned long long prev = __hip_atomic_fetch_add(sub, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == sub_target) __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        bar_target += (unsigned long long)G;
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   // make element e the stencil's slot
   __device__ __forceinline__ void at(int e) {
@@ -165,26 +179,38 @@ struct BigTeam {
   template <int NV>
   __device__ __forceinline__ void sum(double (&v)[NV]) {
     static_assert(NV <= BIG_RED_NV, "team reduction buffer too small");
-    block_sum<NV, false>(v, L.red + redslot * NRED * (BIG_BLOCK / 64));
-    redslot ^= 1;
-    if (G > 1) {  // partial sums of the members, added up by everybody in member order (two buffers: see tsync's ordering)
-      double* slot = gred + (size_t)gslot * BIG_TEAM_MAX * BIG_RED_NV;
-      gslot ^= 1;
-      if (threadIdx.x < NV) {
-        double mine = 0.0;
+    if (G == 1) {
+      block_sum<NV, false>(v, L.red + redslot * NRED * (BIG_BLOCK / 64));
+      redslot ^= 1;
+      return;
+    }
+    // team: partial sums of the members in global memory ([value][member], two buffers: see tsync's ordering), added up by the
+    // first wave of every member in the same order (lanes over members, then the wave's butterfly), handed to the other waves
+    // through LDS.  LDS slot 0 serves the workgroup's own reduction, slot 1 the team's result.
+    block_sum<NV, false>(v, L.red);
+    double* slot = gred + (size_t)gslot * BIG_TEAM_MAX * BIG_RED_NV;
+    gslot ^= 1;
+    if (threadIdx.x < NV) {
+      double mine = 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; i++)
-          if ((int)threadIdx.x == i) mine = v[i];
-        slot[member * BIG_RED_NV + threadIdx.x] = mine;
-      }
-      tsync();
+      for (int i = 0; i < NV; i++)
+        if ((int)threadIdx.x == i) mine = v[i];
+      slot[threadIdx.x * BIG_TEAM_MAX + member] = mine;
+    }
+    tsync();
+    double* res = L.red + NRED * (BIG_BLOCK / 64);
+    if (threadIdx.x < 64) {
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         double t = 0.0;
-        for (int m = 0; m < G; m++) t += __builtin_nontemporal_load(slot + m * BIG_RED_NV + i);
-        v[i] = t;
+        for (int m = threadIdx.x; m < G; m += 64) t += slot[i * BIG_TEAM_MAX + m];
+        t = wave_sum(t);
+        if (threadIdx.x == 0) res[i] = t;
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = res[i];
   }
   __device__ __forceinline__ float sum_f32(float v) {
     if (G > 1) {

@@ -35,7 +35,7 @@ extern "C" int qd_comm_unique_id(unsigned char* id) {
 extern "C" int qd_comm_create(const unsigned char* id, int rank, int nranks, int device_ordinal, qd_comm** out) {
   if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(QD_ERR_INVALID, "qd_comm_create: bad argument");
   *out = nullptr;
-  QD_HIP(hipSetDevice(device_ordinal));
+  QD_HIP(qd::use_device(device_ordinal));
   qd_comm* c = new qd_comm();
   c->rank = rank;
   c->nranks = nranks;
@@ -91,6 +91,7 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
 extern "C" void qd_comm_destroy(qd_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   c->dbuf.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
@@ -114,7 +115,7 @@ int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_
 extern "C" int qd_comm_allreduce(qd_comm* c, double* buf, int n, int op) {
   if (!c || !buf || n < 0 || (op != 0 && op != 1)) return fail(QD_ERR_INVALID, "qd_comm_allreduce: bad argument");
   if (n == 0) return QD_OK;
-  QD_HIP(hipSetDevice(c->device));
+  QD_HIP(qd::use_device(c->device));
   int r;
   if ((r = c->dbuf.ensure(n))) return r;
   QD_HIP(hipMemcpyAsync(c->dbuf.p, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));

@@ -63,6 +63,7 @@ static int upload(T** dst, const std::vector<T>& v) {
 extern "C" void qd_destroy(qd_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   for (DBuf* b : {&h->d_params, &h->d_tbar, &h->d_tred, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_res,
                   &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_ecoef, &h->d_edig, &h->d_work, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
@@ -238,7 +239,7 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
   // ---- device resources
   int rc = QD_OK;
   auto dev_setup = [&]() -> int {
-    QD_HIP(hipSetDevice(h->device));
+    QD_HIP(qd::use_device(h->device));
     QD_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     QD_HIP(hipEventCreate(&h->ev0));
     QD_HIP(hipEventCreate(&h->ev1));
@@ -338,7 +339,7 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   if ((hc_re == nullptr) != (hc_im == nullptr)) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: give both parts of the control Hamiltonians or neither");
   // (dim <= 1024: the LDS kernels V11-V13 / V15; beyond: the global-memory sweeps of qd_big.h with the dense operator)
   if (h->S.Q > 5) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: the dense-operator kernels are instantiated for 1..5 oscillators");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const size_t nn = (size_t)h->S.N * h->S.N;
   if ((double)h->sched_t.size() * (double)nn * 16.0 > 16e9)
     return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: the table of G(t) would exceed 16 GB (time steps x N^2)");
@@ -388,7 +389,7 @@ extern "C" int qd_set_precision(qd_handle* h, int precision) {
 extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
   if (!h || (!alpha && ndesign > 0)) return fail(QD_ERR_INVALID, "qd_set_params: null argument");
   if (ndesign != h->ndesign) return fail(QD_ERR_INVALID, "qd_set_params: ndesign mismatch");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   if (ndesign > 0) {
     std::memcpy(h->params.data(), alpha, sizeof(double) * ndesign);
     std::memcpy(h->h_params.p, alpha, sizeof(double) * ndesign);
@@ -434,7 +435,7 @@ double qd_handle::energy_penalty_host() const {
 
 extern "C" int qd_eval_controls(qd_handle* h, const double* times, int nt, double* pq) {
   if (!h || !times || !pq || nt < 0) return fail(QD_ERR_INVALID, "qd_eval_controls: bad argument");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   for (int i = 0; i < nt; i++)
     if (times[i] > h->dctl.Tfinal) return fail(QD_ERR_INVALID, "qd_eval_controls: t > Tfinal (src/oscillator.cpp:284-287)");
   DBuf dt, dz, dtab;
@@ -485,7 +486,7 @@ static int check_cfg(const LaunchCfg& cfg) {
 extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double* x, double* y, int nb) {
   if (!h || !x || !y || nb < 1) return fail(QD_ERR_INVALID, "qd_apply_rhs: bad argument");
   if (t > h->dctl.Tfinal) return fail(QD_ERR_INVALID, "qd_apply_rhs: t > Tfinal (src/oscillator.cpp:284-287)");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const size_t n = (size_t)nb * 2 * h->S.dim;
   int r;
   if ((r = h->d_x0.ensure(n)) || (r = h->d_y.ensure(n))) return r;
@@ -515,7 +516,7 @@ extern "C" int qd_set_target(qd_handle* h, const qd_target* tgt, int nb) {
   if (tgt->target_type != QD_TARGET_PURE && !tgt->target_states) return fail(QD_ERR_INVALID, "qd_set_target: target states required");
   if (tgt->objective_type == QD_OBJ_JMEASURE && tgt->target_type != QD_TARGET_PURE)
     return fail(QD_ERR_INVALID, "qd_set_target: Jmeasure needs a pure target (src/optimtarget.cpp:758-761)");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   int r;
   h->dtg.target_type = tgt->target_type;
   h->dtg.objective_type = tgt->objective_type;
@@ -652,7 +653,7 @@ int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarge
 
 // enqueue the whole forward sweep (tables, kernel, objective pieces, asynchronous result download) on the handle's stream
 int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTarget* tgp) {
-  QD_HIP(hipSetDevice(device));
+  QD_HIP(qd::use_device(device));
   int r;
   if (pen.gamma_penalty > 1e-13 && pen.penalty_param > 1e-13 && !tgp)
     return fail(QD_ERR_STATE, "qd_forward: the weighted-J penalty (optim_penalty_param > 0) needs qd_set_target first");
@@ -716,7 +717,7 @@ int qd_handle::forward_finish(double* energy) {
   float ms = 0.f;
   QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
   last_fwd_ms = accumulate_fwd_ms ? last_fwd_ms + ms : ms;
-  last_mean_applies = (double)nap / ((double)nb * (double)nsub);
+  last_mean_applies = (double)nap / ((double)nb * (double)tg.ntime);  // per TIME step (all stages of a composite step)
   last_nb = nb;
   traj_valid = store;
   pending_store = false;
@@ -727,7 +728,7 @@ int qd_handle::forward_finish(double* energy) {
 extern "C" int qd_forward(qd_handle* h, const double* x0, int nb, int store_trajectory, qd_forward_out* out) {
   if (!h || !x0 || nb < 1) return fail(QD_ERR_INVALID, "qd_forward: bad argument");
   if (h->target_set && h->target_nb != nb) return fail(QD_ERR_INVALID, "qd_forward: batch size differs from qd_set_target");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const size_t n = (size_t)nb * 2 * h->S.dim;
   int r;
   if ((r = h->d_x0.ensure(n))) return r;
@@ -756,7 +757,7 @@ extern "C" int qd_get_state(qd_handle* h, int timestep, double* x) {
   if (!h || !x) return fail(QD_ERR_INVALID, "qd_get_state: null argument");
   if (!h->traj_valid) return fail(QD_ERR_STATE, "qd_get_state: no stored trajectory (call qd_forward with store_trajectory=1)");
   if (timestep < 0 || timestep > h->tg.ntime) return fail(QD_ERR_INVALID, "qd_get_state: time step out of range");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const size_t n = (size_t)h->last_nb * 2 * h->S.dim;
   if (h->precision == QD_PRECISION_F32MIXED) {  // stored as interleaved float2 per element
     std::vector<float> tmp(n);
@@ -777,7 +778,7 @@ extern "C" int qd_get_observables(qd_handle* h, int stride, double* expected, do
                                   double* population_composite) {
   if (!h || stride < 1) return fail(QD_ERR_INVALID, "qd_get_observables: bad argument");
   if (!h->traj_valid) return fail(QD_ERR_STATE, "qd_get_observables: no stored trajectory (forward sweep with store_trajectory=1 first)");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const DevSys& S = h->S;
   const int nb = h->last_nb, nout = h->tg.ntime / stride + 1;
   int nlev = 0;
@@ -812,7 +813,7 @@ int qd_handle::adjoint_dev(const double* dxbarT, const double* djbar, int nb, co
 }
 
 int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb, const DevTarget* tgp, bool accumulate) {
-  QD_HIP(hipSetDevice(device));
+  QD_HIP(qd::use_device(device));
   if (!(traj_valid || pending_store) || last_nb != nb) return fail(QD_ERR_STATE, "qd_adjoint: needs a forward sweep of the same batch with store_trajectory=1");
   if (has_pipulse) return fail(QD_ERR_UNSUPPORTED, "qd_adjoint: derivative of pi-pulses is not implemented in the reference (src/oscillator.cpp:373-378)");
   if (has_ampbasis) return fail(QD_ERR_UNSUPPORTED, "qd_adjoint: the spline_amplitude parameterisation has no gradient in the reference (src/oscillator.cpp:350-356)");
@@ -861,7 +862,7 @@ int qd_handle::adjoint_finish(bool accumulate) {
 }
 
 int qd_handle::gradient_launch(double ebar, double* dgrad) {
-  QD_HIP(hipSetDevice(device));
+  QD_HIP(qd::use_device(device));
   if (ndesign == 0) return QD_OK;
   const int nsub_flag = sol.stepper == QD_STEPPER_EE ? -nsub : nsub;
   QD_HIP(launch_grad(dctl, d_params.p, d_table.p, cs, nsub_flag, d_coeffsum.p, d_etable.p, tg.ntime, ebar, dgrad, ndesign, stream));
@@ -869,7 +870,7 @@ int qd_handle::gradient_launch(double ebar, double* dgrad) {
 }
 
 int qd_handle::gradient_from_coeffs(double ebar, double* grad) {
-  QD_HIP(hipSetDevice(device));
+  QD_HIP(qd::use_device(device));
   int r;
   if (ndesign == 0) return QD_OK;
   if ((r = d_grad.ensure(ndesign))) return r;
@@ -881,7 +882,7 @@ int qd_handle::gradient_from_coeffs(double ebar, double* grad) {
 
 extern "C" int qd_adjoint(qd_handle* h, const double* xbarT, const double* jbar, int nb, double* grad) {
   if (!h || !xbarT || !jbar || !grad || nb < 1) return fail(QD_ERR_INVALID, "qd_adjoint: bad argument");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const size_t n = (size_t)nb * 2 * h->S.dim;
   int r;
   if ((r = h->d_xbar.ensure(n)) || (r = h->d_jbar.ensure((size_t)3 * nb))) return r;
@@ -908,7 +909,7 @@ extern "C" int qd_bench_apply_f32(qd_handle* h, double t, const double* x, doubl
   bool qubits = S.lindblad && !S.dense && !S.hasJ && (S.Q == 4 || S.Q == 5);
   for (int k = 0; k < S.Q; k++) qubits = qubits && S.n[k] == 2;
   if (!qubits || (mfma && S.Q != 5)) return fail(QD_ERR_UNSUPPORTED, "qd_bench_apply_f32: all-qubit Lindblad systems with 4 or 5 oscillators (MFMA: 5)");
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   const size_t n = (size_t)nb * 2 * S.dim;
   int r;
   if ((r = h->d_x0.ensure(n)) || (r = h->d_y.ensure(n))) return r;

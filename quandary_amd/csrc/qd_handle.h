@@ -21,6 +21,14 @@
 
 namespace qd {
 
+// Entry points select the handle's device and drop whatever error an earlier, unrelated HIP call of this thread left behind
+// (the launch wrappers report hipGetLastError(), which is sticky per thread).
+inline hipError_t use_device(int device) {
+  const hipError_t e = hipSetDevice(device);
+  (void)hipGetLastError();
+  return e;
+}
+
 hipError_t launch_observables(const DevSys& S, const double* traj, int f32, int nb, int nstages, int stride, int nout, int nlev_total,
                               double* expected, double* population, double* expcomp, double* popcomp, hipStream_t st);
 

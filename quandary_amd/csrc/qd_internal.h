@@ -101,7 +101,7 @@ struct SweepArgs {
 // teams of workgroups in the global-memory sweeps (qd_big.h)
 constexpr int BIG_TEAM_MAX = 256;   // workgroups per initial condition
 constexpr int BIG_RED_NV = 16;      // doubles per member in the team reduction buffer
-constexpr int BIG_BAR_STRIDE = 16;  // 128 B between the barrier counters of two teams
+constexpr int BIG_BAR_STRIDE = 16 * 9;  // per team: the team's counter and eight first-level counters, 128 B apart
 
 struct LaunchCfg {
   int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)

@@ -502,9 +502,11 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   return c;
 }
 
-// Workgroups per initial condition of the global-memory sweeps: as many as keep every team resident (one 1024-thread workgroup
-// per CU is what the register budget of these kernels allows for sure) and leave each thread four elements per pass.  Members of
-// a team on one XCD (32 CUs) by default; QD_BIG_TEAM / QD_BIG_SPREAD override (tests, measurements).
+// Workgroups per initial condition of the global-memory sweeps.  A team barrier costs 2 us (8 members) to 3 us (64) and there
+// are about two per operator application, one workgroup alone needs 2-17 ns per element and application: the team grows while it
+// leaves each thread at least half an element, up to 64 members, and while all teams stay resident (one 1024-thread workgroup per
+// CU is what the register budget of these kernels allows for sure; the cooperative launch checks it).  Members dealt over all XCDs
+// by default.  QD_BIG_TEAM / QD_BIG_SPREAD override (tests, measurements: profiles/big_probe.py).
 void big_team(const DevSys& S, int nb, int& team, int& spread) {
   static int ncu = 0;
   if (!ncu) {
@@ -514,11 +516,12 @@ void big_team(const DevSys& S, int nb, int& team, int& spread) {
     if (ncu <= 0) ncu = 256;
   }
   const char* es = getenv("QD_BIG_SPREAD");
-  spread = es ? atoi(es) != 0 : 0;
+  spread = es ? atoi(es) != 0 : 1;
   const int gmax = spread ? BIG_TEAM_MAX : 32;
   const int slots = spread ? nb : (nb + 7) / 8 * 8;
   int g = 1;
-  while (g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)S.dim >= (size_t)4 * BIG_BLOCK * (g * 2)) g *= 2;
+  while (g * 2 <= 64 && g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)2 * S.dim >= (size_t)BIG_BLOCK * (g * 2)) g *= 2;
+  if (S.dim <= 4096) g = 1;  // (the global-memory kernels forced onto a small system)
   if (const char* et = getenv("QD_BIG_TEAM")) {
     const int v = atoi(et);
     if (v >= 1 && v <= gmax && (v & (v - 1)) == 0 && (long)slots * v <= ncu) g = v;

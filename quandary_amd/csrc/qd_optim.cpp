@@ -233,6 +233,7 @@ static void fill_from_file(const qd_handle* h, const double* data, std::vector<d
 extern "C" void qd_optim_destroy(qd_optim* o) {
   if (!o) return;
   (void)hipSetDevice(o->h->device);
+  struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   for (DBuf* b : {&o->d_x0, &o->d_tgt, &o->d_pur, &o->d_rbib, &o->d_jbar, &o->d_xbar, &o->d_w, &o->d_red}) b->release();
   o->h_red.release();
   for (hipEvent_t e : o->evr)
@@ -380,7 +381,7 @@ extern "C" int qd_optim_create(qd_handle* h, const qd_objective* ob, int rank, i
   }
   int rc = QD_OK;
   auto dev = [&]() -> int {
-    QD_HIP(hipSetDevice(h->device));
+    QD_HIP(qd::use_device(h->device));
     int r;
     if ((r = o->d_x0.ensure(x0.size())) || (r = o->d_pur.ensure(o->nlocal))) return r;
     QD_HIP(hipMemcpy(o->d_x0.p, x0.data(), sizeof(double) * x0.size(), hipMemcpyHostToDevice));
@@ -432,7 +433,7 @@ extern "C" int qd_optim_ninit_local(const qd_optim* o) { return o ? o->nlocal : 
 
 extern "C" int qd_optim_initial_state(qd_optim* o, int i, double* x0, int* initid) {
   if (!o || !x0 || i < 0 || i >= o->nlocal) return fail(QD_ERR_INVALID, "qd_optim_initial_state: bad argument");
-  QD_HIP(hipSetDevice(o->h->device));
+  QD_HIP(qd::use_device(o->h->device));
   const size_t n2 = (size_t)2 * o->h->S.dim;
   QD_HIP(hipMemcpy(x0, o->d_x0.p + (size_t)i * n2, sizeof(double) * n2, hipMemcpyDeviceToHost));
   if (initid) *initid = o->init_id[i];
@@ -441,7 +442,7 @@ extern "C" int qd_optim_initial_state(qd_optim* o, int i, double* x0, int* initi
 
 extern "C" int qd_optim_target_state(qd_optim* o, int i, double* xt) {
   if (!o || !xt || i < 0 || i >= o->nlocal) return fail(QD_ERR_INVALID, "qd_optim_target_state: bad argument");
-  QD_HIP(hipSetDevice(o->h->device));
+  QD_HIP(qd::use_device(o->h->device));
   const size_t n2 = (size_t)2 * o->h->S.dim;
   if (o->tg.tstates) {
     QD_HIP(hipMemcpy(xt, o->d_tgt.p + (size_t)i * n2, sizeof(double) * n2, hipMemcpyDeviceToHost));
@@ -537,7 +538,7 @@ static DevTarget shifted_target(const qd_optim* o, int offset) {
 extern "C" int qd_optim_forward_local(qd_optim* o, const double* alpha, int store_trajectory, double* partial) {
   if (!o || !partial || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_forward_local: null argument");
   qd_handle* h = o->h;
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   int r;
   if ((r = qd_set_params(h, alpha, h->ndesign))) return r;
   o->last_alpha.assign(alpha, alpha + h->ndesign);
@@ -589,7 +590,7 @@ extern "C" int qd_optim_finalize(qd_optim* o, const double* alpha, const double*
 extern "C" int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const double* sums, double* grad) {
   if (!o || !sums || !grad || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_adjoint_local: null argument");
   qd_handle* h = o->h;
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   if (!o->forward_done || (int)o->last_alpha.size() != h->ndesign || !std::equal(o->last_alpha.begin(), o->last_alpha.end(), alpha))
     return fail(QD_ERR_STATE, "qd_optim_adjoint_local: call qd_optim_forward_local with the same parameters first");
   const int nl = o->nlocal, nd = h->ndesign;
@@ -713,7 +714,7 @@ extern "C" int qd_optim_evalF_dist(qd_optim* o, qd_comm* c, const double* alpha,
   if (!o || !c || !val || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_evalF_dist: null argument");
   if (c->nranks != o->nranks || c->rank != o->rank) return fail(QD_ERR_INVALID, "qd_optim_evalF_dist: communicator and objective disagree on rank / nranks");
   qd_handle* h = o->h;
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   PenaltyScope ps(h, o->pen);
   int r;
   if ((r = dist_forward(o, c, alpha, false))) return r;
@@ -727,7 +728,7 @@ extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* al
   if (!o || !c || !val || !grad || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_evalGradF_dist: null argument");
   if (c->nranks != o->nranks || c->rank != o->rank) return fail(QD_ERR_INVALID, "qd_optim_evalGradF_dist: communicator and objective disagree on rank / nranks");
   qd_handle* h = o->h;
-  QD_HIP(hipSetDevice(h->device));
+  QD_HIP(qd::use_device(h->device));
   PenaltyScope ps(h, o->pen);
   const int nl = o->nlocal, nd = h->ndesign;
   int r;

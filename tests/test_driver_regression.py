@@ -192,3 +192,46 @@ def test_driver_with_rccl_communicator(tmp_path):
     h1, h2 = _load(os.path.join(out1, "optim_history.dat")), _load(os.path.join(out2, "optim_history.dat"))
     np.testing.assert_allclose(h2, h1, rtol=1e-12, atol=1e-15)
     assert not os.path.exists(os.path.join(out2, ".qd_comm_id"))
+
+
+@pytest.mark.gpu
+def test_driver_step_and_spline_amplitude_segments(tmp_path):
+    """`control_segments = step, ...` and `spline_amplitude, ...` through the config-file driver (src/oscillator.cpp:50-70, :109-127):
+    the driver's own parser / initialisation against the Python restatement and the oracle; the amplitude basis is forward only."""
+    from helpers import synthetic_cfg
+    from oracle.oracle import Oracle
+    from quandary_amd import config
+
+    text = synthetic_cfg([2, 3], lindblad=False, ntime=40, segments=["spline, 6, 0.0, 0.2, step, 0.4, 0.1, 0.03, 0.2, 0.4", "step, 0.3, -0.2, 0.05"],
+                         carrier="0.05", ctrl_init=["random, 0.01, constant, 0.1", "constant, 0.12"], target="pure", objective="Jfrobenius",
+                         penalties=True)
+    (tmp_path / "s").mkdir()
+    (tmp_path / "s" / "step.cfg").write_text(text)
+    r = subprocess.run([EXE, "step.cfg", "--quiet"], cwd=tmp_path / "s", capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sp = config.build_spec(config.parse_config_text(text))
+    orc = Oracle(sp)
+    oval, og = orc.evalGradF(sp.params0)
+    out = tmp_path / "s" / "data_out"
+    np.testing.assert_allclose(_load(out / "params.dat").ravel(), sp.params0, rtol=1e-13, atol=1e-15)
+    g = _load(out / "grad.dat").ravel()
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    hist = _load(out / "optim_history.dat")[0]
+    assert hist[1] == pytest.approx(oval["objective"], rel=REF_RTOL)
+    orc.close()
+
+    text = synthetic_cfg([2, 3], lindblad=True, ntime=40, segments="spline_amplitude, 8, 0.7", ctrl_init="random, 0.01, 0.4", target="pure",
+                         objective="Jmeasure", enforce_bc=True)
+    (tmp_path / "a").mkdir()
+    (tmp_path / "a" / "amp.cfg").write_text(text.replace("runtype = gradient", "runtype = simulation"))
+    r = subprocess.run([EXE, "amp.cfg", "--quiet"], cwd=tmp_path / "a", capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sp = config.build_spec(config.parse_config_text(text))
+    orc = Oracle(sp)
+    out = tmp_path / "a" / "data_out"
+    np.testing.assert_allclose(_load(out / "params.dat").ravel(), sp.params0, rtol=1e-13, atol=1e-15)
+    assert _load(out / "optim_history.dat")[0][1] == pytest.approx(orc.evalF(sp.params0)[0]["objective"], rel=REF_RTOL)
+    orc.close()
+    (tmp_path / "a" / "ampg.cfg").write_text(text)
+    r = subprocess.run([EXE, "ampg.cfg", "--quiet"], cwd=tmp_path / "a", capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "no gradient in the reference" in r.stdout + r.stderr

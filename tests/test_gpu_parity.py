@@ -846,6 +846,7 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper,
     opt = capi.Optim(h, sp)
     nb = opt.ninit
     if (nb if spread else (nb + 7) // 8 * 8) * team > 256:
+        opt.close(); h.close(); orc.close()
         pytest.skip("these teams would not be resident together")
     val, g = opt.evalGradF(sp.params0)
     assert h.last_team == team
@@ -868,12 +869,12 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper,
 
 
 def test_team_size_follows_batch_and_dimension():
-    """The selection rule: one pure initial condition of the 10x10 Lindblad system (dim 10 000 >= 2 x 4096 elements) runs on two
-    workgroups; a 9x9 system (dim 6561) stays on one."""
-    for nl, want in (([10, 10], 2), ([9, 9], 1)):
-        sp = synthetic_spec(nl, lindblad=True, ntime=2, nspline=5, target="pure", objective="Jfrobenius", init="pure, 0, 1")
+    """The selection rule (big_team, qd_kernels.hip): at least half an element per thread, at most 64 members, every team resident."""
+    for nl, init, want in (([10, 10], "pure, 0, 1", 16), ([9, 9], "pure, 0, 1", 8), ([10, 10], "basis, 0", 2)):
+        sp = synthetic_spec(nl, lindblad=True, ntime=2, nspline=5, target="pure", objective="Jfrobenius", init=init)
         h = capi.Handle(sp)
         opt = capi.Optim(h, sp)
+        assert opt.ninit == (100 if init.startswith("basis") else 1)
         opt.evalF(sp.params0)
         assert h.last_team == want
         opt.close(); h.close()
