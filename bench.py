@@ -319,6 +319,10 @@ EXTRA = [
     ("c4", "fwd", "neumann", "f64", {"ntime": 250}, 2),
     ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1),
     ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1),  # = the 1-GPU point of the `--gpus N` strong-scaling series
+    # one large state (dim 160 000, beyond LDS): a team of workgroups per initial condition, and the same on one workgroup
+    ("l20", "fwd", "neumann", "f64", {}, 3),
+    ("l20", "fwd", "neumann", "f64", {"_env": {"QD_BIG_TEAM": "1"}}, 1),
+    ("l20", "fwd", "gmres", "f64", {}, 2),
 ]
 # small systems: no chip-filling possible (4 / 16 single-wave workgroups); reported so that the bench line says it
 SMALL = [("c1", "grad", "gmres", "f64", {}, 3), ("c3", "grad", "neumann", "f64", {}, 3)]
@@ -463,6 +467,10 @@ def main():
             out["workloads"] = []
             for (wn, wm, ws, wd, wo, wsteps) in EXTRA + SMALL:
                 ent = {"name": wn, "mode": wm, "linearsolver": ws, "dtype": DTYPE_NAME[wd]}
+                wo = dict(wo)
+                wenv = wo.pop("_env", {})
+                saved_env = {k: os.environ.get(k) for k in wenv}
+                os.environ.update(wenv)
                 try:
                     r = Runner(wn, wm, {**wo, "linearsolver_type": ws}, wd, 0, 1, local_rank, False, None)
                     el, km, apl = r.time(wsteps, 1, sync)
@@ -472,7 +480,9 @@ def main():
                                 "rhs_applications_per_step": apl, "objective": cf["objective"], "roofline": rf})
                     if wm == "grad":
                         ent["grad_wall_ms"] = el / wsteps * 1e3
-                    if ws == "neumann" and wm == "fwd":  # one oracle check per (workload, dtype): small sample, few steps
+                    if r.handle.dim > 4096:
+                        ent["workgroups_per_initial_condition"] = r.handle.last_team
+                    if ws == "neumann" and wm == "fwd" and not wenv:  # one oracle check per (workload, dtype): small sample, few steps
                         kk = 8 if r.spec.ninit % 8 == 0 else 1
                         nn = 20 if r.spec.dim > 256 else 100
                         ent["oracle_check"] = {"sample": f"first {kk} initial conditions x first {nn} steps",
@@ -488,6 +498,12 @@ def main():
                     r.close()
                 except (Exception, SystemExit) as e:  # noqa: BLE001  (a failed extra never hides the headline)
                     ent["error"] = f"{type(e).__name__}: {e}"
+                finally:
+                    for k2, v2 in saved_env.items():
+                        if v2 is None:
+                            os.environ.pop(k2, None)
+                        else:
+                            os.environ[k2] = v2
                 out["workloads"].append(ent)
     if comm is not None:
         comm.barrier()

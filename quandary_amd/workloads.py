@@ -42,6 +42,27 @@ def _axc(ntime, linsolve="neumann", init="basis", runtype="simulation"):
     ]) + "\n"
 
 
+def _big(levels, ntime, dt, init, linsolve="neumann", runtype="simulation"):
+    """One (or a few) initial conditions of a system whose state exceeds one CU's LDS: the reference's <20,20>, <4,4,4,4>, ... templates
+    (src/mastereq.cpp:3046-3047, :3150-3151, :3202), state preparation of the ground state."""
+    q = len(levels)
+    lines = [
+        "nlevels = " + ",".join(str(n) for n in levels), f"ntime = {ntime}", f"dt = {dt}",
+        "transfreq = " + ",".join(f"{4.1 + 0.1 * k:.4f}" for k in range(q)),
+        "rotfreq = " + ",".join(f"{4.1 + 0.1 * k:.4f}" for k in range(q)),
+        "selfkerr = " + ",".join(["0.2"] * q), "crosskerr = 0.001", "Jkl = 0.0", "collapse_type = both",
+        "decay_time = " + ",".join(["80.0"] * q), "dephase_time = " + ",".join(["26.0"] * q),
+        f"initialcondition = {init}", "control_enforceBC = false", "optim_target = pure, " + ",".join(["0"] * q),
+        "optim_objective = Jmeasure", "optim_regul = 1e-4", "optim_penalty = 0.0", "optim_penalty_param = 0.5",
+        "optim_penalty_energy = 0.0", "optim_penalty_dpdm = 0.0", "optim_penalty_variation = 0.0",
+        f"linearsolver_type = {linsolve}", "linearsolver_maxiter = 20", "timestepper = IMR",
+        "rand_seed = 1234", "usematfree = true", f"runtype = {runtype}",
+    ]
+    for k in range(q):
+        lines += [f"control_segments{k} = spline, 10", f"control_initialization{k} = random, 0.005", f"carrier_frequency{k} = 0.0, -0.2"]
+    return "\n".join(lines) + "\n"
+
+
 def random_hamiltonians(n, nosc, seed=1234):
     """Synthetic user Hamiltonians for the dense-operator path: random Hermitian Hsys and Hc_k (rad/ns)."""
     import numpy as np
@@ -70,6 +91,9 @@ WORKLOADS = {
            lambda mode: _axc(2500 if mode == "simulation" else 500, runtype=mode)),
     "c5": ("C5 2^5 Lindblad (dim 1024), 1024 basis initial conditions, ntime 1000, fp64 stencil path",
            lambda mode: _qubits(5, True, 1000, 0.01, 30, runtype=mode)),
+    # one pure initial state of the 20 x 20 Lindblad system (dim 160 000): a team of workgroups per state (qd_big.h)
+    "l20": ("20x20 Lindblad (the reference's <20,20> template), one pure initial condition, state dimension 160 000, ntime 200",
+            lambda mode: _big([20, 20], 200, 0.001, "pure, 1, 1", runtype=mode)),
     # dense user-Hamiltonian operator (hamiltonian_file_Hsys / _Hc of the reference): random Hermitian 16 x 16
     "d4": ("D4 2^4 Lindblad with user-supplied dense Hamiltonians (dim 256), 256 basis initial conditions, ntime 1000",
            lambda mode: _qubits(4, True, 1000, 0.002, 30, runtype=mode) + "synthetic_hamiltonian_seed = 1234\n"),
