@@ -558,7 +558,7 @@ int qd_handle::traj_doubles(int nb, size_t* n) const {
 // max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
 // by their amplitude).  QD_GMRES_POLY overrides the degree (1 = never precondition).
 int qd_handle::gmres_poly_degree() const {
-  const int want = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : 4;
+  const int want = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : 6;  // degree sweep: DESIGN.md section 2
   // only where the Krylov basis traffic is the cost (dim > 1024: the column / eight-elements-per-thread kernels); below
   // that plain GMRES keeps the oracle's iteration path, and with it results that agree far below the solver tolerance
   if (want <= 1 || S.dense || S.dim <= 1024) return 1;

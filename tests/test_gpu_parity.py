@@ -140,10 +140,10 @@ def test_gmres_solver_vs_oracle_gmres(kw):
     opt.close(); h.close(); orc.close()
 
 
-@pytest.mark.parametrize("poly", ["1", "4"])
+@pytest.mark.parametrize("poly", ["1", "4", "6"])
 def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
     """The 3x20 system with the reference's AxC constants and time step (dt = 1e-4: the Neumann series contracts): the
-    global-memory GMRES of the column kernel right-preconditioned with the Neumann polynomial of degree 4 (default) and
+    global-memory GMRES of the column kernel right-preconditioned with the Neumann polynomial of degree 4 / 6 (default) and
     plain (QD_GMRES_POLY=1 = KSPGMRES + PCNONE iteration for iteration: application counts of the oracle's GMRES).  Same
     stopping rule on the same true residual, so objective and gradient agree with the oracle either way."""
     from quandary_amd.workloads import workload_spec
@@ -162,7 +162,7 @@ def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
     if poly == "1":
         assert abs(h.mean_applies - orc.mean_applies) < 0.25
     else:
-        assert orc.mean_applies < h.mean_applies < 2.0 * orc.mean_applies  # 1 + 3 x 4 + 3 applications against ~10
+        assert orc.mean_applies < h.mean_applies < 2.0 * orc.mean_applies  # 1 + 3 x p + 3 applications against ~10
     opt.close(); h.close(); orc.close()
 
 
