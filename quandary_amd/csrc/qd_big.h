@@ -335,11 +335,6 @@ struct BigTeam {
         sum<1>(nn);
         const double hn = sqrt(nn[0]);
         hc[jj + 1] = hn;
-        const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
-        for (int e = tid; e < dim; e += nt) {
-          const double2 w = Wv[e];
-          Vg[(size_t)(jj + 1) * dim + e] = make_double2(w.x * ihn, w.y * ihn);
-        }
         double cur_h = hc[0];  // Givens rotations: redundantly by every thread on uniform values, idempotent LDS writes only
         for (int k = 0; k < jj; k++) {
           const double a1 = hc[k + 1], ck = cs[k], sk = sn[k];
@@ -357,9 +352,15 @@ struct BigTeam {
         gcur = -sj * gcur;
         its++;
         jj++;
-        tsync();  // v_{jj} complete (next application reads neighbours), scalars ordered
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
-        if (its >= A.maxiter) break;
+        if (its >= A.maxiter || jj >= MR) break;
+        // the next basis vector is only formed and stored when another iteration follows
+        const double ihn = 1.0 / hn;
+        for (int e = tid; e < dim; e += nt) {
+          const double2 w = Wv[e];
+          Vg[(size_t)jj * dim + e] = make_double2(w.x * ihn, w.y * ihn);
+        }
+        tsync();  // v_{jj} complete (next application reads neighbours), scalars ordered
       }
       for (int rw = jj - 1; rw >= 0; rw--) {
         double sacc = g[rw];

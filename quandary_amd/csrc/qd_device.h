@@ -1808,9 +1808,6 @@ struct Team {
         sum<1>(nn);
         const double hn = sqrt(nn[0]);
         hc[j + 1] = hn;
-        const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
-        v = make_double2(w.x * ihn, w.y * ihn);
-        if (on) Vb[(size_t)(j + 1) * dim + e] = v;
         // Givens rotations on the new column, update of the rotated right-hand side.  Every thread does
         // this redundantly on wave-uniform values; LDS locations are only ever written with values that
         // do not depend on an earlier write of the same phase (no read-modify-write), so waves of one
@@ -1832,9 +1829,13 @@ struct Team {
         gcur = -sj * gcur;
         its++;
         j++;
-        team_sync<V::ONEWAVE>();  // v_{j} is readable by every thread
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
-        if (its >= A.maxiter) break;
+        if (its >= A.maxiter || j >= GMRES_MR) break;
+        // the next basis vector is only formed and stored when another iteration follows
+        const double ihn = 1.0 / hn;
+        v = make_double2(w.x * ihn, w.y * ihn);
+        if (on) Vb[(size_t)j * dim + e] = v;
+        team_sync<V::ONEWAVE>();  // v_{j} is readable by every thread
       }
       // back substitution R yk = g, y += V yk
       for (int rw = j - 1; rw >= 0; rw--) {
@@ -1872,7 +1873,9 @@ struct Team {
   // b - (I - alpha M) y, so the stopping rule max(rtol ||b||, abstol) of the reference is unchanged; what changes is the
   // path: p applications per Krylov vector, but only ~ (iterations of plain GMRES) / p Krylov vectors.  With the basis in
   // HBM the cost of plain GMRES is its m^2 + 3m passes over 2 dim doubles per step (3x20 Lindblad: m = 11, 9.7 MB per
-  // step and initial condition); p = 4 needs m = 3.  The host only asks for p > 1 where the Neumann series provably
+  // step and initial condition); p = 6 needs m = 2.  The preconditioned vectors z_j = P v_j (Horner: z <- v_j + alpha M z, p - 1
+  // applications; w = z - alpha M z is the p-th) are kept next to the basis, so the solution y = sum_j yk_j z_j costs no
+  // further application (restart 14 then: 15 + 14 vectors + the parked total fit the 32 slots of the plain basis).  The host only asks for p > 1 where the Neumann series provably
   // contracts (a Gershgorin bound of ||alpha M||_inf <= 0.7 from the system constants and the current control
   // parameters, qd_handle::gmres_poly_degree); otherwise, and with p = 1, this is KSPGMRES + PCNONE iteration for iteration.
   template <bool TRANS>
@@ -1886,16 +1889,16 @@ struct Team {
     double* R = g + (GMRES_MR_G + 2);
     double* yk = R + GMRES_MR_G * GMRES_MR_G;
     const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
+    const int MRE = poly > 1 ? (GMRES_MR_G - 2) / 2 : GMRES_MR_G;         // restart length
+    double2* __restrict__ Zg = Vg + (size_t)(MRE + 1) * dim;               // z_j = P v_j (poly > 1)
+    const double2* __restrict__ Sg = poly > 1 ? Zg : Vg;                   // the vectors the solution is a combination of
     double2 yy[EPT], r[EPT], v[EPT], w[EPT];
     int napp = 0;
-    // z <- (alpha M) z, reading z from the published vector
-    auto amul = [&](double2(&z)[EPT]) {
-      double2 t2[EPT];
+    // t2 <- M z, reading z from the published vector
+    auto mapply = [&](const double2(&z)[EPT], double2(&t2)[EPT]) {
       if (ST::NEEDS_SLOTS && !A.S.hasJ) apply_sweep<TRANS, false>(A.S, c, z, t2);
       else apply_sweep<TRANS, true>(A.S, c, z, t2);
       napp++;
-#pragma unroll
-      for (int j = 0; j < EPT; j++) z[j] = make_double2(alpha * t2[j].x, alpha * t2[j].y);
     };
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
@@ -1921,46 +1924,98 @@ struct Team {
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         v[j] = make_double2(r[j].x * ibeta, r[j].y * ibeta);
-        if (ok(j)) Vg[at_use<EPE>(st.it[j])] = v[j];
+        if (cycle > 0 && ok(j)) Vg[at_use<EPE>(st.it[j])] = v[j];  // (first cycle: v_0 = b / beta is recomputed from registers)
       }
       publish(v);
       double gcur = beta;
       int jj = 0;
       bool conv = false;
-      while (jj < GMRES_MR_G) {
-        // w = (I - (alpha M)^p) v_jj
+      while (jj < MRE) {
+        // z = P v_jj by Horner's rule (the published vector is v_jj on entry), w = (I - alpha M) z = (I - (alpha M)^p) v_jj
 #pragma unroll
         for (int j = 0; j < EPT; j++) w[j] = v[j];
-        for (int i = 0; i < poly; i++) {
-          if (i > 0) publish(w);
-          amul(w);
-        }
+        for (int i = 1; i < poly; i++) {
+          if (i > 1) publish(w);
+          double2 t2[EPT];
+          mapply(w, t2);
 #pragma unroll
-        for (int j = 0; j < EPT; j++) w[j] = make_double2(v[j].x - w[j].x, v[j].y - w[j].y);
+          for (int j = 0; j < EPT; j++) w[j] = make_double2(fma(alpha, t2[j].x, v[j].x), fma(alpha, t2[j].y, v[j].y));
+        }
+        if (poly > 1) {
+#pragma unroll
+          for (int j = 0; j < EPT; j++)
+            if (ok(j)) Zg[(size_t)jj * dim + at_use<EPE>(st.it[j])] = w[j];
+          publish(w);
+        }
+        {
+          double2 t2[EPT];
+          mapply(w, t2);
+#pragma unroll
+          for (int j = 0; j < EPT; j++) w[j] = make_double2(fma(-alpha, t2[j].x, w[j].x), fma(-alpha, t2[j].y, w[j].y));
+        }
         // classical Gram-Schmidt: all projections against the un-updated w, four per block reduction.  (The squared norm of
         // the orthogonalised vector is NOT taken from ||w||^2 - sum h_k^2: classical Gram-Schmidt loses orthogonality as
         // the residual falls towards 1e-10 and that identity then misjudges h_{j+1,j} - measured: the recurrence residual
         // stops tracking the true one and every solve runs to maxiter.)
-        for (int k0 = 0; k0 <= jj; k0 += 4) {
+        // Positions of a block: 0 = v_jj (still in registers), 1 = v_0 (first cycle: b / beta, recomputed from registers), then
+        // v_1 .. v_{jj-1} read back from the basis in one branch-free run of loads.
+        auto v0elem = [&](int j) {
+          if (cycle == 0) return make_double2(b[j].x * ibeta, b[j].y * ibeta);
+          return Vg[at_use<EPE>(st.it[j])];
+        };
+        for (int p0 = 0; p0 <= jj; p0 += 4) {
           double h4[4] = {0.0, 0.0, 0.0, 0.0};
-          const int nk = min(4, jj + 1 - k0);
-          for (int q = 0; q < nk; q++) {
+          const int np = min(4, jj + 1 - p0);
+          int q0 = 0;
+          if (p0 == 0) {
+#pragma unroll
+            for (int j = 0; j < EPT; j++)
+              if (ok(j)) h4[0] += w[j].x * v[j].x + w[j].y * v[j].y;
+            q0 = 1;
+            if (jj >= 1) {
+#pragma unroll
+              for (int j = 0; j < EPT; j++)
+                if (ok(j)) {
+                  const double2 vk = v0elem(j);
+                  h4[1] += w[j].x * vk.x + w[j].y * vk.y;
+                }
+              q0 = 2;
+            }
+          }
+          for (int q = q0; q < np; q++) {
 #pragma unroll
             for (int j = 0; j < EPT; j++)
               if (ok(j)) {
-                const double2 vk = Vg[(size_t)(k0 + q) * dim + at_use<EPE>(st.it[j])];
+                const double2 vk = Vg[(size_t)(p0 + q - 1) * dim + at_use<EPE>(st.it[j])];
                 h4[q] += w[j].x * vk.x + w[j].y * vk.y;
               }
           }
-          switch (nk) {  // as many values as there are projections in this block (the first iterations have 1, 2, 3)
+          switch (np) {  // as many values as there are projections in this block (the first iterations have 1, 2, 3)
             case 1: sum<1>(reinterpret_cast<double(&)[1]>(h4)); break;
             case 2: sum<2>(reinterpret_cast<double(&)[2]>(h4)); break;
             case 3: sum<3>(reinterpret_cast<double(&)[3]>(h4)); break;
             default: sum<4>(h4); break;
           }
-          for (int q = 0; q < nk; q++) hc[k0 + q] = h4[q];
+          for (int q = 0; q < np; q++) hc[p0 + q == 0 ? jj : p0 + q - 1] = h4[q];
         }
-        for (int k = 0; k <= jj; k++) {
+        {
+          const double h = hc[jj];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            w[j].x -= h * v[j].x;
+            w[j].y -= h * v[j].y;
+          }
+        }
+        if (jj >= 1) {
+          const double h = hc[0];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            const double2 vk = v0elem(j);
+            w[j].x -= h * vk.x;
+            w[j].y -= h * vk.y;
+          }
+        }
+        for (int k = 1; k < jj; k++) {
           const double h = hc[k];
 #pragma unroll
           for (int j = 0; j < EPT; j++) {
@@ -1976,12 +2031,6 @@ struct Team {
         const double hn2 = nn[0];
         const double hn = sqrt(fmax(hn2, 0.0));
         hc[jj + 1] = hn;
-        const double ihn = hn > 0.0 ? 1.0 / hn : 0.0;
-#pragma unroll
-        for (int j = 0; j < EPT; j++) {
-          v[j] = make_double2(w[j].x * ihn, w[j].y * ihn);
-          if (ok(j)) Vg[(size_t)(jj + 1) * dim + at_use<EPE>(st.it[j])] = v[j];
-        }
         // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
         double cur_h = hc[0];
         for (int k = 0; k < jj; k++) {
@@ -2000,9 +2049,16 @@ struct Team {
         gcur = -sj * gcur;
         its++;
         jj++;
-        publish(v);  // v_{jj} becomes the stencil-readable vector; its barriers also order the scalar writes
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
-        if (its >= A.maxiter) break;
+        if (its >= A.maxiter || jj >= MRE) break;
+        // the next basis vector is only formed, stored and published when another iteration follows
+        const double ihn = 1.0 / hn;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          v[j] = make_double2(w[j].x * ihn, w[j].y * ihn);
+          if (ok(j)) Vg[(size_t)jj * dim + at_use<EPE>(st.it[j])] = v[j];
+        }
+        publish(v);  // v_{jj} becomes the stencil-readable vector; its barriers also order the scalar writes
       }
       for (int rw = jj - 1; rw >= 0; rw--) {
         double sacc = g[rw];
@@ -2011,27 +2067,23 @@ struct Team {
       }
 #pragma unroll
       for (int j = 0; j < EPT; j++) yy[j] = make_double2(0.0, 0.0);
-      for (int cc = 0; cc < jj; cc++) {
-        const double f = yk[cc];
+      if (jj >= 1) {
+        const double f = yk[0];
+        const bool fromb = poly == 1 && cycle == 0;
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
-          const double2 vk = Vg[(size_t)cc * dim + at_use<EPE>(st.it[j])];
+          const double2 vk = fromb ? make_double2(b[j].x * ibeta, b[j].y * ibeta) : Sg[at_use<EPE>(st.it[j])];
           yy[j].x += f * vk.x;
           yy[j].y += f * vk.y;
         }
       }
-      // this cycle's correction y = P u
-      if (poly > 1) {
+      for (int cc = 1; cc < jj; cc++) {
+        const double f = yk[cc];
 #pragma unroll
-        for (int j = 0; j < EPT; j++) w[j] = yy[j];
-        for (int i = 1; i < poly; i++) {
-          publish(w);
-          amul(w);
-#pragma unroll
-          for (int j = 0; j < EPT; j++) {
-            yy[j].x += w[j].x;
-            yy[j].y += w[j].y;
-          }
+        for (int j = 0; j < EPT; j++) {
+          const double2 vk = Sg[(size_t)cc * dim + at_use<EPE>(st.it[j])];
+          yy[j].x += f * vk.x;
+          yy[j].y += f * vk.y;
         }
       }
       if (conv || its >= A.maxiter) break;

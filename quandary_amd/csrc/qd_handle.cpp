@@ -558,7 +558,7 @@ int qd_handle::traj_doubles(int nb, size_t* n) const {
 // max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
 // by their amplitude).  QD_GMRES_POLY overrides the degree (1 = never precondition).
 int qd_handle::gmres_poly_degree() const {
-  const int want = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : 6;  // degree sweep: DESIGN.md section 2
+  const int want = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : poly_cur;  // tuned in forward_finish
   // only where the Krylov basis traffic is the cost (dim > 1024: the column / eight-elements-per-thread kernels); below
   // that plain GMRES keeps the oracle's iteration path, and with it results that agree far below the solver tolerance
   if (want <= 1 || S.dense || S.dim <= 1024) return 1;
@@ -677,6 +677,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   }
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
+  last_poly = a.gmres_poly;
   a.x0 = dx0;
   a.xT = d_xT.p;
   a.traj = store ? d_traj.p : nullptr;
@@ -684,6 +685,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   a.dpdm_out = d_dpdm;
   a.napply = d_napply;
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+  last_var = cfg.var;
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
   if (cfg.gmres == 2) {
@@ -718,6 +720,24 @@ int qd_handle::forward_finish(double* energy) {
   QD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
   last_fwd_ms = accumulate_fwd_ms ? last_fwd_ms + ms : ms;
   last_mean_applies = (double)nap / ((double)nb * (double)tg.ntime);  // per TIME step (all stages of a composite step)
+  // Degree p of the polynomial preconditioner (Team::gmres_g): a solve costs 1 + k p applications plus k rounds of
+  // orthogonalisation, reductions and basis traffic (k = Krylov vectors; on the 3x20 workload one such round costs as much as five
+  // applications), so the best p is the smallest one for which (almost) every solve needs a single Krylov vector.  k is known after
+  // every forward sweep: bracket p between the largest degree seen with k > 1 and the smallest seen with k = 1, bisect, stay.
+  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && last_var != 16 && sol.stepper != QD_STEPPER_EE && !getenv("QD_GMRES_POLY")) {
+    const double per_solve = (double)nap / ((double)nb * (double)nsub);
+    const double k = (per_solve - 1.0) / last_poly;
+    if (k > 1.02) {
+      poly_lo = std::max(poly_lo, last_poly);
+      if (poly_hi && poly_hi <= poly_lo) poly_hi = 0;  // (the controls have moved: the old bracket no longer holds)
+      poly_cur = poly_hi ? (poly_lo + poly_hi + 1) / 2 : std::min(32, (int)std::ceil(last_poly * k));
+      if (poly_cur <= poly_lo) poly_cur = std::min(32, poly_lo + 1);
+    } else {
+      poly_hi = poly_hi ? std::min(poly_hi, last_poly) : last_poly;
+      if (poly_lo >= poly_hi) poly_lo = 1;
+      poly_cur = poly_hi - poly_lo > 1 ? (poly_lo + poly_hi) / 2 : poly_hi;
+    }
+  }
   last_nb = nb;
   traj_valid = store;
   pending_store = false;
@@ -827,6 +847,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   }
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
+  last_poly = a.gmres_poly;
   a.stash = d_stash.p;
   a.traj = d_traj.p;
   a.xbarT = dxbarT;

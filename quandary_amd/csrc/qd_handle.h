@@ -128,7 +128,9 @@ struct qd_handle {
 
   // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
   int refresh_tables();
-  int gmres_poly_degree() const;  // 4 where the Neumann series provably contracts for the current parameters, else 1
+  int gmres_poly_degree() const;  // > 1 where the Neumann series provably contracts for the current parameters, else 1
+  // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
+  int poly_cur = 6, poly_lo = 1, poly_hi = 0, last_poly = 1, last_var = 0;
   int traj_doubles(int nb, size_t* n) const;
   // forward sweep on device-resident states; results stay on the device (d_pen, d_dpdm, d_xT, d_out4)
   int forward_dev(const double* dx0, int nb, bool store, const qd::DevTarget* tg, double* energy);

@@ -354,7 +354,7 @@ struct Team32 {
       for (int j = 0; j < EPT; j++) {
         v[j].x = r[j].x * ibeta;
         v[j].y = r[j].y * ibeta;
-        Vg[opaque(elem(j))] = v[j];
+        if (cycle > 0) Vg[opaque(elem(j))] = v[j];  // (first cycle: v_0 = b / beta is recomputed from registers)
       }
       publish(v);
       double gcur = beta;
@@ -371,22 +371,65 @@ struct Team32 {
         }
         // projections, up to 8 per block reduction (the norm of the orthogonalised vector is reduced separately: the identity
         // ||w - sum h_k v_k||^2 = ||w||^2 - sum h_k^2 breaks down with the orthogonality of classical Gram-Schmidt)
-        for (int k0 = 0; k0 <= jj; k0 += 8) {
+        // Positions of a block: 0 = v_jj (still in registers), 1 = v_0 (first cycle: b / beta, recomputed from registers), then
+        // v_1 .. v_{jj-1} read back from the basis in one branch-free run of loads.
+        auto v0elem = [&](int j) {
+          f2 vk;
+          if (cycle == 0) {
+            vk.x = b[j].x * ibeta;
+            vk.y = b[j].y * ibeta;
+          } else {
+            vk = Vg[opaque(elem(j))];
+          }
+          return vk;
+        };
+        for (int p0 = 0; p0 <= jj; p0 += 8) {
           double h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          const int nk = min(8, jj + 1 - k0);
-          for (int q = 0; q < nk; q++) {
+          const int np = min(8, jj + 1 - p0);
+          int q0 = 0;
+          if (p0 == 0) {
+#pragma unroll
+            for (int j = 0; j < EPT; j++) h8[0] += (double)w[j].x * v[j].x + (double)w[j].y * v[j].y;
+            q0 = 1;
+            if (jj >= 1) {
+#pragma unroll
+              for (int j = 0; j < EPT; j++) {
+                const f2 vk = v0elem(j);
+                h8[1] += (double)w[j].x * vk.x + (double)w[j].y * vk.y;
+              }
+              q0 = 2;
+            }
+          }
+          for (int q = q0; q < np; q++) {
 #pragma unroll
             for (int j = 0; j < EPT; j++) {
-              const f2 vk = Vg[(size_t)(k0 + q) * DIM + opaque(elem(j))];
+              const f2 vk = Vg[(size_t)(p0 + q - 1) * DIM + opaque(elem(j))];
               h8[q] += (double)w[j].x * vk.x + (double)w[j].y * vk.y;
             }
           }
-          if (nk <= 2) sum<2>(reinterpret_cast<double(&)[2]>(h8));
-          else if (nk <= 4) sum<4>(reinterpret_cast<double(&)[4]>(h8));
+          if (np <= 2) sum<2>(reinterpret_cast<double(&)[2]>(h8));
+          else if (np <= 4) sum<4>(reinterpret_cast<double(&)[4]>(h8));
           else sum<8>(h8);
-          for (int q = 0; q < nk; q++) hc[k0 + q] = h8[q];
+          for (int q = 0; q < np; q++) hc[p0 + q == 0 ? jj : p0 + q - 1] = h8[q];
         }
-        for (int k = 0; k <= jj; k++) {
+        {
+          const R h = (R)hc[jj];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            w[j].x -= h * v[j].x;
+            w[j].y -= h * v[j].y;
+          }
+        }
+        if (jj >= 1) {
+          const R h = (R)hc[0];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            const f2 vk = v0elem(j);
+            w[j].x -= h * vk.x;
+            w[j].y -= h * vk.y;
+          }
+        }
+        for (int k = 1; k < jj; k++) {
           const R h = (R)hc[k];
 #pragma unroll
           for (int j = 0; j < EPT; j++) {
@@ -402,13 +445,6 @@ struct Team32 {
         const double hn2 = nn[0];
         const double hn = sqrt(fmax(hn2, 0.0));
         hc[jj + 1] = hn;
-        const R ihn = (R)(hn > 0.0 ? 1.0 / hn : 0.0);
-#pragma unroll
-        for (int j = 0; j < EPT; j++) {
-          v[j].x = w[j].x * ihn;
-          v[j].y = w[j].y * ihn;
-          Vg[(size_t)(jj + 1) * DIM + opaque(elem(j))] = v[j];
-        }
         // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
         double cur_h = hc[0];
         for (int k = 0; k < jj; k++) {
@@ -427,16 +463,39 @@ struct Team32 {
         gcur = -sj * gcur;
         its++;
         jj++;
-        publish(v);  // v_{jj} becomes the stencil-readable vector; its barrier also orders the scalar writes
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
-        if (its >= A.maxiter) break;
+        if (its >= A.maxiter || jj >= MR) break;
+        // the next basis vector is only formed, stored and published when another iteration follows
+        const R ihn = (R)(1.0 / hn);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          v[j].x = w[j].x * ihn;
+          v[j].y = w[j].y * ihn;
+          Vg[(size_t)jj * DIM + opaque(elem(j))] = v[j];
+        }
+        publish(v);  // v_{jj} becomes the stencil-readable vector; its barrier also orders the scalar writes
       }
       for (int rw = jj - 1; rw >= 0; rw--) {
         double sacc = g[rw];
         for (int cc = rw + 1; cc < jj; cc++) sacc -= Rm[rw * MR + cc] * yk[cc];
         yk[rw] = sacc / Rm[rw * MR + rw];
       }
-      for (int cc = 0; cc < jj; cc++) {
+      if (jj >= 1) {
+        const R f = (R)yk[0];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          f2 vk;
+          if (cycle == 0) {
+            vk.x = b[j].x * ibeta;
+            vk.y = b[j].y * ibeta;
+          } else {
+            vk = Vg[opaque(elem(j))];
+          }
+          yy[j].x += f * vk.x;
+          yy[j].y += f * vk.y;
+        }
+      }
+      for (int cc = 1; cc < jj; cc++) {
         const R f = (R)yk[cc];
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
