@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 on one GPU, 3 on several)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 3 / 1)")
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "q4", "c4", "c5", "d4"],
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "q4", "c4", "c5", "d4", "l20"],
                     help="default: c2 on one GPU, c4 on several")
     ap.add_argument("--mode", default=None, choices=["fwd", "grad"], help="default: fwd on one GPU, grad on several")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32mixed"],
