@@ -454,9 +454,14 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       int its;
       const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
       napply += its;
+      double* zdst = A.ztraj ? A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim : nullptr;
       for (int e = tid; e < dim; e += nt) {
         const double2 k = K[e];
         double2 v = X[e];
+        if (zdst) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
+          zdst[e] = fma(0.5 * c.h, k.x, v.x);
+          zdst[dim + e] = fma(0.5 * c.h, k.y, v.y);
+        }
         v.x = fma(c.h, k.x, v.x);
         v.y = fma(c.h, k.y, v.y);
         X[e] = v;
@@ -541,8 +546,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   if (!tm.init(S, smem, A.nb)) return;
   const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
   double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
-  double2 *X = W, *B = W + dim, *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *Z = W + 6 * (size_t)dim, *KB = W + 7 * (size_t)dim,
-          *XB = W + 8 * (size_t)dim;
+  double2 *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *Z = W + 6 * (size_t)dim, *KB = W + 7 * (size_t)dim, *XB = W + 8 * (size_t)dim;
   const double* traj = A.traj;
   auto state = [&](int s, int e) {
     const double* src = traj + ((size_t)s * A.nb + ic) * 2 * dim;
@@ -611,23 +615,15 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     scalarize<Q>(c, jpairs);
     c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
-    for (int e = tid; e < dim; e += nt) X[e] = state(s, e);
-    tm.tsync();
     double cf[2 * Q];
 #pragma unroll
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
-    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694)
-    for (int e = tid; e < dim; e += nt) B[e] = tm.template apply<false>(S, c, X, e);
-    tm.tsync();
-    int its;
+    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z = x + h/2 k (:640-652) was stored by the forward sweep
     {
-      const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
-      for (int e = tid; e < dim; e += nt) {
-        const double2 k = K[e], x = X[e];
-        Z[e] = make_double2(fma(0.5 * c.h, k.x, x.x), fma(0.5 * c.h, k.y, x.y));
-      }
+      const double* zsrc = A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim;
+      for (int e = tid; e < dim; e += nt) Z[e] = make_double2(zsrc[e], zsrc[dim + e]);
     }
-    tm.tsync();
+    int its;
     {
       const double2* K = tm.template solve<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
       for (int e = tid; e < dim; e += nt) {

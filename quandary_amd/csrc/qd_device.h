@@ -2229,6 +2229,15 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
           x[j] = make_double2(xs[e], xs[dim + e]);
         }
       }
+      if (A.ztraj) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (tm.ok(j)) {
+            double* dst = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
+            dst[tm.st.it[j]] = fma(0.5 * c.h, k[j].x, x[j].x);
+            dst[dim + tm.st.it[j]] = fma(0.5 * c.h, k[j].y, x[j].y);
+          }
+      }
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         x[j].x = fma(c.h, k[j].x, x[j].x);
@@ -2421,7 +2430,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 #pragma unroll
       for (int j = 0; j < EPT; j++) x[j] = xnext[CARRY ? j : 0];
       if (s > 0) load_state(s - 1, reinterpret_cast<double2(&)[EPT]>(xnext));
-    } else {
+    } else if (A.stepper_ee) {
       load_state(s, x);
     }
     // ---- penalty adjoints at the end of a full step, using the primal x_n (timestepper.cpp:220-227)
@@ -2543,46 +2552,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         xb[j].y = fma(c.h, t[j].y, xb[j].y);
       }
     } else {
-      // ImplMidpoint::evolveBWD (timestepper.cpp:631-694).  The two linear solves are independent; the
-      // primal one goes first so that x and rhs are dead during the adjoint solve (register pressure of
-      // the several-elements-per-thread variants).
-      tm.publish(x);
-      double2 z[EPT];  // primal stage: (I - h/2 M) k = M x ; z = x + h/2 k
-      constexpr bool STASH = TM::V::LEAN;  // explicit staging through L2/HBM while a solve runs (see SweepArgs::stash)
-      auto park = [&](int slot, const double2(&v)[EPT]) {
-#pragma unroll
-        for (int j = 0; j < EPT; j++)
-          if (tm.ok(j)) {
-            double* d = A.stash + ((size_t)slot * A.nb + tm.ic(j)) * 2 * dim;
-            const int e = at_use<TM::EPE>(tm.st.it[j]);
-            d[e] = v[j].x;
-            d[dim + e] = v[j].y;
-          }
-      };
-      auto unpark = [&](int slot, double2(&v)[EPT]) {
-#pragma unroll
-        for (int j = 0; j < EPT; j++) {
-          const double* d = A.stash + ((size_t)slot * A.nb + tm.ic(j)) * 2 * dim;
-          const int e = at_use<TM::EPE>(tm.st.it[j]);
-          v[j] = make_double2(d[e], d[dim + e]);
-        }
-      };
-      {
-        double2 rhs[EPT];
-        tm.template apply_all<false>(S, c, x, rhs);
-        if (STASH) park(0, xb);  // xbar is dead weight during the primal solve; x is re-read from the trajectory
-        tm.template solve<false>(A, c, 0.5 * c.h, rhs, z);
-      }
-      if (STASH) load_state(s, x);
-#pragma unroll
-      for (int j = 0; j < EPT; j++) {
-        z[j].x = fma(0.5 * c.h, z[j].x, x[j].x);
-        z[j].y = fma(0.5 * c.h, z[j].y, x[j].y);
-      }
-      if (STASH) {
-        park(1, z);
-        unpark(0, xb);
-      }
+      // ImplMidpoint::evolveBWD (timestepper.cpp:631-694).  The reference repeats the forward solve of the sub-step to get the
+      // primal stage z = x + h/2 k (:640-652); here the forward sweep has stored z next to the trajectory (SweepArgs::ztraj,
+      // the same solve on the same data: identical values), so only the adjoint solve remains and neither x nor z is alive
+      // while it runs.
       double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
       tm.template solve<true>(A, c, 0.5 * c.h, xb, kb);
 #pragma unroll
@@ -2590,7 +2563,12 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         kb[j].x *= c.h;
         kb[j].y *= c.h;
       }
-      if (STASH) unpark(1, z);
+      double2 z[EPT];
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double* src = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
+        z[j] = make_double2(src[tm.st.it[j]], src[dim + tm.st.it[j]]);
+      }
       tm.publish(z);
       // gradient coefficients: x^T dM/dp_k z and x^T dM/dq_k z with x := kbar
 #pragma unroll

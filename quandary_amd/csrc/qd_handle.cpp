@@ -65,7 +65,7 @@ extern "C" void qd_destroy(qd_handle* h) {
   (void)hipSetDevice(h->device);
   struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   for (DBuf* b : {&h->d_params, &h->d_tbar, &h->d_tred, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
-                  &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_res,
+                  &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_ztraj, &h->d_res,
                   &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_ecoef, &h->d_edig, &h->d_work, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
@@ -552,6 +552,13 @@ int qd_handle::traj_doubles(int nb, size_t* n) const {
   return QD_OK;
 }
 
+size_t qd_handle::ztraj_doubles(int nb) const {
+  if (sol.stepper == QD_STEPPER_EE) return 0;
+  size_t n = (size_t)nsub * (size_t)nb * 2 * (size_t)S.dim;
+  if (precision == QD_PRECISION_F32MIXED) n /= 2;
+  return n;
+}
+
 // Degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (Team::gmres_g): 4 where the series
 // provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
 // sub-step, from the system constants and the CURRENT control parameters (|p_k(t)|, |q_k(t)| <= sum over carriers of
@@ -670,6 +677,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     size_t nt;
     traj_doubles(nb, &nt);
     if ((r = d_traj.ensure(nt))) return r;
+    if (ztraj_doubles(nb) && (r = d_ztraj.ensure(ztraj_doubles(nb)))) return r;
   }
   {
     LaunchCfg c0 = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
@@ -681,6 +689,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   a.x0 = dx0;
   a.xT = d_xT.p;
   a.traj = store ? d_traj.p : nullptr;
+  a.ztraj = store && ztraj_doubles(nb) ? d_ztraj.p : nullptr;
   a.pen_out = d_pen;
   a.dpdm_out = d_dpdm;
   a.napply = d_napply;
@@ -850,6 +859,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   last_poly = a.gmres_poly;
   a.stash = d_stash.p;
   a.traj = d_traj.p;
+  a.ztraj = ztraj_doubles(nb) ? d_ztraj.p : nullptr;
   a.xbarT = dxbarT;
   a.jbar = djbar;
   a.coeff = d_coeff.p;

@@ -114,6 +114,7 @@ struct qd_handle {
   qd::DBuf d_tstates, d_purity;
   int target_nb = 0;
   // sweep buffers
+  qd::DBuf d_ztraj;  // stored primal stages (SweepArgs::ztraj)
   qd::DBuf d_x0, d_xT, d_traj, d_res, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
   qd::DBuf d_ecoef, d_edig, d_work;  // large states (qd_big.h): element table, work vectors
   int ensure_big(int nb);            // no-op unless the launch configuration is the large-state variant
@@ -132,6 +133,7 @@ struct qd_handle {
   // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
   int poly_cur = 6, poly_lo = 1, poly_hi = 0, last_poly = 1, last_var = 0;
   int traj_doubles(int nb, size_t* n) const;
+  size_t ztraj_doubles(int nb) const;  // 0 for explicit Euler
   // forward sweep on device-resident states; results stay on the device (d_pen, d_dpdm, d_xT, d_out4)
   int forward_dev(const double* dx0, int nb, bool store, const qd::DevTarget* tg, double* energy);
   // the same in two halves: enqueue only / synchronise and collect (lets the caller queue the reductions, the adjoint

@@ -85,6 +85,9 @@ struct SweepArgs {
   const double* x0;  // [nb][2*dim]
   double* xT;        // [nb][2*dim]
   double* traj;      // [(nsub+1)][nb][2*dim] or nullptr
+  // primal stages z_s = x_s + h/2 k_s of the implicit-midpoint family, [nsub][nb][2*dim], stored with the trajectory: the adjoint
+  // sweep reads them instead of repeating the forward solve of every sub-step (ImplMidpoint::evolveBWD, timestepper.cpp:640-652)
+  double* ztraj;
   double* pen_out;   // [nb]
   double* dpdm_out;  // [nb]
   unsigned long long* napply;

@@ -512,12 +512,14 @@ static double control_variation(const qd_handle* h, const double* alpha, double*
 static bool trajectory_fits(qd_handle* h, int nb) {
   size_t need;
   h->traj_doubles(nb, &need);
+  const size_t needz = h->ztraj_doubles(nb);  // the stored primal stages travel with the trajectory
+  need += needz;
   if (const char* ev = getenv("QD_TRAJ_BUDGET_MB"))  // test hook: pretend HBM is this small
     return (double)need * sizeof(double) <= atof(ev) * 1048576.0;
-  if (need <= h->d_traj.cap) return true;
+  if (need - needz <= h->d_traj.cap && needz <= h->d_ztraj.cap) return true;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-  const size_t avail = free_b + h->d_traj.cap * sizeof(double);
+  const size_t avail = free_b + (h->d_traj.cap + h->d_ztraj.cap) * sizeof(double);
   return (double)need * sizeof(double) < 0.85 * (double)avail;
 }
 

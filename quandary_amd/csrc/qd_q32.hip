@@ -592,6 +592,16 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
     napply += 1 + tm.template solve<false>(A, (R)0.5 * hf, rhs, k);
     tm.unpark(x);
     const double h = to_scalar(c.h);
+    if (A.ztraj) {  // the primal stage z = x + h/2 k in R, as the adjoint sweep would recompute it: stored instead
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const f2 xr = to_r2<R>(x[j]);
+        f2 z;
+        z.x = rfma((R)0.5 * hf, k[j].x, xr.x);
+        z.y = rfma((R)0.5 * hf, k[j].y, xr.y);
+        Traj<R>::store(A.ztraj, (size_t)s * A.nb + ic, DIM, tm.elem(j), z);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {  // x += h k: fp64 accumulation of the stage
       x[j].x = fma(h, (double)k[j].x, x[j].x);
@@ -675,26 +685,9 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
     tm.st.prep(c);
     const R hf = uniform((R)c.h);
-    f2 x[EPT], z[EPT];
-#pragma unroll
-    for (int j = 0; j < EPT; j++) x[j] = Traj<R>::load(A.traj, (size_t)s * A.nb + ic, DIM, tm.elem(j));
-    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694): primal stage (I - h/2 M) k = M x ; z = x + h/2 k
-    tm.publish(x);
+    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694).  The primal stage z = x + h/2 k of the sub-step (:640-652) was stored by
+    // the forward sweep (SweepArgs::ztraj): only the adjoint solve remains.
     tm.park(xb);  // the fp64 adjoint accumulators are dead weight until xbar += M^T kbar
-    {
-      f2 rhs[EPT];
-      tm.template apply_all<false>(x, rhs);
-      tm.template solve<false>(A, (R)0.5 * hf, rhs, z);
-    }
-    if (TM::PARK) {  // x is cheaper to re-read (L2) than to keep across the solve
-#pragma unroll
-      for (int j = 0; j < EPT; j++) x[j] = Traj<R>::load(A.traj, (size_t)s * A.nb + ic, DIM, opaque(tm.elem(j)));
-    }
-#pragma unroll
-    for (int j = 0; j < EPT; j++) {
-      z[j].x = rfma((R)0.5 * hf, z[j].x, x[j].x);
-      z[j].y = rfma((R)0.5 * hf, z[j].y, x[j].y);
-    }
     // adjoint stage (I - h/2 M)^T kbar = xbar ; kbar *= h
     f2 kb[EPT], bb[EPT];
     if (TM::PARK) {
@@ -711,6 +704,9 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
       kb[j].y *= hf;
     }
     // gradient coefficients x^T dM/dp_k z, x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604): products in R, fp64 sums
+    f2 z[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) z[j] = Traj<R>::load(A.ztraj, (size_t)s * A.nb + ic, DIM, tm.elem(j));
     tm.publish(z);
     double cf[2 * Q];
 #pragma unroll
