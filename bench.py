@@ -268,7 +268,9 @@ class Runner:
         f_apply = flops_per_apply(spec)
         f_step = mean_applies * f_apply + (12.0 * max(mean_applies - 1.0, 0.0) + 4.0) * dim
         if self.mode == "grad":
-            f_step *= 3.0  # adjoint step = two more solves of the same size + the gradient contraction (~1 apply)
+            # adjoint step = ONE more solve of the same size (the transposed one: the primal stage is read back, not re-solved),
+            # the gradient contraction (~1 application) and xbar += M^T kbar (1 application, booked with the solve's first one)
+            f_step = 2.0 * f_step + f_apply
         valu_peak = FP32_PEAK_TFLOPS if self.dtype == "f32mixed" else fp64_peak
         valu_achieved = f_step * units_per_launch / kern_s / 1e12
         roof = {
