@@ -849,7 +849,6 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   int r;
   const size_t ncol = (size_t)nsub * 2 * S.Q;
   if ((r = d_coeff.ensure((size_t)nb * ncol)) || (r = d_coeffsum.ensure(ncol))) return r;
-  if ((r = d_stash.ensure((size_t)2 * nb * 2 * S.dim))) return r;
   {
     LaunchCfg c0 = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, true);
     if (c0.var == 16 && (r = ensure_big(nb))) return r;
@@ -857,7 +856,6 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   last_poly = a.gmres_poly;
-  a.stash = d_stash.p;
   a.traj = d_traj.p;
   a.ztraj = ztraj_doubles(nb) ? d_ztraj.p : nullptr;
   a.xbarT = dxbarT;
