@@ -287,10 +287,10 @@ struct BigTeam {
         t1[0] += v.x * v.x + v.y * v.y;
       }
       sum<1>(t1);
-      const double beta = sqrt(t1[0]);
+      const double ibeta = t1[0] > 0.0 ? rsqrt_nr(t1[0]) : 0.0;
+      const double beta = t1[0] * ibeta;
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) break;
-      const double ibeta = 1.0 / beta;
       for (int e = tid; e < dim; e += nt) {
         const double2 v = r[e];
         Vg[e] = make_double2(v.x * ibeta, v.y * ibeta);
@@ -333,7 +333,8 @@ struct BigTeam {
           nn[0] += w.x * w.x + w.y * w.y;
         }
         sum<1>(nn);
-        const double hn = sqrt(nn[0]);
+        const double ihn = nn[0] > 0.0 ? rsqrt_nr(nn[0]) : 0.0;
+        const double hn = nn[0] * ihn;
         hc[jj + 1] = hn;
         double cur_h = hc[0];  // Givens rotations: redundantly by every thread on uniform values, idempotent LDS writes only
         for (int k = 0; k < jj; k++) {
@@ -342,12 +343,12 @@ struct BigTeam {
           cur_h = -sk * cur_h + ck * a1;
         }
         const double a0 = cur_h, bb = hn;
-        const double rr = sqrt(a0 * a0 + bb * bb);
-        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
-        const double cj = rr == 0.0 ? 1.0 : a0 * irr, sj = bb * irr;
+        const double s2 = a0 * a0 + bb * bb;
+        const double irr = s2 > 0.0 ? rsqrt_nr(s2) : 0.0;
+        const double cj = s2 > 0.0 ? a0 * irr : 1.0, sj = bb * irr;
         cs[jj] = cj;
         sn[jj] = sj;
-        Rm[jj * MR + jj] = rr;
+        Rm[jj * MR + jj] = irr;  // the diagonal is only ever divided by: keep its reciprocal
         g[jj] = cj * gcur;
         gcur = -sj * gcur;
         its++;
@@ -355,7 +356,6 @@ struct BigTeam {
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter || jj >= MR) break;
         // the next basis vector is only formed and stored when another iteration follows
-        const double ihn = 1.0 / hn;
         for (int e = tid; e < dim; e += nt) {
           const double2 w = Wv[e];
           Vg[(size_t)jj * dim + e] = make_double2(w.x * ihn, w.y * ihn);
@@ -365,7 +365,7 @@ struct BigTeam {
       for (int rw = jj - 1; rw >= 0; rw--) {
         double sacc = g[rw];
         for (int cc = rw + 1; cc < jj; cc++) sacc -= Rm[rw * MR + cc] * yk[cc];
-        yk[rw] = sacc / Rm[rw * MR + rw];
+        yk[rw] = sacc * Rm[rw * MR + rw];
       }
       for (int e = tid; e < dim; e += nt) {
         double2 y = Ysol[e];

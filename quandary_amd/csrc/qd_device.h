@@ -121,6 +121,17 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// 1 / sqrt(x), x > 0, to fp64 round-off without fp64 sqrt or division (~40 dependent instructions each): v_rsq_f64 estimate and two
+// Newton steps.  The Hessenberg scalars of the in-kernel GMRES are computed redundantly by every lane on uniform values: their
+// dependent latency is paid in full by the latency-bound small systems.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
 // value of the next (UP = true) / previous lane of the wave; lanes without a source get 0
 template <bool UP>
 __device__ __forceinline__ double lane_shift(double v) {
@@ -1762,10 +1773,10 @@ struct Team {
     for (int cycle = 0;; cycle++) {
       double t[1] = {on ? r.x * r.x + r.y * r.y : 0.0};
       sum<1>(t);
-      const double beta = sqrt(t[0]);
+      const double ibeta = t[0] > 0.0 ? rsqrt_nr(t[0]) : 0.0;
+      const double beta = t[0] * ibeta;
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) break;
-      const double ibeta = 1.0 / beta;  // one reciprocal instead of two fp64 divisions
       double2 v = make_double2(r.x * ibeta, r.y * ibeta);
       if (on) Vb[e] = v;
       double gcur = beta;  // last entry of the rotated right-hand side
@@ -1806,7 +1817,8 @@ struct Team {
         }
         double nn[1] = {on ? w.x * w.x + w.y * w.y : 0.0};
         sum<1>(nn);
-        const double hn = sqrt(nn[0]);
+        const double ihn = nn[0] > 0.0 ? rsqrt_nr(nn[0]) : 0.0;
+        const double hn = nn[0] * ihn;
         hc[j + 1] = hn;
         // Givens rotations on the new column, update of the rotated right-hand side.  Every thread does
         // this redundantly on wave-uniform values; LDS locations are only ever written with values that
@@ -1819,12 +1831,12 @@ struct Team {
           cur_h = -sk * cur_h + ck * a1;
         }
         const double a = cur_h, bb = hn;
-        const double rr = sqrt(a * a + bb * bb);
-        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
-        const double cj = rr == 0.0 ? 1.0 : a * irr, sj = bb * irr;
+        const double s2 = a * a + bb * bb;
+        const double irr = s2 > 0.0 ? rsqrt_nr(s2) : 0.0;
+        const double cj = s2 > 0.0 ? a * irr : 1.0, sj = bb * irr;
         cs[j] = cj;
         sn[j] = sj;
-        R[j * GMRES_MR + j] = rr;
+        R[j * GMRES_MR + j] = irr;  // the diagonal is only ever divided by: keep its reciprocal
         g[j] = cj * gcur;
         gcur = -sj * gcur;
         its++;
@@ -1832,7 +1844,6 @@ struct Team {
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter || j >= GMRES_MR) break;
         // the next basis vector is only formed and stored when another iteration follows
-        const double ihn = 1.0 / hn;
         v = make_double2(w.x * ihn, w.y * ihn);
         if (on) Vb[(size_t)j * dim + e] = v;
         team_sync<V::ONEWAVE>();  // v_{j} is readable by every thread
@@ -1841,7 +1852,7 @@ struct Team {
       for (int rw = j - 1; rw >= 0; rw--) {
         double sacc = g[rw];
         for (int cc = rw + 1; cc < j; cc++) sacc -= R[rw * GMRES_MR + cc] * yk[cc];
-        yk[rw] = sacc / R[rw * GMRES_MR + rw];
+        yk[rw] = sacc * R[rw * GMRES_MR + rw];
       }
       for (int cc = 0; cc < j; cc++) {
         const double2 vk = Vb[(size_t)cc * dim + e];
@@ -1913,14 +1924,14 @@ struct Team {
 #pragma unroll
       for (int j = 0; j < EPT; j++) t1[0] += ok(j) ? r[j].x * r[j].x + r[j].y * r[j].y : 0.0;
       sum<1>(t1);
-      const double beta = sqrt(t1[0]);
+      const double ibeta = t1[0] > 0.0 ? rsqrt_nr(t1[0]) : 0.0;
+      const double beta = t1[0] * ibeta;
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) {
 #pragma unroll
         for (int j = 0; j < EPT; j++) yy[j] = make_double2(0.0, 0.0);
         break;
       }
-      const double ibeta = 1.0 / beta;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         v[j] = make_double2(r[j].x * ibeta, r[j].y * ibeta);
@@ -2028,8 +2039,8 @@ struct Team {
 #pragma unroll
         for (int j = 0; j < EPT; j++) nn[0] += ok(j) ? w[j].x * w[j].x + w[j].y * w[j].y : 0.0;
         sum<1>(nn);
-        const double hn2 = nn[0];
-        const double hn = sqrt(fmax(hn2, 0.0));
+        const double ihn = nn[0] > 0.0 ? rsqrt_nr(nn[0]) : 0.0;
+        const double hn = nn[0] * ihn;
         hc[jj + 1] = hn;
         // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
         double cur_h = hc[0];
@@ -2039,12 +2050,12 @@ struct Team {
           cur_h = -sk * cur_h + ck * a1;
         }
         const double a0 = cur_h, bb = hn;
-        const double rr = sqrt(a0 * a0 + bb * bb);
-        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
-        const double cj = rr == 0.0 ? 1.0 : a0 * irr, sj = bb * irr;
+        const double s2 = a0 * a0 + bb * bb;
+        const double irr = s2 > 0.0 ? rsqrt_nr(s2) : 0.0;
+        const double cj = s2 > 0.0 ? a0 * irr : 1.0, sj = bb * irr;
         cs[jj] = cj;
         sn[jj] = sj;
-        R[jj * GMRES_MR_G + jj] = rr;
+        R[jj * GMRES_MR_G + jj] = irr;  // the diagonal is only ever divided by: keep its reciprocal
         g[jj] = cj * gcur;
         gcur = -sj * gcur;
         its++;
@@ -2052,7 +2063,6 @@ struct Team {
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter || jj >= MRE) break;
         // the next basis vector is only formed, stored and published when another iteration follows
-        const double ihn = 1.0 / hn;
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
           v[j] = make_double2(w[j].x * ihn, w[j].y * ihn);
@@ -2063,7 +2073,7 @@ struct Team {
       for (int rw = jj - 1; rw >= 0; rw--) {
         double sacc = g[rw];
         for (int cc = rw + 1; cc < jj; cc++) sacc -= R[rw * GMRES_MR_G + cc] * yk[cc];
-        yk[rw] = sacc / R[rw * GMRES_MR_G + rw];
+        yk[rw] = sacc * R[rw * GMRES_MR_G + rw];
       }
 #pragma unroll
       for (int j = 0; j < EPT; j++) yy[j] = make_double2(0.0, 0.0);

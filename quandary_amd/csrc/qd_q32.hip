@@ -346,10 +346,11 @@ struct Team32 {
 #pragma unroll
       for (int j = 0; j < EPT; j++) t1[0] += (double)r[j].x * r[j].x + (double)r[j].y * r[j].y;
       sum<1>(t1);
-      const double beta = sqrt(t1[0]);
+      const double ibeta_d = t1[0] > 0.0 ? rsqrt_nr(t1[0]) : 0.0;
+      const double beta = t1[0] * ibeta_d;
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) break;
-      const R ibeta = (R)(1.0 / beta);
+      const R ibeta = (R)ibeta_d;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         v[j].x = r[j].x * ibeta;
@@ -442,8 +443,8 @@ struct Team32 {
 #pragma unroll
         for (int j = 0; j < EPT; j++) nn[0] += (double)w[j].x * w[j].x + (double)w[j].y * w[j].y;
         sum<1>(nn);
-        const double hn2 = nn[0];
-        const double hn = sqrt(fmax(hn2, 0.0));
+        const double ihn_d = nn[0] > 0.0 ? rsqrt_nr(nn[0]) : 0.0;
+        const double hn = nn[0] * ihn_d;
         hc[jj + 1] = hn;
         // Givens rotations: redundantly by every thread on wave-uniform values, idempotent LDS writes only
         double cur_h = hc[0];
@@ -453,12 +454,12 @@ struct Team32 {
           cur_h = -sk * cur_h + ck * a1;
         }
         const double a0 = cur_h, bb = hn;
-        const double rr = sqrt(a0 * a0 + bb * bb);
-        const double irr = rr == 0.0 ? 0.0 : 1.0 / rr;
-        const double cj = rr == 0.0 ? 1.0 : a0 * irr, sj = bb * irr;
+        const double s2 = a0 * a0 + bb * bb;
+        const double irr = s2 > 0.0 ? rsqrt_nr(s2) : 0.0;
+        const double cj = s2 > 0.0 ? a0 * irr : 1.0, sj = bb * irr;
         cs[jj] = cj;
         sn[jj] = sj;
-        Rm[jj * MR + jj] = rr;
+        Rm[jj * MR + jj] = irr;  // the diagonal is only ever divided by: keep its reciprocal
         g[jj] = cj * gcur;
         gcur = -sj * gcur;
         its++;
@@ -466,7 +467,7 @@ struct Team32 {
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter || jj >= MR) break;
         // the next basis vector is only formed, stored and published when another iteration follows
-        const R ihn = (R)(1.0 / hn);
+        const R ihn = (R)ihn_d;
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
           v[j].x = w[j].x * ihn;
@@ -478,7 +479,7 @@ struct Team32 {
       for (int rw = jj - 1; rw >= 0; rw--) {
         double sacc = g[rw];
         for (int cc = rw + 1; cc < jj; cc++) sacc -= Rm[rw * MR + cc] * yk[cc];
-        yk[rw] = sacc / Rm[rw * MR + rw];
+        yk[rw] = sacc * Rm[rw * MR + rw];
       }
       if (jj >= 1) {
         const R f = (R)yk[0];
