@@ -2203,9 +2203,9 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (tm.ok(j)) {
-          double* dst = traj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-          dst[tm.st.it[j]] = x[j].x;
-          dst[dim + tm.st.it[j]] = x[j].y;
+          double* dst = traj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;  // written once, read by the adjoint sweep much later:
+          __builtin_nontemporal_store(x[j].x, dst + tm.st.it[j]);        // streaming stores, the caches keep the solver's vectors
+          __builtin_nontemporal_store(x[j].y, dst + dim + tm.st.it[j]);
         }
     }
     // rhs = M x   (ImplMidpoint::evolveFWD, timestepper.cpp:594; ExplEuler :502)
@@ -2244,8 +2244,8 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
         for (int j = 0; j < EPT; j++)
           if (tm.ok(j)) {
             double* dst = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-            dst[tm.st.it[j]] = fma(0.5 * c.h, k[j].x, x[j].x);
-            dst[dim + tm.st.it[j]] = fma(0.5 * c.h, k[j].y, x[j].y);
+            __builtin_nontemporal_store(fma(0.5 * c.h, k[j].x, x[j].x), dst + tm.st.it[j]);
+            __builtin_nontemporal_store(fma(0.5 * c.h, k[j].y, x[j].y), dst + dim + tm.st.it[j]);
           }
       }
 #pragma unroll
@@ -2367,7 +2367,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       const double* src = traj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-      dst[j] = make_double2(src[tm.st.it[j]], src[dim + tm.st.it[j]]);
+      dst[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
     }
   };
 #pragma unroll
@@ -2577,7 +2577,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         const double* src = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-        z[j] = make_double2(src[tm.st.it[j]], src[dim + tm.st.it[j]]);
+        z[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
       }
       tm.publish(z);
       // gradient coefficients: x^T dM/dp_k z and x^T dM/dq_k z with x := kbar

@@ -536,17 +536,25 @@ template <> __device__ __forceinline__ double2 to_r2<double>(const double2 v) { 
 // Stored trajectory.  fp32-mixed: [nsub+1][nb][dim] interleaved float2; fp64: the layout of every other fp64 kernel and of
 // qd_get_state, [nsub+1][nb][2 dim] blocked [u ; v].
 template <typename R> struct Traj;
+// (trajectory and stored stages are written once and read by the adjoint sweep much later: streaming stores / loads)
+typedef float traj_f2 __attribute__((ext_vector_type(2)));
 template <> struct Traj<float> {
-  __device__ __forceinline__ static void store(double* base, size_t state, int dim, int e, float2 v) { reinterpret_cast<float2*>(base)[state * dim + e] = v; }
-  __device__ __forceinline__ static float2 load(const double* base, size_t state, int dim, int e) { return reinterpret_cast<const float2*>(base)[state * dim + e]; }
+  __device__ __forceinline__ static void store(double* base, size_t state, int dim, int e, float2 v) {
+    traj_f2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<traj_f2*>(base) + state * dim + e);
+  }
+  __device__ __forceinline__ static float2 load(const double* base, size_t state, int dim, int e) {
+    const traj_f2 t = __builtin_nontemporal_load(reinterpret_cast<const traj_f2*>(base) + state * dim + e);
+    return make_float2(t.x, t.y);
+  }
 };
 template <> struct Traj<double> {
   __device__ __forceinline__ static void store(double* base, size_t state, int dim, int e, double2 v) {
-    base[state * 2 * dim + e] = v.x;
-    base[state * 2 * dim + dim + e] = v.y;
+    __builtin_nontemporal_store(v.x, base + state * 2 * dim + e);
+    __builtin_nontemporal_store(v.y, base + state * 2 * dim + dim + e);
   }
   __device__ __forceinline__ static double2 load(const double* base, size_t state, int dim, int e) {
-    return make_double2(base[state * 2 * dim + e], base[state * 2 * dim + dim + e]);
+    return make_double2(__builtin_nontemporal_load(base + state * 2 * dim + e), __builtin_nontemporal_load(base + state * 2 * dim + dim + e));
   }
 };
 
