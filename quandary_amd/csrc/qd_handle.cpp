@@ -559,8 +559,8 @@ size_t qd_handle::ztraj_doubles(int nb) const {
   return n;
 }
 
-// Degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (Team::gmres_g): 4 where the series
-// provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
+// Degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (Team::gmres_g): poly_cur (tuned from sweep to
+// sweep in forward_finish, starting at 6) where the series provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
 // sub-step, from the system constants and the CURRENT control parameters (|p_k(t)|, |q_k(t)| <= sum over carriers of
 // max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
 // by their amplitude).  QD_GMRES_POLY overrides the degree (1 = never precondition).
