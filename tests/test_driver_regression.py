@@ -235,3 +235,24 @@ def test_driver_step_and_spline_amplitude_segments(tmp_path):
     (tmp_path / "a" / "ampg.cfg").write_text(text)
     r = subprocess.run([EXE, "ampg.cfg", "--quiet"], cwd=tmp_path / "a", capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "no gradient in the reference" in r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_driver_large_state_runs_on_a_team_of_workgroups(tmp_path):
+    """One pure initial condition of the 10x10 Lindblad system (dim 10 000 > 4096) through the config-file driver: the global-memory
+    sweeps with a team of workgroups (cooperative launch from the C++ process), gradient against the oracle."""
+    from helpers import synthetic_cfg
+    from oracle.oracle import Oracle
+    from quandary_amd import config
+
+    text = synthetic_cfg([10, 10], lindblad=True, ntime=4, nspline=5, target="pure", objective="Jfrobenius", init="pure, 0, 1", penalties=True)
+    (tmp_path / "big.cfg").write_text(text)
+    r = subprocess.run([EXE, "big.cfg", "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sp = config.build_spec(config.parse_config_text(text))
+    orc = Oracle(sp)
+    oval, og = orc.evalGradF(sp.params0)
+    g = _load(tmp_path / "data_out" / "grad.dat").ravel()
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    assert _load(tmp_path / "data_out" / "optim_history.dat")[0][1] == pytest.approx(oval["objective"], rel=REF_RTOL)
+    orc.close()
