@@ -76,6 +76,7 @@ struct BigTeam {
   int G, member, ic, gtid, gnt, gslot;
   unsigned long long* bar;
   unsigned long long bar_target, sub_target;  // (thread 0 only)
+  double2* scratch;  // one more work vector of the state (polynomial preconditioner of gmres)
   double* gred;
 
   static size_t lds_bytes(const DevSys& S) {
@@ -106,6 +107,7 @@ struct BigTeam {
     bar_target = 0;
     sub_target = 0;
     gred = S.tred + (size_t)ic * 2 * BIG_TEAM_MAX * BIG_RED_NV;
+    scratch = reinterpret_cast<double2*>(S.work) + ((size_t)ic * BIG_NV + 9) * dim;  // slot 9: unused by both sweeps
     coef = reinterpret_cast<const double2*>(S.ecoef);
     dig = reinterpret_cast<const uint2*>(S.edig);
     const int tl = table_len(S);
@@ -275,6 +277,13 @@ struct BigTeam {
     double* g = sn + MR;
     double* Rm = g + (MR + 2);
     double* yk = Rm + MR * MR;
+    // A.gmres_poly = p > 1: right preconditioning with the Neumann polynomial (Team::gmres_g of qd_device.h: GMRES on
+    // (I - alpha M) P = I - (alpha M)^p, the preconditioned vectors z_j = P v_j stored next to the basis, restart 14).  Every team
+    // barrier and reduction saved counts double here: one Krylov vector per solve once the host has tuned p (forward_finish).
+    const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
+    const int MRE = poly > 1 ? (MR - 2) / 2 : MR;
+    double2* Zg = Vg + (size_t)(MRE + 1) * dim;
+    const double2* Sg = poly > 1 ? Zg : Vg;
     for (int e = tid; e < dim; e += nt) Ysol[e] = make_double2(0.0, 0.0);
     int its = 0, napp = 0;
     double ttol = 0.0;
@@ -299,11 +308,24 @@ struct BigTeam {
       double gcur = beta;
       int jj = 0;
       bool conv = false;
-      while (jj < MR) {
+      while (jj < MRE) {
         const double2* vj = Vg + (size_t)jj * dim;
-        for (int e = tid; e < dim; e += nt) {
-          const double2 t = apply<TRANS>(A.S, c, vj, e);
-          const double2 v = vj[e];
+        // z = P v_jj by Horner's rule (z <- v + alpha M z, p - 1 times), alternating between the scratch vector and z's final place
+        const double2* z = vj;
+        for (int i = 1; i < poly; i++) {
+          double2* dst = ((poly - 1 - i) & 1) ? scratch : Zg + (size_t)jj * dim;
+          for (int e = tid; e < dim; e += nt) {
+            const double2 t = apply<TRANS>(A.S, c, z, e);
+            const double2 v = vj[e];
+            dst[e] = make_double2(fma(alpha, t.x, v.x), fma(alpha, t.y, v.y));
+          }
+          napp++;
+          tsync();
+          z = dst;
+        }
+        for (int e = tid; e < dim; e += nt) {  // w = (I - alpha M) z
+          const double2 t = apply<TRANS>(A.S, c, z, e);
+          const double2 v = z[e];
           Wv[e] = make_double2(v.x - alpha * t.x, v.y - alpha * t.y);
         }
         napp++;
@@ -354,7 +376,7 @@ struct BigTeam {
         its++;
         jj++;
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
-        if (its >= A.maxiter || jj >= MR) break;
+        if (its >= A.maxiter || jj >= MRE) break;
         // the next basis vector is only formed and stored when another iteration follows
         for (int e = tid; e < dim; e += nt) {
           const double2 w = Wv[e];
@@ -371,7 +393,7 @@ struct BigTeam {
         double2 y = Ysol[e];
         for (int cc = 0; cc < jj; cc++) {
           const double f = yk[cc];
-          const double2 vk = Vg[(size_t)cc * dim + e];
+          const double2 vk = Sg[(size_t)cc * dim + e];
           y.x += f * vk.x;
           y.y += f * vk.y;
         }

@@ -733,7 +733,7 @@ int qd_handle::forward_finish(double* energy) {
   // orthogonalisation, reductions and basis traffic (k = Krylov vectors; on the 3x20 workload one such round costs as much as five
   // applications), so the best p is the smallest one for which (almost) every solve needs a single Krylov vector.  k is known after
   // every forward sweep: bracket p between the largest degree seen with k > 1 and the smallest seen with k = 1, bisect, stay.
-  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && last_var != 16 && sol.stepper != QD_STEPPER_EE && !getenv("QD_GMRES_POLY")) {
+  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && !getenv("QD_GMRES_POLY")) {
     const double per_solve = (double)nap / ((double)nb * (double)nsub);
     const double k = (per_solve - 1.0) / last_poly;
     if (k > 1.02) {
