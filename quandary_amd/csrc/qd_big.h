@@ -230,14 +230,15 @@ struct BigTeam {
   template <bool TRANS>
   __device__ __forceinline__ double2* neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
                                               double2* Yb, int* iters) {
-    for (int e = gtid; e < dim; e += gnt) Ya[e] = Bv[e];
-    tsync();
+    // y_0 = b is read in place (the caller has put a team barrier behind the last write to Bv); the iterates alternate Ya / Yb
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
     const float rel2 = (float)(A.reltol * A.reltol);
     float d0 = 1.f;
-    int iter;
-    double2 *cur = Ya, *nxt = Yb;
+    int iter, wb = 0;
+    double2* const bufs[2] = {Ya, Yb};
+    const double2* cur = Bv;
     for (iter = 0; iter < A.maxiter; iter++) {
+      double2* nxt = bufs[wb];
       double dl = 0.0;
       for (int e = gtid; e < dim; e += gnt) {
         const double2 t = apply<TRANS>(A.S, c, cur, e);
@@ -250,15 +251,14 @@ struct BigTeam {
         nxt[e] = w;
       }
       const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the (team) barrier and its fences
-      double2* t2 = cur;
       cur = nxt;
-      nxt = t2;
+      wb ^= 1;
       if (iter == 0) d0 = d;
       if (d < 1.f) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
     }
     *iters = iter;
-    return cur;
+    return const_cast<double2*>(cur);
   }
 
   // GMRES (KSPGMRES + PCNONE of the reference, as Team::gmres_g with p = 1): zero initial guess, classical Gram-Schmidt,
@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
         }
         XB[e] = xb;
       }
+      tm.tsync();  // the adjoint solve reads xbar in place
     }
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
