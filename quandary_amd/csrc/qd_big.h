@@ -1,9 +1,8 @@
 // qd_big.h — sweeps for states that do not fit one CU's LDS (dim > 4096): the reference's matrix-free templates go up to
 // <20,20> (Lindblad dim 160 000), <4,4,4,4> (65 536) and <3,3,3,3,3> (59 049) (src/mastereq.cpp:3046-3047, :3150-3151, :3202).
 // A team of G workgroups (1024 threads each; G = 1 when the batch alone fills the chip) owns one initial condition for the whole
-// time loop; the vectors of the step
-// (state, right-hand side, solver iterates, adjoint state, ...) live in a per-state work area in global memory and
-// are exchanged through L2 (4 MiB per XCD; workgroup-scope visibility through the fences of __syncthreads()).  Each
+// time loop; the vectors of the step (state, right-hand side, solver iterates, adjoint state, ...) live in a per-state work area
+// in global memory and are exchanged through L2 (G = 1: workgroup-scope visibility through the fences of __syncthreads()).  Each
 // thread loops over its elements; the per-element invariants (digits, Delta, d) come from a table built once per
 // system (k_big_table) instead of registers.  The stencil itself is GenStencil::apply / ::ladder of qd_device.h with the
 // element's invariants loaded into the (one-slot) stencil object - the same code that the LDS kernels run.
@@ -13,10 +12,9 @@
 // agent-scope release / acquire: L2 write-back and invalidate, so the exchange is correct across XCDs) and every reduction
 // goes through per-workgroup partial sums that all members add up in the same order (bit-identical scalars in all members:
 // the solver's control flow stays uniform over the team).  The members of a team are consecutive blocks, i.e. dealt over all
-// eight XCDs (measured 2-3x faster than a team kept on ONE XCD - member j of team t = block 8 (G (t / 8) + j) + t % 8, selected
+// eight XCDs (measured 1.3-2x faster than a team kept on ONE XCD - member j of team t = block 8 (G (t / 8) + j) + t % 8, selected
 // with S.team_spread = 0 - which shares one L2 but also one XCD's share of the fabric: profiles/r2_big_probe.jsonl).  The kernel
-// is launched cooperatively (co-residency is checked by the
-// runtime: a team that cannot be resident is an error, never a hang).
+// is launched cooperatively (co-residency is checked by the runtime: a team that cannot be resident is an error, never a hang).
 #pragma once
 #include <type_traits>
 
