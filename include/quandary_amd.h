@@ -348,8 +348,9 @@ int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* alpha, qd_obj
  * Arithmetic of the sweeps.  QD_PRECISION_F64 (default): everything IEEE double like the reference.
  * QD_PRECISION_F32MIXED (BASELINE config 5): the exchange vector in LDS, the stencil arithmetic, the linear-solver
  * iterates and the stored trajectory are fp32; the state / adjoint-state accumulators, every norm, objective sum and
- * gradient coefficient are fp64.  Built for all-qubit Lindblad systems with 4 or 5 oscillators, Neumann solver, IMR
- * family; QD_ERR_UNSUPPORTED elsewhere.  Call before the first sweep.
+ * gradient coefficient are fp64.  Built for all-qubit Lindblad systems with 4 or 5 oscillators, both linear solvers
+ * (GMRES: Krylov basis as float2, Hessenberg problem in fp64), IMR family; QD_ERR_UNSUPPORTED elsewhere.  Call before
+ * the first sweep.
  * ------------------------------------------------------------------------- */
 enum { QD_PRECISION_F64 = 0, QD_PRECISION_F32MIXED = 1 };
 int qd_set_precision(qd_handle* h, int precision);

@@ -378,8 +378,8 @@ extern "C" int qd_set_precision(qd_handle* h, int precision) {
     bool qubits = S.lindblad && !S.dense && (S.Q == 4 || S.Q == 5);
     for (int k = 0; k < S.Q; k++) qubits = qubits && S.n[k] == 2 && S.ness[k] == 2;
     if (!qubits || S.hasJ) return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps are built for all-qubit Lindblad systems with 4 or 5 oscillators without dipole-dipole coupling");
-    if (h->sol.linsolve != QD_LINSOLVE_NEUMANN || h->sol.stepper == QD_STEPPER_EE)
-      return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps need the Neumann solver and a stepper of the IMR family");
+    if (h->sol.stepper == QD_STEPPER_EE)
+      return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps need a stepper of the IMR family");
   }
   h->precision = precision;
   h->traj_valid = false;
@@ -697,7 +697,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   last_var = cfg.var;
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
-  if (cfg.gmres == 2) {
+  if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
@@ -864,7 +864,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
-  if (cfg.gmres == 2) {
+  if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }

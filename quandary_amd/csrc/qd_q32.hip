@@ -22,6 +22,8 @@
 // Neumann :697-727, time loops :96-253, weighted-J penalty :256-339, gradient coefficients include/mastereq.hpp:553-604.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "qd_device.h"
 
 namespace qd {
@@ -348,7 +350,9 @@ struct Team32 {
       sum<1>(t1);
       const double ibeta_d = t1[0] > 0.0 ? rsqrt_nr(t1[0]) : 0.0;
       const double beta = t1[0] * ibeta_d;
-      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+      // fp32 vectors: the true residual stalls near 2^-22 ||b|| while the recurrence residual keeps falling - the same floor as
+      // the fp32 Neumann iteration's stopping rule
+      if (cycle == 0) ttol = fmax(fmax(A.reltol * beta, A.abstol), std::is_same<R, float>::value ? (double)F32_SOLVER_TOL * beta : 0.0);
       if (beta <= ttol || its >= A.maxiter) break;
       const R ibeta = (R)ibeta_d;
 #pragma unroll
@@ -562,7 +566,7 @@ template <> struct Traj<double> {
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
 template <int Q, int SB, typename R, bool GM = false>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_forward_q32(const SweepArgs A) {
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (GM && sizeof(R) == 4 ? 1 : 0))) k_forward_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team32<Q, SB, R, GM> TM;
   typedef typename TM::f2 f2;
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
 template <int Q, int SB, typename R, bool GM = false>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_adjoint_q32(const SweepArgs A) {
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (GM && sizeof(R) == 4 ? 1 : 0))) k_adjoint_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team32<Q, SB, R, GM> TM;
   typedef typename TM::f2 f2;
@@ -962,12 +966,22 @@ static hipError_t go_app(const DevSys& S, const double* ctlrow, int tr, const do
 
 hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q);
+  if (a.use_gmres) {  // Krylov basis in global memory as float2, Hessenberg problem in fp64
+    if (a.S.Q == 5) return go_fwd<5, 2, float, true>(a, st);
+    if (a.S.Q == 4) return go_fwd<4, 0, float, true>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (a.S.Q == 5) return go_fwd<5, 2, float>(a, st);
   if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2, float>(a, st) : go_fwd<4, 0, float>(a, st);
   return hipErrorInvalidValue;
 }
 hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q);
+  if (a.use_gmres) {
+    if (a.S.Q == 5) return go_adj<5, 2, float, true>(a, st);
+    if (a.S.Q == 4) return go_adj<4, 0, float, true>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (a.S.Q == 5) return go_adj<5, 2, float>(a, st);
   if (a.S.Q == 4) return sb == 2 ? go_adj<4, 2, float>(a, st) : go_adj<4, 0, float>(a, st);
   return hipErrorInvalidValue;
