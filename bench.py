@@ -318,6 +318,7 @@ EXTRA = [
     ("c5", "grad", "neumann", "f64", {}, 2),
     ("c5", "fwd", "neumann", "f32mixed", {}, 3),
     ("c5", "grad", "neumann", "f32mixed", {}, 2),
+    ("c5", "fwd", "gmres", "f32mixed", {}, 2),
     ("c4", "fwd", "neumann", "f64", {"ntime": 250}, 2),
     ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1),
     ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1),  # = the 1-GPU point of the `--gpus N` strong-scaling series
