@@ -509,6 +509,19 @@ def main():
                         else:
                             os.environ[k2] = v2
                 out["workloads"].append(ent)
+    if rank == 0 and multi and not weak:
+        # The same workload on ONE GPU (rank 0 alone, after the timed region): the one-GPU point of this strong-scaling series in
+        # the same line - the default one-GPU invocation of this script times BASELINE config 2 instead.
+        ref = {"note": "rank 0 alone on the whole batch, same run, outside the timed region"}
+        try:
+            r1 = Runner(name, mode, over, args.dtype, 0, 1, local_rank, False, None)
+            el1, km1, _ = r1.time(1, 1, lambda: torch.cuda.synchronize())
+            v1, _, _ = r1.report(el1, km1, mean_applies, 1, 0.0)
+            r1.close()
+            ref.update({"value": v1, "ms_per_step": el1 * 1e3, "speedup": value / v1, "n_gpus": world})
+        except (Exception, SystemExit) as e:  # noqa: BLE001
+            ref["error"] = f"{type(e).__name__}: {e}"
+        out["same_workload_one_gpu"] = ref
     if comm is not None:
         comm.barrier()
         comm.close()
