@@ -231,6 +231,8 @@ DENSE_SHAPES = [
     # N = 16 Lindblad: the matrix-core kernel (v_mfma_f64_16x16x4_f64)
     pytest.param(dict(nlevels=[4, 4], lindblad=True, nessential=[3, 3], target="pure", objective="Jfrobenius", init="diagonal, 0"), id="dense-4x4-lindblad-mfma"),
     pytest.param(dict(nlevels=[2, 2, 2, 2], lindblad=True, init="diagonal, 0, 1"), id="dense-2^4-lindblad-mfma"),
+    # N = 32 Lindblad (dim 1024): the largest dense operator of the LDS kernels (vector arithmetic; matrix cores only for N = 16)
+    pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True, init="diagonal, 0"), id="dense-2^5-lindblad-dim1024"),
 ]
 
 
