@@ -73,7 +73,10 @@ template <> struct Variant<14> : VariantDef<4, 256, true, false, 1, true, true, 
 template <> struct Variant<15> : VariantDef<4, 64, false, true, 1, false, false, true, false, true> {};
 // V16: states beyond one CU's LDS (dim > 4096): work vectors in global memory, exchanged through L2 (qd_big.h)
 template <> struct Variant<16> : VariantDef<1, 1024, false, false> {};
-constexpr int NVARIANTS = 17;
+// V17: dense operator of a 32 x 32 density matrix (dim 1024) on the fp64 matrix cores: four waves, one 16 x 16 tile of rho each
+// (PACKED marks the two-tiles-per-dimension form of the matrix-core stencil)
+template <> struct Variant<17> : VariantDef<4, 256, true, false, 1, false, false, true, true, true> {};
+constexpr int NVARIANTS = 18;
 // BLDS: the right-hand side of the linear solve is parked in a second LDS vector instead of registers
 // (large elements-per-thread variants would otherwise spill)
 
@@ -1383,6 +1386,108 @@ struct DenseMfmaStencil : DenseStencil<Q, true, 4, 4> {
   }
 };
 
+// The same for N = 32 (dim 1024): four waves, wave w owns the 16 x 16 tile (row tile w & 1, column tile w >> 1) of rho in the
+// accumulator layout; eight K-slabs per product, G's row block / column block of the tile in registers for the sub-step (both
+// orientations: the transposed real operator needs G^H), rho's operands from the published LDS vector (16 reads per lane and
+// application against 128 per element of the vector formulation): 64 MFMA instructions per wave and application.
+template <int Q>
+struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
+  typedef DenseStencil<Q, true, 4, 4> Base;
+  static constexpr bool WHOLE = true;
+  static constexpr int N = 32, EPT = 4, NS = 8;
+  using Base::dbra;
+  using Base::dd;
+  using Base::dig;
+  using Base::dket;
+  using Base::it;
+  using Base::ofs;
+  using Base::valid;
+  int r0, c0;              // first row / column of this wave's tile
+  double2 gA[NS], gB[NS];    // G[r0 + lo][4 s + hi], G[4 s + hi][c0 + lo]
+  double2 gAh[NS], gBh[NS];  // G^H at the same places: conj(G[4 s + hi][r0 + lo]), conj(G[c0 + lo][4 s + hi])
+  double l1f[EPT][Q], l1t[EPT][Q];
+
+  __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
+    Base::init(S, L);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    r0 = 16 * (w & 1);
+    c0 = 16 * (w >> 1);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int I = r0 + (lane >> 4) + 4 * j, Ip = c0 + (lane & 15);
+      it[j] = Ip * N + I;
+      valid[j] = true;
+      int ia[Q], ipa[Q];
+      dbra[j] = 0;
+      dket[j] = 0;
+      double d = 0.0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        ia[k] = (I / S.post[k]) % S.n[k];
+        ipa[k] = (Ip / S.post[k]) % S.n[k];
+        dbra[j] |= (unsigned)ia[k] << (Base::DB * k);
+        dket[j] |= (unsigned)ipa[k] << (Base::DB * k);
+        d += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
+        const bool up = ia[k] < S.n[k] - 1 && ipa[k] < S.n[k] - 1;
+        l1f[j][k] = up ? S.g1off[k] * sqrt((double)(ia[k] + 1)) * sqrt((double)(ipa[k] + 1)) : 0.0;
+        l1t[j][k] = S.g1off[k] * sqrt((double)ia[k]) * sqrt((double)ipa[k]);
+      }
+      dd[j] = d;
+    }
+  }
+
+  __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>& c) {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      gA[s] = c.g[(r0 + lo) * N + 4 * s + hi];
+      gB[s] = c.g[(4 * s + hi) * N + c0 + lo];
+      const double2 a = c.g[(4 * s + hi) * N + r0 + lo], b = c.g[(c0 + lo) * N + 4 * s + hi];
+      gAh[s] = make_double2(a.x, -a.y);
+      gBh[s] = make_double2(b.x, -b.y);
+    }
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ void apply_whole(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>&,
+                                              const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    mfma_d4 ar = {0.0, 0.0, 0.0, 0.0}, ai = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      // first product: Gt rho; A operand Gt[r0 + lo][4 s + hi] from registers, B operand rho[4 s + hi][c0 + lo] from LDS
+      const double2 ga = TRANS ? gAh[s] : gA[s];
+      const double2 pb = sx[(c0 + lo) * N + 4 * s + hi];
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(ga.x, pb.x, ar, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-ga.y, pb.y, ar, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(ga.x, pb.y, ai, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(ga.y, pb.x, ai, 0, 0, 0);
+      // second product: - rho Gt; A operand rho[r0 + lo][4 s + hi] from LDS, B operand Gt[4 s + hi][c0 + lo] from registers
+      const double2 pa = sx[(4 * s + hi) * N + r0 + lo];
+      const double2 gb = TRANS ? gBh[s] : gB[s];
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.x, gb.x, ar, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, gb.y, ar, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.x, gb.y, ai, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.y, gb.x, ai, 0, 0, 0);
+    }
+    const int top = S.dim - 1;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      double yr = fma(dd[j], x[j].x, ar[j]), yi = fma(dd[j], x[j].y, ai[j]);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        if (S.g1off[k] == 0.0) continue;  // wave-uniform
+        const int st = S.post[k] * (N + 1);
+        const double l1 = TRANS ? l1t[j][k] : l1f[j][k];
+        const double2 xn = sx[TRANS ? max(it[j] - st, 0) : min(it[j] + st, top)];
+        yr = fma(l1, xn.x, yr);
+        yi = fma(l1, xn.y, yi);
+      }
+      y[j] = make_double2(yr, yi);
+    }
+  }
+};
+
 template <int Q, bool LIND, int EPT, int EPE, bool QUBIT, bool COL = false, bool DENSE = false, bool PACKED = false, bool MFMA = false>
 struct StencilSel { typedef GenStencil<Q, LIND, EPT, EPE> type; };
 template <int Q, bool LIND, int EPT, int EPE>
@@ -1395,6 +1500,8 @@ template <int Q, bool LIND, int EPT, int EPE>
 struct StencilSel<Q, LIND, EPT, EPE, false, false, true, false, false> { typedef DenseStencil<Q, LIND, EPT, EPE> type; };
 template <int Q>
 struct StencilSel<Q, true, 4, 4, false, false, true, false, true> { typedef DenseMfmaStencil<Q> type; };
+template <int Q>
+struct StencilSel<Q, true, 4, 4, false, false, true, true, true> { typedef DenseMfma32Stencil<Q> type; };
 
 template <typename ST, typename = void> struct has_split_fetch { static constexpr bool value = false; };
 template <typename ST> struct has_split_fetch<ST, decltype((void)ST::SPLIT_FETCH)> { static constexpr bool value = ST::SPLIT_FETCH; };
@@ -1412,6 +1519,8 @@ template <int Q, bool LIND, int EPT, int EPE>
 __device__ __forceinline__ bool slot_valid(const DenseStencil<Q, LIND, EPT, EPE>& st, int j) { return st.valid[j]; }
 template <int Q>
 __device__ __forceinline__ bool slot_valid(const DenseMfmaStencil<Q>& st, int j) { return st.valid[j]; }
+template <int Q>
+__device__ __forceinline__ bool slot_valid(const DenseMfma32Stencil<Q>& st, int j) { return st.valid[j]; }
 
 // ---------------------------------------------------------------------------------------------
 // objective pieces evaluated on register-resident states (OptimTarget::evalJ / evalJ_diff)

@@ -34,7 +34,7 @@ constexpr bool variant_built() {
   // least two levels: dim >= 2^Q, or 4^Q for Lindblad) - the five-oscillator Lindblad unit alone took 6 minutes
   constexpr long kMinDim = kLind ? (1L << (2 * QD_Q)) : (1L << QD_Q);
   constexpr bool fits0 = kMinDim <= 64, fits1 = kMinDim <= 256, fits2 = kMinDim <= 1024;
-  if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4) || VAR == 16;
+  if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4) || (kLind && VAR == 17 && QD_Q <= 5) || VAR == 16;
   if (!kQubit) return (VAR == 0 && fits0) || (VAR == 1 && fits1) || (VAR == 2 && fits2) || VAR == 4 || (kLind && (VAR == 9 || VAR == 14)) || VAR == 16;
   if (kQubitDim <= 64) return VAR == 0;
   if (kQubitDim <= 256) return VAR == 1;
@@ -135,6 +135,7 @@ static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream
     case 13: return FN<13>(__VA_ARGS__);     \
     case 14: return FN<14>(__VA_ARGS__);     \
     case 15: return FN<15>(__VA_ARGS__);     \
+    case 17: return FN<17>(__VA_ARGS__);     \
     case 16: return FN<16>(__VA_ARGS__);     \
     default: return hipErrorInvalidValue;    \
   }

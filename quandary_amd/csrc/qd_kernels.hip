@@ -429,7 +429,7 @@ constexpr VarInfo var_info() {
 static const VarInfo kVar[NVARIANTS] = {var_info<0>(), var_info<1>(), var_info<2>(),  var_info<3>(),  var_info<4>(),
                                         var_info<5>(), var_info<6>(), var_info<7>(),  var_info<8>(),  var_info<9>(),
                                         var_info<10>(), var_info<11>(), var_info<12>(), var_info<13>(), var_info<14>(),
-                                        var_info<15>(), var_info<16>()};
+                                        var_info<15>(), var_info<16>(), var_info<17>()};
 int variant_max_block(int var) { return (var >= 0 && var < NVARIANTS) ? kVar[var].maxb : 0; }
 
 void big_team(const DevSys& S, int nb, int& team, int& spread);
@@ -453,7 +453,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
     return (dim + (kVar[v].ept / kVar[v].icpb) - 1) / (kVar[v].ept / kVar[v].icpb) <= kVar[v].maxb;
   };
   auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
-    if (S.dense) return (v >= 11 && v <= 13) || (v == 15 && S.lindblad && S.N == 16);
+    if (S.dense) return (v >= 11 && v <= 13) || (v == 15 && S.lindblad && S.N == 16) || (v == 17 && S.lindblad && S.N == 32);
     if (!qubit) return v <= 2 || v == 4 || (S.lindblad && (v == 9 || v == 14));
     return dim <= 64 ? v == 0 : dim <= 256 ? v == 1 : v == 2;
   };
@@ -468,6 +468,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   // matrix cores for the sweeps whose cost is the operator; the adjoint's gradient contraction (2Q commutators per
   // step) is faster spread over four waves (measured: gradient 59.8 ms with V12 vs 83.2 ms with V15)
   if (S.dense && S.lindblad && S.N == 16 && !adjoint) var = 15;
+  if (S.dense && S.lindblad && S.N == 32 && !adjoint && !getenv("QD_NO_MFMA32")) var = 17;
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
