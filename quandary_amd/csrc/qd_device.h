@@ -1384,6 +1384,45 @@ struct DenseMfmaStencil : DenseStencil<Q, true, 4, 4> {
       y[j] = make_double2(yr, yi);
     }
   }
+
+  // Gradient contraction on the matrix cores: A = [Im(Hc_k), z], B = [Re(Hc_k), z] for the thread's four elements (DenseStencil::
+  // ladder element by element: 2 N products per element and oscillator).  z's operands of the eight K-slabs are read from the
+  // published vector once and serve every oscillator; Hc_k is real: 8 instead of 16 products per slab and commutator pair.
+  struct ZOps {
+    double2 pb[4], pa[4];
+  };
+  __device__ __forceinline__ void ladder_fetch(const double2* __restrict__ sx, ZOps& z) const {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      z.pb[s] = sx[lo * N + 4 * s + hi];
+      z.pa[s] = sx[(4 * s + hi) * N + lo];
+    }
+  }
+  __device__ __forceinline__ void ladder_whole(const DevSys& S, const ZOps& z, int k, double2 (&Av)[EPT], double2 (&Bv)[EPT]) const {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const double* __restrict__ hr = S.hcr + (size_t)k * N * N;
+    const double* __restrict__ hm = S.hci + (size_t)k * N * N;
+    mfma_d4 Ar = {0.0, 0.0, 0.0, 0.0}, Ai = Ar, Br = Ar, Bi = Ar;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int il = lo * N + 4 * s + hi, ir = (4 * s + hi) * N + lo;
+      const double hmL = hm[il], hrL = hr[il], hmR = hm[ir], hrR = hr[ir];
+      Ar = __builtin_amdgcn_mfma_f64_16x16x4f64(hmL, z.pb[s].x, Ar, 0, 0, 0);
+      Ai = __builtin_amdgcn_mfma_f64_16x16x4f64(hmL, z.pb[s].y, Ai, 0, 0, 0);
+      Br = __builtin_amdgcn_mfma_f64_16x16x4f64(hrL, z.pb[s].x, Br, 0, 0, 0);
+      Bi = __builtin_amdgcn_mfma_f64_16x16x4f64(hrL, z.pb[s].y, Bi, 0, 0, 0);
+      Ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].x, hmR, Ar, 0, 0, 0);
+      Ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].y, hmR, Ai, 0, 0, 0);
+      Br = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].x, hrR, Br, 0, 0, 0);
+      Bi = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].y, hrR, Bi, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      Av[j] = make_double2(Ar[j], Ai[j]);
+      Bv[j] = make_double2(Br[j], Bi[j]);
+    }
+  }
 };
 
 // The same for N = 32 (dim 1024): four waves, wave w owns the 16 x 16 tile (row tile w & 1, column tile w >> 1) of rho in the
@@ -1484,6 +1523,45 @@ struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
         yi = fma(l1, xn.y, yi);
       }
       y[j] = make_double2(yr, yi);
+    }
+  }
+
+  // Gradient contraction on the matrix cores: A = [Im(Hc_k), z], B = [Re(Hc_k), z] for the thread's four elements (DenseStencil::
+  // ladder element by element: 2 N products per element and oscillator).  z's operands of the eight K-slabs are read from the
+  // published vector once and serve every oscillator; Hc_k is real: 8 instead of 16 products per slab and commutator pair.
+  struct ZOps {
+    double2 pb[NS], pa[NS];
+  };
+  __device__ __forceinline__ void ladder_fetch(const double2* __restrict__ sx, ZOps& z) const {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      z.pb[s] = sx[(c0 + lo) * N + 4 * s + hi];
+      z.pa[s] = sx[(4 * s + hi) * N + r0 + lo];
+    }
+  }
+  __device__ __forceinline__ void ladder_whole(const DevSys& S, const ZOps& z, int k, double2 (&Av)[EPT], double2 (&Bv)[EPT]) const {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const double* __restrict__ hr = S.hcr + (size_t)k * N * N;
+    const double* __restrict__ hm = S.hci + (size_t)k * N * N;
+    mfma_d4 Ar = {0.0, 0.0, 0.0, 0.0}, Ai = Ar, Br = Ar, Bi = Ar;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int il = (r0 + lo) * N + 4 * s + hi, ir = (4 * s + hi) * N + c0 + lo;
+      const double hmL = hm[il], hrL = hr[il], hmR = hm[ir], hrR = hr[ir];
+      Ar = __builtin_amdgcn_mfma_f64_16x16x4f64(hmL, z.pb[s].x, Ar, 0, 0, 0);
+      Ai = __builtin_amdgcn_mfma_f64_16x16x4f64(hmL, z.pb[s].y, Ai, 0, 0, 0);
+      Br = __builtin_amdgcn_mfma_f64_16x16x4f64(hrL, z.pb[s].x, Br, 0, 0, 0);
+      Bi = __builtin_amdgcn_mfma_f64_16x16x4f64(hrL, z.pb[s].y, Bi, 0, 0, 0);
+      Ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].x, hmR, Ar, 0, 0, 0);
+      Ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].y, hmR, Ai, 0, 0, 0);
+      Br = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].x, hrR, Br, 0, 0, 0);
+      Bi = __builtin_amdgcn_mfma_f64_16x16x4f64(-z.pa[s].y, hrR, Bi, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      Av[j] = make_double2(Ar[j], Ai[j]);
+      Bv[j] = make_double2(Br[j], Bi[j]);
     }
   }
 };
@@ -2690,17 +2768,33 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       }
       tm.publish(z);
       // gradient coefficients: x^T dM/dp_k z and x^T dM/dq_k z with x := kbar
+      if constexpr (TM::ST::WHOLE) {  // matrix-core stencils: the commutators of all the thread's elements at once per oscillator
+        typename TM::ST::ZOps zo;
+        tm.st.ladder_fetch(tm.vec(), zo);
 #pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (tm.ok(j)) {
+        for (int k = 0; k < Q; k++) {
+          double2 Av[EPT], Bv[EPT];
+          tm.st.ladder_whole(S, zo, k, Av, Bv);
 #pragma unroll
-          for (int k = 0; k < Q; k++) {
-            double2 Av, Bv;
-            tm.st.ladder(S, tm.L, tm.vecj(j), k, j, Av, Bv);
-            cf[tm.icslot(j) * 2 * Q + 2 * k] += Bv.y * kb[j].x - Bv.x * kb[j].y;
-            cf[tm.icslot(j) * 2 * Q + 2 * k + 1] += Av.x * kb[j].x + Av.y * kb[j].y;
-          }
+          for (int j = 0; j < EPT; j++)
+            if (tm.ok(j)) {
+              cf[tm.icslot(j) * 2 * Q + 2 * k] += Bv[j].y * kb[j].x - Bv[j].x * kb[j].y;
+              cf[tm.icslot(j) * 2 * Q + 2 * k + 1] += Av[j].x * kb[j].x + Av[j].y * kb[j].y;
+            }
         }
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (tm.ok(j)) {
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+              double2 Av, Bv;
+              tm.st.ladder(S, tm.L, tm.vecj(j), k, j, Av, Bv);
+              cf[tm.icslot(j) * 2 * Q + 2 * k] += Bv.y * kb[j].x - Bv.x * kb[j].y;
+              cf[tm.icslot(j) * 2 * Q + 2 * k + 1] += Av.x * kb[j].x + Av.y * kb[j].y;
+            }
+          }
+      }
       store_coeffs();
       // xbar += M^T kbar
       tm.publish(kb);

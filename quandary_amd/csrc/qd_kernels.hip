@@ -465,10 +465,10 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   // N = 49 4.3M vs 6.7M, N = 64 3.3M vs 5.2M
   else var = (fits(QD_COL_DEFAULT) && S.N >= 44) ? QD_COL_DEFAULT : 4;
   if (S.dense) var = dim <= 64 ? 11 : dim <= 256 ? 12 : 13;  // qd_set_hamiltonian limits dim to 1024
-  // matrix cores for the sweeps whose cost is the operator; the adjoint's gradient contraction (2Q commutators per
-  // step) is faster spread over four waves (measured: gradient 59.8 ms with V12 vs 83.2 ms with V15)
-  if (S.dense && S.lindblad && S.N == 16 && !adjoint) var = 15;
-  if (S.dense && S.lindblad && S.N == 32 && !adjoint && !getenv("QD_NO_MFMA32")) var = 17;
+  // matrix cores for the dense operator and (adjoint sweep) for the gradient contraction's 2Q commutators per step; QD_NO_MFMA
+  // keeps the vector kernels (measurements)
+  if (S.dense && S.lindblad && S.N == 16 && !getenv("QD_NO_MFMA")) var = 15;
+  if (S.dense && S.lindblad && S.N == 32 && !getenv("QD_NO_MFMA")) var = 17;
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
