@@ -1425,7 +1425,7 @@ struct DenseMfmaStencil : DenseStencil<Q, true, 4, 4> {
   }
 };
 
-// The same for N = 32 (dim 1024): four waves, wave w owns the 16 x 16 tile (row tile w & 1, column tile w >> 1) of rho in the
+// The same for 17 <= N <= 32 (dim up to 1024; N < 32 zero-padded): four waves, wave w owns the 16 x 16 tile (row tile w & 1, column tile w >> 1) of rho in the
 // accumulator layout; eight K-slabs per product, G's row block / column block of the tile in registers for the sub-step (both
 // orientations: the transposed real operator needs G^H), rho's operands from the published LDS vector (16 reads per lane and
 // application against 128 per element of the vector formulation): 64 MFMA instructions per wave and application.
@@ -1433,7 +1433,8 @@ template <int Q>
 struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
   typedef DenseStencil<Q, true, 4, 4> Base;
   static constexpr bool WHOLE = true;
-  static constexpr int N = 32, EPT = 4, NS = 8;
+  static constexpr int EPT = 4, NS = 8;  // 32 x 32 tiles; a smaller rho (N >= 17) is zero-padded: operands outside read as 0
+  int N;
   using Base::dbra;
   using Base::dd;
   using Base::dig;
@@ -1448,14 +1449,16 @@ struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
 
   __device__ __forceinline__ void init(const DevSys& S, const Lds& L) {
     Base::init(S, L);
+    N = S.N;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     r0 = 16 * (w & 1);
     c0 = 16 * (w >> 1);
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int I = r0 + (lane >> 4) + 4 * j, Ip = c0 + (lane & 15);
+      const int Iraw = r0 + (lane >> 4) + 4 * j, Ipraw = c0 + (lane & 15);
+      const int I = min(Iraw, N - 1), Ip = min(Ipraw, N - 1);  // (padding slots compute on a clamped element and are never stored)
       it[j] = Ip * N + I;
-      valid[j] = true;
+      valid[j] = Iraw < N && Ipraw < N;
       int ia[Q], ipa[Q];
       dbra[j] = 0;
       dket[j] = 0;
@@ -1477,13 +1480,16 @@ struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
 
   __device__ __forceinline__ void prep(const DevSys&, const Lds&, const StepC<Q>& c) {
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const double2 zero = make_double2(0.0, 0.0);
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      gA[s] = c.g[(r0 + lo) * N + 4 * s + hi];
-      gB[s] = c.g[(4 * s + hi) * N + c0 + lo];
-      const double2 a = c.g[(4 * s + hi) * N + r0 + lo], b = c.g[(c0 + lo) * N + 4 * s + hi];
-      gAh[s] = make_double2(a.x, -a.y);
-      gBh[s] = make_double2(b.x, -b.y);
+      const int kk = 4 * s + hi, kc = min(kk, N - 1), rr = min(r0 + lo, N - 1), cc = min(c0 + lo, N - 1);
+      const bool inr = kk < N && r0 + lo < N, inc = kk < N && c0 + lo < N;
+      gA[s] = inr ? c.g[rr * N + kc] : zero;
+      gB[s] = inc ? c.g[kc * N + cc] : zero;
+      const double2 a = c.g[kc * N + rr], b = c.g[cc * N + kc];
+      gAh[s] = inr ? make_double2(a.x, -a.y) : zero;
+      gBh[s] = inc ? make_double2(b.x, -b.y) : zero;
     }
   }
 
@@ -1495,14 +1501,18 @@ struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       // first product: Gt rho; A operand Gt[r0 + lo][4 s + hi] from registers, B operand rho[4 s + hi][c0 + lo] from LDS
+      if (4 * s >= N) break;  // (uniform: slabs beyond a zero-padded rho contribute nothing)
+      const int kk = 4 * s + hi, kc = min(kk, N - 1);
       const double2 ga = TRANS ? gAh[s] : gA[s];
-      const double2 pb = sx[(c0 + lo) * N + 4 * s + hi];
+      double2 pb = sx[min(c0 + lo, N - 1) * N + kc];
+      if (!(kk < N && c0 + lo < N)) pb = make_double2(0.0, 0.0);
       ar = __builtin_amdgcn_mfma_f64_16x16x4f64(ga.x, pb.x, ar, 0, 0, 0);
       ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-ga.y, pb.y, ar, 0, 0, 0);
       ai = __builtin_amdgcn_mfma_f64_16x16x4f64(ga.x, pb.y, ai, 0, 0, 0);
       ai = __builtin_amdgcn_mfma_f64_16x16x4f64(ga.y, pb.x, ai, 0, 0, 0);
       // second product: - rho Gt; A operand rho[r0 + lo][4 s + hi] from LDS, B operand Gt[4 s + hi][c0 + lo] from registers
-      const double2 pa = sx[(4 * s + hi) * N + r0 + lo];
+      double2 pa = sx[kc * N + min(r0 + lo, N - 1)];
+      if (!(kk < N && r0 + lo < N)) pa = make_double2(0.0, 0.0);
       const double2 gb = TRANS ? gBh[s] : gB[s];
       ar = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.x, gb.x, ar, 0, 0, 0);
       ar = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, gb.y, ar, 0, 0, 0);
@@ -1536,8 +1546,11 @@ struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      z.pb[s] = sx[(c0 + lo) * N + 4 * s + hi];
-      z.pa[s] = sx[(4 * s + hi) * N + r0 + lo];
+      const int kk = 4 * s + hi, kc = min(kk, N - 1);
+      z.pb[s] = sx[min(c0 + lo, N - 1) * N + kc];
+      z.pa[s] = sx[kc * N + min(r0 + lo, N - 1)];
+      if (!(kk < N && c0 + lo < N)) z.pb[s] = make_double2(0.0, 0.0);
+      if (!(kk < N && r0 + lo < N)) z.pa[s] = make_double2(0.0, 0.0);
     }
   }
   __device__ __forceinline__ void ladder_whole(const DevSys& S, const ZOps& z, int k, double2 (&Av)[EPT], double2 (&Bv)[EPT]) const {
@@ -1547,8 +1560,11 @@ struct DenseMfma32Stencil : DenseStencil<Q, true, 4, 4> {
     mfma_d4 Ar = {0.0, 0.0, 0.0, 0.0}, Ai = Ar, Br = Ar, Bi = Ar;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      const int il = (r0 + lo) * N + 4 * s + hi, ir = (4 * s + hi) * N + c0 + lo;
-      const double hmL = hm[il], hrL = hr[il], hmR = hm[ir], hrR = hr[ir];
+      if (4 * s >= N) break;
+      const int kk = 4 * s + hi, kc = min(kk, N - 1);
+      const int il = min(r0 + lo, N - 1) * N + kc, ir = kc * N + min(c0 + lo, N - 1);
+      const bool inl = kk < N && r0 + lo < N, inr = kk < N && c0 + lo < N;
+      const double hmL = inl ? hm[il] : 0.0, hrL = inl ? hr[il] : 0.0, hmR = inr ? hm[ir] : 0.0, hrR = inr ? hr[ir] : 0.0;
       Ar = __builtin_amdgcn_mfma_f64_16x16x4f64(hmL, z.pb[s].x, Ar, 0, 0, 0);
       Ai = __builtin_amdgcn_mfma_f64_16x16x4f64(hmL, z.pb[s].y, Ai, 0, 0, 0);
       Br = __builtin_amdgcn_mfma_f64_16x16x4f64(hrL, z.pb[s].x, Br, 0, 0, 0);

@@ -453,7 +453,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
     return (dim + (kVar[v].ept / kVar[v].icpb) - 1) / (kVar[v].ept / kVar[v].icpb) <= kVar[v].maxb;
   };
   auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
-    if (S.dense) return (v >= 11 && v <= 13) || (v == 15 && S.lindblad && S.N == 16) || (v == 17 && S.lindblad && S.N == 32);
+    if (S.dense) return (v >= 11 && v <= 13) || (v == 15 && S.lindblad && S.N == 16) || (v == 17 && S.lindblad && S.N > 16 && S.N <= 32);
     if (!qubit) return v <= 2 || v == 4 || (S.lindblad && (v == 9 || v == 14));
     return dim <= 64 ? v == 0 : dim <= 256 ? v == 1 : v == 2;
   };
@@ -468,7 +468,8 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   // matrix cores for the dense operator and (adjoint sweep) for the gradient contraction's 2Q commutators per step; QD_NO_MFMA
   // keeps the vector kernels (measurements)
   if (S.dense && S.lindblad && S.N == 16 && !getenv("QD_NO_MFMA")) var = 15;
-  if (S.dense && S.lindblad && S.N == 32 && !getenv("QD_NO_MFMA")) var = 17;
+  // (zero-padded 32 x 32 tiles pay the full 32^3 products: worth it from N = 22 on, 96.8 ms x (N / 32)^3 against 23.7 ms)
+  if (S.dense && S.lindblad && S.N >= 22 && S.N <= 32 && !getenv("QD_NO_MFMA")) var = 17;
   if (const char* ev = getenv("QD_VAR")) {  // tuning override
     const int v = atoi(ev);
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
@@ -487,6 +488,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   const int epe = kVar[var].ept / kVar[var].icpb;
   c.var = var;
   c.block = kVar[var].col ? colblock(var) : ((dim + epe - 1) / epe + 63) / 64 * 64;
+  if (var == 17) c.block = 256;  // four waves = the four 16 x 16 tiles, whatever N
   c.gmres = 0;
   const bool dn = S.dense == 2;  // G(t) staged in LDS
   c.lds = lds_bytes(S, c.block, kVar[var].dbuf, false, 0, kVar[var].icpb, kVar[var].col, dn);

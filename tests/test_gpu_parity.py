@@ -233,6 +233,9 @@ DENSE_SHAPES = [
     pytest.param(dict(nlevels=[2, 2, 2, 2], lindblad=True, init="diagonal, 0, 1"), id="dense-2^4-lindblad-mfma"),
     # N = 32 Lindblad (dim 1024): the largest dense operator of the LDS kernels (vector arithmetic; matrix cores only for N = 16)
     pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True, init="diagonal, 0"), id="dense-2^5-lindblad-dim1024"),
+    # 22 <= N < 32: the same matrix-core stencil on zero-padded 32 x 32 tiles (N = 24 above, N = 27 and N = 30 here, guard levels)
+    pytest.param(dict(nlevels=[3, 3, 3], lindblad=True, nessential=[2, 3, 2], target="pure", objective="Jfrobenius", init="diagonal, 1"), id="dense-3x3x3-lindblad-N27"),
+    pytest.param(dict(nlevels=[5, 6], lindblad=True, target="pure", objective="Jmeasure", init="diagonal, 0"), id="dense-5x6-lindblad-N30"),
 ]
 
 
