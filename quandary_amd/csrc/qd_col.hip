@@ -1,0 +1,669 @@
+// qd_col.hip — lean column kernels: Lindblad sweeps of density matrices with 33 <= N <= 64 rows and runtime level counts
+// (BASELINE config 4: 3 x 20 levels, dim 3600, 3600 initial conditions).  gfx950 / CDNA4 only.
+//
+// Layout (as ColStencil of qd_device.h: lane = row I of rho, a wave owns EPT consecutive columns I', vectorised index
+// it = I' N + I, util.cpp:150), rewritten for register and issue economy:
+//   * the exchange vector lives in LDS with a PADDED column stride of 64 rows (1 KiB per column), double buffered: the address of
+//     every neighbour is a thread invariant plus a compile-time immediate (slot j of the wave = + j KiB) - no per-slot address
+//     registers, nothing for the compiler to hoist and spill;
+//   * a neighbour that does not exist has a zero coefficient, and its address is folded onto the element itself ONCE (thread
+//     invariants for the bra side, wave-uniform scalar offsets for the ket side), so no clamping happens in the hot loop;
+//   * idle lanes (row >= N) and idle slots (column >= N) carry zeros through the same arithmetic: no divergence, no predication
+//     except on global memory;
+//   * the bra neighbours of the stride-1 oscillator are the adjacent lanes (DPP), its ket neighbours the adjacent slots
+//     (registers); the other oscillators read LDS: ~5 ds_read_b128 per element and application for two oscillators;
+//   * the state x is parked in its output buffer while a linear solve runs; the solver holds b and the iterate, nothing else.
+//
+// Reference semantics (paths relative to the reference repository): stencil include/mastereq.hpp:316-912 as instantiated by
+// src/mastereq.cpp:1464-1709 (two oscillators) / :1713-2018 (three); IMR forward / adjoint src/timestepper.cpp:584-694,
+// Neumann :697-727, time loops :96-253, penalties :256-339, gradient coefficients include/mastereq.hpp:553-604.
+#include <hip/hip_runtime.h>
+
+#include "qd_device.h"
+
+namespace qd {
+
+constexpr unsigned COLB = 1024;  // bytes per padded column: 64 rows x 16 B
+
+// Largest workgroup of the EPT-columns-per-wave kernels = their register budget: 16 waves x 128, 12 x 168 (five columns per wave
+// cover N <= 60), 11 x 168, 8 x 256 VGPRs
+constexpr int col_max_threads(int ept) { return ept == 5 ? 768 : 64 * ((64 + ept - 1) / ept); }
+
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int Q, int EPT, int FL = 0>
+struct ColLean {
+  static constexpr bool BRALDS = (FL & 1) != 0;   // bra neighbours of the stride-1 oscillator from LDS instead of lane shifts
+  static constexpr bool NOFENCE = (FL & 2) != 0;  // no scheduling fence between the slots
+  static constexpr bool FIXIT = (FL & 4) != 0;    // measurement only: run maxiter iterations, no norm reduction
+  static constexpr int L = Q - 1;  // the stride-1 oscillator (post[Q-1] == 1)
+  // thread invariants (functions of the row)
+  double su[Q], sd[Q];    // sqrt(i_k + 1) (0 at the top level), sqrt(i_k)
+  double g1u[Q], g1d[Q];  // gamma_1 su / gamma_1 sd: thread part of the T1 off-diagonal coefficient, forward / transposed
+  double dw[EPT], dd[EPT];  // Delta = h(I) - h(I'), d = L2 + L1diag of the thread's element in slot j (mastereq.hpp:316-433)
+  unsigned tb;              // LDS byte address of (row, first column of the wave) in the buffer being READ
+  unsigned aru[Q], ard[Q];  // the same with the row moved up / down by post[k] where that bra neighbour exists (else tb)
+  int dlt;                  // byte distance from the buffer being read to the other one (+- bufbytes)
+  // wave-uniform (functions of the wave's columns; scalar registers)
+  double cx[EPT][Q], cy[EPT][Q];  // sqrt(i'_k + 1) (0 at the top level), sqrt(i'_k) of the column of slot j
+  int ocu[EPT][Q], ocd[EPT][Q];   // byte offset to the ket neighbour column up / down (0 where there is none)
+  int N, row, col0;
+  bool rowok;
+  unsigned char* smem;
+
+  __device__ __forceinline__ double2 ld(unsigned a) const { return *reinterpret_cast<const double2*>(smem + a); }
+  __device__ __forceinline__ void st(unsigned a, const double2 v) const { *reinterpret_cast<double2*>(smem + a) = v; }
+  __device__ __forceinline__ int colof(int j) const { return col0 + j; }
+  __device__ __forceinline__ bool colok(int j) const { return col0 + j < N; }
+  __device__ __forceinline__ bool ok(int j) const { return rowok && colok(j); }
+  __device__ __forceinline__ int elem(int j) const { return (col0 + j) * N + row; }  // vectorised index (valid slots only)
+  static __host__ __device__ int ncols(int N) { return (N + EPT - 1) / EPT * EPT; }
+  static __host__ __device__ unsigned bufbytes(int N) { return (unsigned)ncols(N) * COLB; }
+  static size_t lds_bytes(int N) { return 2 * (size_t)bufbytes(N) + 2 * sizeof(double) * NRED * (size_t)(ncols(N) / EPT) + 128; }
+
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* sm) {
+    smem = sm;
+    N = S.N;
+    const int lane = threadIdx.x & 63;
+    const int w = uniform_i((int)(threadIdx.x >> 6));
+    col0 = w * EPT;
+    row = lane;
+    rowok = lane < N;
+    // zero the exchange buffers once: padding rows and idle columns are read (with zero coefficients) and must stay finite
+    {
+      const unsigned total = 2 * bufbytes(N);
+      for (unsigned a = threadIdx.x * 16u; a < total; a += blockDim.x * 16u) st(a, make_double2(0.0, 0.0));
+    }
+    tb = (unsigned)col0 * COLB + (unsigned)lane * 16u;
+    dlt = (int)bufbytes(N);
+    int ia[Q];
+    double hd = 0.0, drow = 0.0;  // h(I) and the row part of d
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      ia[k] = rowok ? (row / S.post[k]) % S.n[k] : 0;
+      su[k] = (rowok && ia[k] < S.n[k] - 1) ? sqrt((double)(ia[k] + 1)) : 0.0;
+      sd[k] = rowok ? sqrt((double)ia[k]) : 0.0;
+      g1u[k] = S.g1off[k] * su[k];
+      g1d[k] = S.g1off[k] * sd[k];
+      aru[k] = tb + (su[k] != 0.0 ? (unsigned)S.post[k] * 16u : 0u);
+      ard[k] = tb - (sd[k] != 0.0 ? (unsigned)S.post[k] * 16u : 0u);
+    }
+    {
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        hd += S.detune[k] * ia[k] - S.xi[k] / 2.0 * ia[k] * (ia[k] - 1);
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) hd -= S.xikl[pair++] * ia[k] * ia[l];
+      }
+    }
+    (void)drow;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int cc = col0 + j;
+      const bool cok = cc < N;
+      int ipa[Q];
+      double hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) ipa[k] = cok ? (cc / S.post[k]) % S.n[k] : 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        hdp += S.detune[k] * ipa[k] - S.xi[k] / 2.0 * ipa[k] * (ipa[k] - 1);
+        d += S.g2[k] * (ia[k] * ipa[k] - 0.5 * (ia[k] * ia[k] + ipa[k] * ipa[k])) - S.g1[k] / 2.0 * (ia[k] + ipa[k]);
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) hdp -= S.xikl[pair++] * ipa[k] * ipa[l];
+        const bool up = cok && ipa[k] < S.n[k] - 1, dn = cok && ipa[k] > 0;
+        cx[j][k] = to_scalar(up ? sqrt((double)(ipa[k] + 1)) : 0.0);
+        cy[j][k] = to_scalar(dn ? sqrt((double)ipa[k]) : 0.0);
+        ocu[j][k] = uniform_i(up ? S.post[k] * (int)COLB : 0);
+        ocd[j][k] = uniform_i(dn ? -S.post[k] * (int)COLB : 0);
+      }
+      const bool live = rowok && cok;
+      dw[j] = live ? hd - hdp : 0.0;
+      dd[j] = live ? d : 0.0;
+    }
+  }
+
+  // the other buffer becomes the one being read
+  __device__ __forceinline__ void flip() {
+    tb += (unsigned)dlt;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      aru[k] += (unsigned)dlt;
+      ard[k] += (unsigned)dlt;
+    }
+    dlt = -dlt;
+  }
+
+  // the four ladder neighbours of oscillator k of the element in slot j: bra up / down (xu, xd), ket up / down (xup, xdp);
+  // own / prev / next = the thread's elements of the vector being read in slots j, j - 1, j + 1
+  __device__ __forceinline__ void nbrs(int k, int j, const double2 own, const double2 prev, const double2 next, double2& xu, double2& xd,
+                                       double2& xup, double2& xdp) const {
+    if (k == L) {
+      xu = BRALDS ? ld(aru[k] + (unsigned)j * COLB) : lane_shift<true>(own);
+      xd = BRALDS ? ld(ard[k] + (unsigned)j * COLB) : lane_shift<false>(own);
+      xup = j < EPT - 1 ? next : ld(tb + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+      xdp = j > 0 ? prev : ld(tb + (unsigned)ocd[j][k] + (unsigned)j * COLB);
+    } else {
+      xu = ld(aru[k] + (unsigned)j * COLB);
+      xd = ld(ard[k] + (unsigned)j * COLB);
+      xup = ld(tb + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+      xdp = ld(tb + (unsigned)ocd[j][k] + (unsigned)j * COLB);
+    }
+  }
+
+  // y = M x (TRANS = false) or M^T x at slot j (ColStencil::apply of qd_device.h; HASJ = false)
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply(const StepC<Q>& c, int j, const double2 own, const double2 prev, const double2 next) const {
+    const double dwj = TRANS ? -dw[j] : dw[j];
+    double ar = dd[j] * own.x, ai = dd[j] * own.y;
+    ar = fma(dwj, own.y, ar);
+    ai = fma(-dwj, own.x, ai);
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      double2 xu, xd, xup, xdp;
+      nbrs(k, j, own, prev, next, xu, xd, xup, xdp);
+      const double er = fma(-cy[j][k], xdp.x, su[k] * xu.x), ei = fma(-cy[j][k], xdp.y, su[k] * xu.y);  // U1 - D2
+      const double fr = fma(cx[j][k], xup.x, -sd[k] * xd.x), fi = fma(cx[j][k], xup.y, -sd[k] * xd.y);  // U2 - D1
+      const double pk = TRANS ? -c.p[k] : c.p[k], qk = TRANS ? -c.q[k] : c.q[k];
+      ar = fma(qk, er + fr, fma(pk, ei - fi, ar));
+      ai = fma(qk, ei + fi, fma(-pk, er - fr, ai));
+      // T1 off-diagonal term: forward couples to (row + s, column + s), transposed to (row - s, column - s)
+      double2 xl;
+      if (k == L) {
+        if (TRANS) xl = j > 0 ? (BRALDS ? ld(ard[k] + (unsigned)(j - 1) * COLB) : lane_shift<false>(prev)) : ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB);
+        else xl = j < EPT - 1 ? (BRALDS ? ld(aru[k] + (unsigned)(j + 1) * COLB) : lane_shift<true>(next)) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+      } else {
+        xl = TRANS ? ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+      }
+      const double l1 = TRANS ? g1d[k] * cy[j][k] : g1u[k] * cx[j][k];
+      ar = fma(l1, xl.x, ar);
+      ai = fma(l1, xl.y, ai);
+    }
+    return make_double2(ar, ai);
+  }
+
+  // gradient contraction (ColStencil::ladder): A = e + f, B = e - f with e = U1 - D2, f = U2 - D1 of the published vector
+  __device__ __forceinline__ void ladder(int k, int j, const double2 own, const double2 prev, const double2 next, double2& A, double2& B) const {
+    double2 xu, xd, xup, xdp;
+    nbrs(k, j, own, prev, next, xu, xd, xup, xdp);
+    const double er = fma(-cy[j][k], xdp.x, su[k] * xu.x), ei = fma(-cy[j][k], xdp.y, su[k] * xu.y);
+    const double fr = fma(cx[j][k], xup.x, -sd[k] * xd.x), fi = fma(cx[j][k], xup.y, -sd[k] * xd.y);
+    A.x = er + fr;
+    A.y = ei + fi;
+    B.x = er - fr;
+    B.y = ei - fi;
+  }
+
+  // isGuardLevel (util.cpp:259-278) of the row's level combination; the leakage term sums the DIAGONAL elements of those rows
+  __device__ __forceinline__ bool row_is_guard(const DevSys& S) const {
+    bool g = false;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const int a = rowok ? (row / S.post[k]) % S.n[k] : 0;
+      g = g || (a == S.n[k] - 1 && a >= S.ness[k]);
+    }
+    return g && rowok;
+  }
+};
+
+// per-workgroup machinery: buffers, reductions, the Neumann solver
+template <int Q, int EPT, int FL = 0>
+struct ColTeam {
+  typedef ColLean<Q, EPT, FL> ST;
+  ST st;
+  double* red;
+  float4* fred;  // two slots of 16 partial sums of the solver's fp32 norm reduction
+  int redslot, nw;
+
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
+    st.init(S, smem);
+    red = reinterpret_cast<double*>(smem + 2 * ST::bufbytes(S.N));
+    redslot = 0;
+    nw = (int)(blockDim.x >> 6);
+    fred = reinterpret_cast<float4*>(red + 2 * NRED * nw);
+    if (threadIdx.x < 32) reinterpret_cast<float*>(fred)[threadIdx.x] = 0.f;  // (16 partial sums are read whatever the number of waves)
+    __syncthreads();  // zero fill complete
+  }
+
+  // x becomes the vector being read
+  __device__ __forceinline__ void publish(const double2 (&x)[EPT]) {
+    const unsigned wa = st.tb + (unsigned)st.dlt;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) st.st(wa + (unsigned)j * COLB, x[j]);
+    st.flip();
+    __syncthreads();
+  }
+
+  template <int NV>
+  __device__ __forceinline__ void sum(double (&v)[NV]) {
+    block_sum<NV, false>(v, red + redslot * NRED * nw);
+    redslot ^= 1;
+  }
+  // workgroup sum of the solver's squared update norm (fp32; only compared with a threshold).  One barrier - the one that makes the
+  // new iterate readable - and ONE round of LDS latency: the <= 16 partial sums are fetched by four broadcast reads and added as a tree
+  // (a loop over the waves would chain 15 dependent LDS round trips in front of every stopping test).
+  __device__ __forceinline__ float sum_f32(float v) {
+    float4* rf = fred + redslot * 4;
+    redslot ^= 1;
+    v = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<float*>(rf)[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float4 a = rf[0], b = rf[1], c = rf[2], d = rf[3];
+    return (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+  }
+
+  template <bool TRANS>
+  __device__ __forceinline__ void apply_all(const StepC<Q>& c, const double2 (&x)[EPT], double2 (&y)[EPT]) const {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      y[j] = st.template apply<TRANS>(c, j, x[j], x[j > 0 ? j - 1 : 0], x[j + 1 < EPT ? j + 1 : j]);
+      if (!ST::NOFENCE) slot_fence<EPT>();
+    }
+  }
+
+  // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727); stopping rule on squared
+  // norms reduced in fp32 exactly as Team::neumann of qd_device.h.  Returns the number of RHS applications; y in registers.
+  template <bool TRANS>
+  __device__ __forceinline__ int neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = b[j];
+    publish(y);
+    const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
+    const float rel2 = (float)(A.reltol * A.reltol);
+    float d0 = 1.f;
+    int iter;
+    for (iter = 0; iter < A.maxiter; iter++) {
+      const unsigned wa = st.tb + (unsigned)st.dlt;
+      double dl = 0.0;
+      double2 prev = y[0];
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 own = y[j];
+        const double2 t = st.template apply<TRANS>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
+        double2 w;
+        w.x = fma(alpha, t.x, b[j].x);
+        w.y = fma(alpha, t.y, b[j].y);
+        const double dx = own.x - w.x, dy = own.y - w.y;
+        dl = fma(dx, dx, fma(dy, dy, dl));
+        prev = own;
+        y[j] = w;
+        st.st(wa + (unsigned)j * COLB, w);
+        if (!ST::NOFENCE) slot_fence<EPT>();
+      }
+      float d;
+      if (ST::FIXIT) {
+        d = (float)dl + 2.f;
+        __syncthreads();
+      } else {
+        d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
+      }
+      st.flip();
+      if (iter == 0) d0 = d;
+      if (d < 1.f) { iter++; break; }
+      if (d < rel2 * d0) { iter++; break; }
+    }
+    return iter;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward sweep (TimeStepper::solveODE for every initial condition of the batch)
+// ---------------------------------------------------------------------------------------------
+template <int Q, int EPT, int FL = 0>
+__global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef ColTeam<Q, EPT, FL> TM;
+  const DevSys& S = A.S;
+  TM tm;
+  tm.init(S, smem);
+  const int ic = blockIdx.x, dim = S.dim;
+  double2 x[EPT];
+  {
+    const double* x0 = A.x0 + (size_t)ic * 2 * dim;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = tm.st.ok(j) ? make_double2(x0[tm.st.elem(j)], x0[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
+  }
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+  const bool leak = pen_on && A.leak_on && tm.st.row_is_guard(S);
+  double pen_local = 0.0, pen_uniform = 0.0;
+  unsigned long long napply = 0;
+  double* xpark = A.xT + (size_t)ic * 2 * dim;
+  // global accesses of the thread's elements: one divergent region per call (rows), uniform branches inside (columns)
+  auto store_state = [&](double* dst, const double2(&v)[EPT], bool nt) {
+    if (tm.st.rowok) {
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (tm.st.colok(j)) {
+          const int e = opaque(tm.st.elem(j));
+          if (nt) {
+            __builtin_nontemporal_store(v[j].x, dst + e);
+            __builtin_nontemporal_store(v[j].y, dst + dim + e);
+          } else {
+            dst[e] = v[j].x;
+            dst[dim + e] = v[j].y;
+          }
+        }
+    }
+  };
+
+  for (int s = 0; s < A.nsub; s++) {
+    StepC<Q> c;
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    scalarize<Q>(c, false);
+    if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
+    // x is not needed during the linear solve: parked in the output buffer (L2 resident) BEFORE the right-hand side is formed, so that
+    // no control flow separates the operator application from the solver that consumes it
+    store_state(xpark, x, false);
+    tm.publish(x);
+    double2 rhs[EPT], k[EPT];
+    tm.template apply_all<false>(c, x, rhs);  // rhs = M x (ImplMidpoint::evolveFWD, timestepper.cpp:594)
+    napply += 1 + tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = make_double2(0.0, 0.0);
+    if (tm.st.rowok) {
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (tm.st.colok(j)) {
+          const int e = opaque(tm.st.elem(j));
+          x[j] = make_double2(xpark[e], xpark[dim + e]);
+        }
+    }
+    if (A.ztraj) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
+      double2 z[EPT];
+#pragma unroll
+      for (int j = 0; j < EPT; j++) z[j] = make_double2(fma(0.5 * c.h, k[j].x, x[j].x), fma(0.5 * c.h, k[j].y, x[j].y));
+      store_state(A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim, z, true);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      x[j].x = fma(c.h, k[j].x, x[j].x);
+      x[j].y = fma(c.h, k[j].y, x[j].y);
+    }
+    // in-loop penalties at the end of a FULL time step (timestepper.cpp:141-154, :256-298)
+    if (pen_on && (s + 1) % A.nstages == 0) {
+      const int n = (s + 1) / A.nstages - 1;
+      const double tstop = (n + 1) * A.dt;
+      if (wj_on) {
+        const double a = (tstop - A.Tfinal) / A.penalty_param;
+        const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+        if (tm.st.rowok) {
+#pragma unroll
+          for (int j = 0; j < EPT; j++)
+            if (tm.st.colok(j)) {
+              double jr = 0.0, ji = 0.0;
+              evalJ_part<true>(S, A.tg, ic, opaque(tm.st.elem(j)), x[j], jr, ji);
+              // finalizeJ is affine for Lindblad: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Jtrace)
+              pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
+            }
+        }
+        if (A.tg.objective_type == QD_OBJ_JTRACE) pen_uniform += weight * A.dt;
+      }
+      if (leak) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (tm.st.colof(j) == tm.st.row) pen_local += (x[j].x * x[j].x + x[j].y * x[j].y) / A.ntime;
+      }
+    }
+  }
+  store_state(A.xT + (size_t)ic * 2 * dim, x, false);
+  if (A.traj) store_state(A.traj + ((size_t)A.nsub * A.nb + ic) * 2 * dim, x, false);
+  double v[1] = {pen_local};
+  tm.template sum<1>(v);
+  if (threadIdx.x == 0) {
+    A.pen_out[ic] = v[0] + pen_uniform;
+    A.dpdm_out[ic] = 0.0;  // the dpdm penalty is Schroedinger only (timestepper.cpp:143-146)
+    atomicAdd(A.napply, napply);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
+// ---------------------------------------------------------------------------------------------
+template <int Q, int EPT>
+__global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef ColTeam<Q, EPT> TM;
+  const DevSys& S = A.S;
+  TM tm;
+  tm.init(S, smem);
+  const int ic = blockIdx.x, dim = S.dim;
+  double2 xb[EPT];
+  {
+    const double* xbT = A.xbarT + (size_t)ic * 2 * dim;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) xb[j] = tm.st.ok(j) ? make_double2(xbT[tm.st.elem(j)], xbT[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
+  }
+  const double jbar_pen = A.jbar[ic * 3 + 0];
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+  const bool leak = pen_on && A.leak_on && tm.st.row_is_guard(S);
+  auto load_state = [&](const double* base, int s, double2(&dst)[EPT]) {
+    const double* src = base + ((size_t)s * A.nb + ic) * 2 * dim;
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      dst[j] = tm.st.ok(j) ? make_double2(__builtin_nontemporal_load(src + opaque(tm.st.elem(j))), __builtin_nontemporal_load(src + dim + opaque(tm.st.elem(j))))
+                           : make_double2(0.0, 0.0);
+  };
+
+  for (int s = A.nsub - 1; s >= 0; s--) {
+    // penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227, :300-339)
+    if (pen_on && (s + 1) % A.nstages == 0 && (wj_on || leak)) {
+      const int n = (s + 1) / A.nstages;
+      const double tstop = n * A.dt;
+      double2 xn[EPT];
+      load_state(A.traj, s + 1, xn);
+      if (wj_on) {
+        const double a = (tstop - A.Tfinal) / A.penalty_param;
+        const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+        double rb, ib;
+        finalizeJ_diff<true>(A.tg, 0.0, 0.0, rb, ib);
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (tm.st.ok(j)) evalJ_diff_elem<true>(S, A.tg, ic, opaque(tm.st.elem(j)), xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+      }
+      if (leak) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (tm.st.colof(j) == tm.st.row) {
+            xb[j].x += 2.0 * xn[j].x * jbar_pen / A.ntime;
+            xb[j].y += 2.0 * xn[j].y * jbar_pen / A.ntime;
+          }
+      }
+    }
+    StepC<Q> c;
+    load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    scalarize<Q>(c, false);
+    // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z of the sub-step was stored by the forward sweep
+    double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
+    tm.template neumann<true>(A, c, 0.5 * c.h, xb, kb);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      kb[j].x *= c.h;
+      kb[j].y *= c.h;
+    }
+    double cf[2 * Q];
+#pragma unroll
+    for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
+    {
+      double2 z[EPT];
+      load_state(A.ztraj, s, z);
+      tm.publish(z);
+      // gradient coefficients x^T dM/dp_k z and x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604)
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+          double2 Av, Bv;
+          tm.st.ladder(k, j, z[j], z[j > 0 ? j - 1 : 0], z[j + 1 < EPT ? j + 1 : j], Av, Bv);
+          cf[2 * k] += Bv.y * kb[j].x - Bv.x * kb[j].y;
+          cf[2 * k + 1] += Av.x * kb[j].x + Av.y * kb[j].y;
+        }
+        slot_fence<EPT>();
+      }
+    }
+    tm.template sum<2 * Q>(cf);
+    {
+      double* co = A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q;
+#pragma unroll
+      for (int i = 0; i < 2 * Q; i++)
+        if (threadIdx.x == i) co[i] = cf[i];
+    }
+    // xbar += M^T kbar
+    tm.publish(kb);
+    double2 t[EPT];
+    tm.template apply_all<true>(c, kb, t);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      xb[j].x += t[j].x;
+      xb[j].y += t[j].y;
+    }
+  }
+  if (A.xbar0) {
+    double* d0 = A.xbar0 + (size_t)ic * 2 * dim;
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (tm.st.ok(j)) {
+        d0[tm.st.elem(j)] = xb[j].x;
+        d0[dim + tm.st.elem(j)] = xb[j].y;
+      }
+  }
+}
+
+// single operator application (test hook = MatMult / MatMultTranspose on the shell)
+template <int Q, int EPT>
+__global__ void __launch_bounds__(col_max_threads(EPT)) k_apply_col(const DevSys S, const double* __restrict__ ctlrow, int transpose, const double* __restrict__ xin,
+                                                          double* __restrict__ yout) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef ColTeam<Q, EPT> TM;
+  TM tm;
+  tm.init(S, smem);
+  const int ic = blockIdx.x, dim = S.dim;
+  double2 x[EPT], y[EPT];
+  const double* x0 = xin + (size_t)ic * 2 * dim;
+#pragma unroll
+  for (int j = 0; j < EPT; j++) x[j] = tm.st.ok(j) ? make_double2(x0[tm.st.elem(j)], x0[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
+  StepC<Q> c;
+  load_step<Q>(ctlrow, c, false);
+  scalarize<Q>(c, false);
+  tm.publish(x);
+  if (transpose) tm.template apply_all<true>(c, x, y);
+  else tm.template apply_all<false>(c, x, y);
+  double* yo = yout + (size_t)ic * 2 * dim;
+#pragma unroll
+  for (int j = 0; j < EPT; j++)
+    if (tm.st.ok(j)) {
+      yo[tm.st.elem(j)] = y[j].x;
+      yo[dim + tm.st.elem(j)] = y[j].y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t set_lds_col(K kern, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// Lindblad, matrix-free, no dipole-dipole coupling, runtime level counts that are not all 2, two or three oscillators, a density
+// matrix of 33..64 rows (one lane per row), the last oscillator with stride 1 (always: post[Q-1] == 1)
+bool collean_available(const DevSys& S) {
+  if (!S.lindblad || S.dense || S.hasJ || (S.Q != 2 && S.Q != 3) || S.N < 33 || S.N > 64) return false;
+  bool qubit = true;
+  for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2;
+  return !qubit && S.post[S.Q - 1] == 1;
+}
+
+template <int Q, int EPT, int FL>
+static hipError_t go_fwd_col_fl(const SweepArgs& a, hipStream_t st) {
+  typedef ColLean<Q, EPT> ST;
+  const size_t lds = ST::lds_bytes(a.S.N);
+  auto kf = k_forward_col<Q, EPT, FL>;
+  hipError_t e = set_lds_col(kf, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3(a.nb), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
+  return hipGetLastError();
+}
+template <int Q, int EPT>
+static hipError_t go_fwd_col(const SweepArgs& a, hipStream_t st) {
+  if constexpr (Q == 2 && (EPT == 4 || EPT == 8)) {  // measurement variants (QD_COL_X)
+    const char* e = getenv("QD_COL_X");
+    switch (e ? atoi(e) : 0) {
+      case 1: return go_fwd_col_fl<Q, EPT, 1>(a, st);
+      case 2: return go_fwd_col_fl<Q, EPT, 2>(a, st);
+      case 4: return go_fwd_col_fl<Q, EPT, 4>(a, st);
+      default: break;
+    }
+  }
+  return go_fwd_col_fl<Q, EPT, 0>(a, st);
+}
+template <int Q, int EPT>
+static hipError_t go_adj_col(const SweepArgs& a, hipStream_t st) {
+  typedef ColLean<Q, EPT> ST;
+  const size_t lds = ST::lds_bytes(a.S.N);
+  auto kf = k_adjoint_col<Q, EPT>;
+  hipError_t e = set_lds_col(kf, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3(a.nb), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
+  return hipGetLastError();
+}
+template <int Q, int EPT>
+static hipError_t go_app_col(const DevSys& S, const double* ctlrow, int tr, const double* x, double* y, int nb, hipStream_t st) {
+  typedef ColLean<Q, EPT> ST;
+  const size_t lds = ST::lds_bytes(S.N);
+  auto kf = k_apply_col<Q, EPT>;
+  hipError_t e = set_lds_col(kf, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kf, dim3(nb), dim3(64 * (ST::ncols(S.N) / EPT)), lds, st, S, ctlrow, tr, x, y);
+  return hipGetLastError();
+}
+
+// Columns per wave.  Measured on the 3 x 20 workload (3600 initial conditions x 100 steps, forward sweep, one lease): 4 columns
+// (15 waves, 128 VGPRs, 63 spills) 58.9 ms, 5 columns (12 waves, 168 VGPRs) 48.4 ms, 6 columns (10 waves, 59 spills) 62.9 ms,
+// 8 columns (8 waves, 234 VGPRs, no spills) 53.4 ms; the general column kernel of qd_device.h 73.1 ms.  Five columns per wave cover
+// N <= 60, eight the rest.  QD_COL_EPT overrides (measurements).
+static int col_ept(int N) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("QD_COL_EPT");
+    forced = e ? atoi(e) : 0;
+    if (forced != 4 && forced != 5 && forced != 6 && forced != 8) forced = 0;
+  }
+  if (forced) return forced;
+  return N <= 60 ? 5 : 8;
+}
+#define QD_COL_DISPATCH(FN, ...)                                  \
+  do {                                                            \
+    const int e = col_ept(Nn);                                      \
+    if (Qn == 2) {                                                \
+      if (e == 4) return FN<2, 4>(__VA_ARGS__);                   \
+      if (e == 5 && Nn <= 60) return FN<2, 5>(__VA_ARGS__);       \
+      if (e == 6) return FN<2, 6>(__VA_ARGS__);                   \
+      return FN<2, 8>(__VA_ARGS__);                               \
+    }                                                             \
+    if (Qn == 3) {                                                \
+      if (e == 4) return FN<3, 4>(__VA_ARGS__);                   \
+      if (e == 5 && Nn <= 60) return FN<3, 5>(__VA_ARGS__);       \
+      if (e == 6) return FN<3, 6>(__VA_ARGS__);                   \
+      return FN<3, 8>(__VA_ARGS__);                               \
+    }                                                             \
+    return hipErrorInvalidValue;                                  \
+  } while (0)
+
+hipError_t launch_forward_col(const SweepArgs& a, hipStream_t st) {
+  const int Qn = a.S.Q, Nn = a.S.N;
+  QD_COL_DISPATCH(go_fwd_col, a, st);
+}
+hipError_t launch_adjoint_col(const SweepArgs& a, hipStream_t st) {
+  const int Qn = a.S.Q, Nn = a.S.N;
+  QD_COL_DISPATCH(go_adj_col, a, st);
+}
+hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
+  const int Qn = S.Q, Nn = S.N;
+  QD_COL_DISPATCH(go_app_col, S, ctlrow, transpose, x, y, nb, st);
+}
+
+}  // namespace qd

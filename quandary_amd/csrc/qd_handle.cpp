@@ -505,6 +505,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
   }
   if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
   else if (cfg.var != 16 && lean64_available(h->S)) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
+  else if (cfg.var == 9 && collean_available(h->S) && !getenv("QD_NO_COLLEAN")) QD_HIP(launch_apply_col(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
   else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
@@ -707,6 +708,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
+  else if (cfg.var == 9 && !cfg.gmres && collean_available(S) && sol.stepper != QD_STEPPER_EE && !getenv("QD_NO_COLLEAN")) QD_HIP(launch_forward_col(a, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));
@@ -873,6 +875,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, stream));
+  else if (cfg.var == 9 && !cfg.gmres && collean_available(S) && sol.stepper != QD_STEPPER_EE && !getenv("QD_NO_COLLEAN")) QD_HIP(launch_adjoint_col(a, stream));
   else QD_HIP(launch_adjoint(a, cfg, stream));
   QD_HIP(hipEventRecord(ev3, stream));
   QD_HIP(launch_reduce_coeff(d_coeff.p, nb, (int)ncol, d_coeffsum.p, accumulate ? 1 : 0, stream));

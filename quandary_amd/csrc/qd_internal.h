@@ -146,6 +146,11 @@ bool lean64_available(const DevSys& S);
 hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st);
 hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st);
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
+// lean column kernels (qd_col.hip): Lindblad Neumann sweeps of density matrices with 33..64 rows and runtime level counts
+bool collean_available(const DevSys& S);
+hipError_t launch_forward_col(const SweepArgs& a, hipStream_t st);
+hipError_t launch_adjoint_col(const SweepArgs& a, hipStream_t st);
+hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
 LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false, bool adjoint = false);
 size_t krylov_doubles(const DevSys& S, int nb);
 size_t big_work_doubles(const DevSys& S, int nb);

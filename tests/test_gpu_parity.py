@@ -115,6 +115,46 @@ def test_column_layout_variants(kw, var, monkeypatch):
     opt.close(); h.close(); orc.close()
 
 
+LEANCOL_SHAPES = [
+    pytest.param(dict(nlevels=[3, 20], lindblad=True, target="pure", objective="Jmeasure", init="diagonal, 0"), id="3x20"),
+    pytest.param(dict(nlevels=[4, 12], lindblad=True, nessential=[3, 10], target="pure", objective="Jfrobenius", init="diagonal, 1"), id="4x12-guard"),
+    pytest.param(dict(nlevels=[8, 8], lindblad=True, nessential=[7, 8], target="pure", objective="Jtrace", init="basis, 0"), id="8x8-N64"),
+    pytest.param(dict(nlevels=[3, 3, 5], lindblad=True, nessential=[2, 3, 4], target="pure", objective="Jmeasure", init="diagonal, 2"), id="3x3x5-N45"),
+    pytest.param(dict(nlevels=[2, 4, 7], lindblad=True, target="pure", objective="Jfrobenius", init="diagonal, 0"), id="2x4x7-N56"),
+    pytest.param(dict(nlevels=[7, 9], lindblad=True, detuned=True, target="pure", objective="Jmeasure", init="diagonal, 1"), id="7x9-N63"),
+]
+
+
+@pytest.mark.parametrize("stepper", ["IMR", "IMR4"])
+@pytest.mark.parametrize("kw", LEANCOL_SHAPES)
+def test_lean_column_kernels(kw, stepper):
+    """qd_col.hip (Lindblad, 44 <= N <= 64 rows, two or three oscillators, Neumann): operator and transpose at 1e-13, objective
+    parts and gradient against the oracle with every Lindblad penalty (weighted J, leakage through guard levels, energy), and
+    bit-for-bit agreement of nothing: the general column kernel of qd_device.h (QD_NO_COLLEAN) must give the same numbers to
+    round-off, which pins the two implementations against each other as well."""
+    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, dt=0.001)  # (self-Kerr 0.2 GHz on up to 20 levels: the Neumann
+    assert h.dim > 1024                                                           # series needs ||h/2 M|| < 1)
+    rng = np.random.default_rng(11)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    x = rng.standard_normal((3, 2 * h.dim))
+    t = 0.41 * sp.time.ntime * sp.time.dt
+    for tr in (False, True):
+        yo = orc.apply_rhs(t, x, transpose=tr)
+        np.testing.assert_allclose(h.apply_rhs(t, x, transpose=tr), yo, rtol=1e-13, atol=1e-13 * np.abs(yo).max())
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    orc.reset_stats()
+    orc.evalF(sp.params0)
+    opt.evalF(sp.params0)
+    assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[4], SHAPES[5], SHAPES[6], SHAPES[7]])
 def test_gmres_solver_vs_oracle_gmres(kw):
     """linearsolver_type = gmres: in-kernel GMRES against the oracle's GMRES.  Small systems keep the Krylov
