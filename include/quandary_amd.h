@@ -354,6 +354,14 @@ int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* alpha, qd_obj
  * ------------------------------------------------------------------------- */
 enum { QD_PRECISION_F64 = 0, QD_PRECISION_F32MIXED = 1 };
 int qd_set_precision(qd_handle* h, int precision);
+/* Tuning and test options of a handle, as "key", "value" strings (the counterpart of PETSc's options database the reference is
+ * steered with, e.g. -ksp_* for the linear solver of src/timestepper.cpp:541-550).  Integer values unless noted; "auto" restores
+ * the default.  Keys: neumann_split (diagonal of M on the left-hand side of the Neumann iteration: same fixed point and stopping
+ * rule, fewer iterations on systems whose level energies dominate; auto = where it pays, 0 = the reference's iteration everywhere),
+ * gmres_poly (degree of the polynomial preconditioner, 0 = tuned, 1 = none), force_neumann, var (kernel variant), no_mfma,
+ * no_lean64, no_collean, col_ept, big_team, big_spread, f32_sb, traj_budget_mb (double).  Every key is also read from the
+ * environment variable QD_<KEY> once, at qd_create (tests, measurements).  Unknown keys: QD_ERR_INVALID. */
+int qd_set_option(qd_handle* h, const char* key, const char* value);
 int qd_get_precision(const qd_handle* h);
 /* Measurement hook: nrep chained forward applications y <- M(t) (1e-3 y) on nb states, starting from x, in fp32 by the
  * stencil kernel (mfma = 0) or as the dense Kronecker-factor product G rho - rho G on the fp32 matrix cores (mfma = 1,

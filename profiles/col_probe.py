@@ -1,5 +1,5 @@
 """Column-kernel probe (run on the GPU box): the 3x20 workload (BASELINE config 4) with the lean column kernels of qd_col.hip and,
-under QD_NO_COLLEAN=1, with the general column kernel of qd_device.h - same lease, same process.
+under the option no_collean, with the general column kernel of qd_device.h - same lease, same process.
 usage: col_probe.py <ntime> <ninit or 0 = all> [grad]"""
 import os
 import sys
@@ -14,12 +14,10 @@ grad = len(sys.argv) > 3 and sys.argv[3] == "grad"
 over = {"ntime": ntime}
 if ninit:
     over["initialcondition"] = "diagonal, 0" if ninit == 60 else "basis, 0" if ninit == 9 else "basis"
-for tag, env in (("lean", None), ("general", "1"), ("lean", None), ("general", "1")):
-    if env:
-        os.environ["QD_NO_COLLEAN"] = env
-    else:
-        os.environ.pop("QD_NO_COLLEAN", None)
+for tag, opts in (("lean+split", {}), ("lean", {"neumann_split": 0}), ("general", {"no_collean": 1}), ("lean+split", {}), ("lean", {"neumann_split": 0}),
+                  ("general", {"no_collean": 1})):
     sp = workload_spec("c4", "gradient" if grad else "simulation", over)
+    sp.options = opts
     h = capi.Handle(sp)
     o = capi.Optim(h, sp)
     for i in range(2):

@@ -178,7 +178,7 @@ EXPORTS = [
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
     "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
-    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables",
+    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables", "qd_set_option",
 ]
 COMM_ID_BYTES = 128
 PRECISION = {"f64": 0, "f32mixed": 1}
@@ -252,6 +252,7 @@ def load_library(path=None):
     lib.qd_optim_evalF_dist.argtypes = [vp, vp, c_dp, C.POINTER(qd_objective_value), c_dp]
     lib.qd_optim_evalGradF_dist.argtypes = [vp, vp, c_dp, C.POINTER(qd_objective_value), c_dp, c_dp]
     lib.qd_set_precision.argtypes = [vp, C.c_int]
+    lib.qd_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.qd_get_precision.argtypes = [vp]
     lib.qd_get_observables.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_dp]
     lib.qd_bench_apply_f32.argtypes = [vp, C.c_double, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -299,6 +300,8 @@ class Handle:
         prec = getattr(spec, "precision", "f64") or "f64"
         if prec != "f64":
             self.set_precision(prec)
+        for k, v in (getattr(spec, "options", None) or {}).items():
+            self.set_option(k, v)
 
     def bench_apply_f32(self, t, x, nrep=1, mfma=False):
         """Measurement hook: nrep chained fp32 applications of M(t) by the stencil kernel or on the fp32 matrix cores."""
@@ -308,6 +311,10 @@ class Handle:
         _check(self.lib, self.lib.qd_bench_apply_f32(self._h, float(t), dptr(x), dptr(y), x.shape[0], int(nrep), int(bool(mfma)), C.byref(ms)),
                "qd_bench_apply_f32")
         return y, ms.value
+
+    def set_option(self, key, value):
+        """qd_set_option: tuning / test options of the handle as strings (include/quandary_amd.h)."""
+        _check(self.lib, self.lib.qd_set_option(self._h, str(key).encode(), str(value).encode()), "qd_set_option")
 
     def set_precision(self, name):
         """'f64' (default, like the reference) or 'f32mixed' (fp32 exchange vector / stencil, fp64 accumulation)."""

@@ -31,16 +31,17 @@ constexpr int col_max_threads(int ept) { return ept == 5 ? 768 : 64 * ((64 + ept
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int Q, int EPT, int FL = 0>
+// SPLIT: the kernels of the diagonal-split solver keep (1 - alpha D)^-1 per element instead of the diagonal itself; the diagonal is then
+// re-derived where the full operator is applied (once or twice per step) from a row part held by the thread and a column part in LDS
+template <int Q, int EPT, bool SPLIT = false>
 struct ColLean {
-  static constexpr bool BRALDS = (FL & 1) != 0;   // bra neighbours of the stride-1 oscillator from LDS instead of lane shifts
-  static constexpr bool NOFENCE = (FL & 2) != 0;  // no scheduling fence between the slots
-  static constexpr bool FIXIT = (FL & 4) != 0;    // measurement only: run maxiter iterations, no norm reduction
   static constexpr int L = Q - 1;  // the stride-1 oscillator (post[Q-1] == 1)
   // thread invariants (functions of the row)
   double su[Q], sd[Q];    // sqrt(i_k + 1) (0 at the top level), sqrt(i_k)
   double g1u[Q], g1d[Q];  // gamma_1 su / gamma_1 sd: thread part of the T1 off-diagonal coefficient, forward / transposed
-  double dw[EPT], dd[EPT];  // Delta = h(I) - h(I'), d = L2 + L1diag of the thread's element in slot j (mastereq.hpp:316-433)
+  double dw[SPLIT ? 1 : EPT], dd[SPLIT ? 1 : EPT];  // Delta = h(I) - h(I'), d = L2 + L1diag of the element in slot j (mastereq.hpp:316-433)
+  double hrow, drow, g2ia[Q];  // SPLIT: h(I), the row part of d, gamma_2 i_k
+  unsigned ctb;                // SPLIT: LDS byte address of the wave's first entry of the column table (h(I'), column part of d, i'_k)
   unsigned tb;              // LDS byte address of (row, first column of the wave) in the buffer being READ
   unsigned aru[Q], ard[Q];  // the same with the row moved up / down by post[k] where that bra neighbour exists (else tb)
   int dlt;                  // byte distance from the buffer being read to the other one (+- bufbytes)
@@ -59,7 +60,8 @@ struct ColLean {
   __device__ __forceinline__ int elem(int j) const { return (col0 + j) * N + row; }  // vectorised index (valid slots only)
   static __host__ __device__ int ncols(int N) { return (N + EPT - 1) / EPT * EPT; }
   static __host__ __device__ unsigned bufbytes(int N) { return (unsigned)ncols(N) * COLB; }
-  static size_t lds_bytes(int N) { return 2 * (size_t)bufbytes(N) + 2 * sizeof(double) * NRED * (size_t)(ncols(N) / EPT) + 128; }
+  static __host__ __device__ unsigned tab_off(int N) { return 2 * bufbytes(N) + 2 * (unsigned)sizeof(double) * NRED * (unsigned)(ncols(N) / EPT) + 128; }
+  static size_t lds_bytes(int N) { return (size_t)tab_off(N) + 48 * (size_t)ncols(N); }
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* sm) {
     smem = sm;
@@ -77,7 +79,7 @@ struct ColLean {
     tb = (unsigned)col0 * COLB + (unsigned)lane * 16u;
     dlt = (int)bufbytes(N);
     int ia[Q];
-    double hd = 0.0, drow = 0.0;  // h(I) and the row part of d
+    double hd = 0.0;  // h(I)
 #pragma unroll
     for (int k = 0; k < Q; k++) {
       ia[k] = rowok ? (row / S.post[k]) % S.n[k] : 0;
@@ -97,7 +99,37 @@ struct ColLean {
         for (int l = k + 1; l < Q; l++) hd -= S.xikl[pair++] * ia[k] * ia[l];
       }
     }
-    (void)drow;
+    hrow = rowok ? hd : 0.0;
+    drow = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      drow -= 0.5 * S.g2[k] * ia[k] * ia[k] + 0.5 * S.g1[k] * ia[k];
+      g2ia[k] = rowok ? S.g2[k] * ia[k] : 0.0;
+    }
+    if (!rowok) drow = 0.0;
+    ctb = tab_off(N) + (unsigned)col0 * 48u;
+    if (SPLIT) {  // column table: (h(I'), column part of d), (i'_0, i'_1), (i'_2, 0); zeros for idle columns
+      for (int cc = threadIdx.x; cc < ncols(N); cc += blockDim.x) {
+        double hc = 0.0, dc = 0.0, ip[3] = {0.0, 0.0, 0.0};
+        if (cc < N) {
+          int ipa[Q], pair = 0;
+#pragma unroll
+          for (int k = 0; k < Q; k++) ipa[k] = (cc / S.post[k]) % S.n[k];
+#pragma unroll
+          for (int k = 0; k < Q; k++) {
+            hc += S.detune[k] * ipa[k] - S.xi[k] / 2.0 * ipa[k] * (ipa[k] - 1);
+            dc -= 0.5 * S.g2[k] * ipa[k] * ipa[k] + 0.5 * S.g1[k] * ipa[k];
+            ip[k] = (double)ipa[k];
+#pragma unroll
+            for (int l = k + 1; l < Q; l++) hc -= S.xikl[pair++] * ipa[k] * ipa[l];
+          }
+        }
+        double2* t = reinterpret_cast<double2*>(smem + tab_off(N) + (unsigned)cc * 48u);
+        t[0] = make_double2(hc, dc);
+        t[1] = make_double2(ip[0], ip[1]);
+        t[2] = make_double2(ip[2], 0.0);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       const int cc = col0 + j;
@@ -120,8 +152,27 @@ struct ColLean {
         ocd[j][k] = uniform_i(dn ? -S.post[k] * (int)COLB : 0);
       }
       const bool live = rowok && cok;
-      dw[j] = live ? hd - hdp : 0.0;
-      dd[j] = live ? d : 0.0;
+      if (!SPLIT) {
+        dw[j] = live ? hd - hdp : 0.0;
+        dd[j] = live ? d : 0.0;
+      }
+    }
+  }
+
+  // diagonal of M at the element in slot j: (Delta, d)
+  __device__ __forceinline__ void diag(int j, double& dwj, double& ddj) const {
+    if (!SPLIT) {
+      dwj = dw[j];
+      ddj = dd[j];
+    } else {
+      const double2 t0 = ld(ctb + (unsigned)j * 48u), t1 = ld(ctb + (unsigned)j * 48u + 16u);
+      dwj = hrow - t0.x;
+      double d = drow + t0.y;
+      d = fma(g2ia[0], t1.x, d);
+      if (Q > 1) d = fma(g2ia[Q > 1 ? 1 : 0], t1.y, d);
+      if (Q > 2) d = fma(g2ia[Q > 2 ? 2 : 0], ld(ctb + (unsigned)j * 48u + 32u).x, d);
+      ddj = rowok ? d : 0.0;
+      if (!rowok) dwj = 0.0;
     }
   }
 
@@ -141,8 +192,8 @@ struct ColLean {
   __device__ __forceinline__ void nbrs(int k, int j, const double2 own, const double2 prev, const double2 next, double2& xu, double2& xd,
                                        double2& xup, double2& xdp) const {
     if (k == L) {
-      xu = BRALDS ? ld(aru[k] + (unsigned)j * COLB) : lane_shift<true>(own);
-      xd = BRALDS ? ld(ard[k] + (unsigned)j * COLB) : lane_shift<false>(own);
+      xu = lane_shift<true>(own);
+      xd = lane_shift<false>(own);
       xup = j < EPT - 1 ? next : ld(tb + (unsigned)ocu[j][k] + (unsigned)j * COLB);
       xdp = j > 0 ? prev : ld(tb + (unsigned)ocd[j][k] + (unsigned)j * COLB);
     } else {
@@ -154,12 +205,17 @@ struct ColLean {
   }
 
   // y = M x (TRANS = false) or M^T x at slot j (ColStencil::apply of qd_device.h; HASJ = false)
-  template <bool TRANS>
+  // NODIAG: only the off-diagonal part C = M - diag(M) (the diagonal-split solver applies the diagonal in closed form)
+  template <bool TRANS, bool NODIAG = false>
   __device__ __forceinline__ double2 apply(const StepC<Q>& c, int j, const double2 own, const double2 prev, const double2 next) const {
-    const double dwj = TRANS ? -dw[j] : dw[j];
-    double ar = dd[j] * own.x, ai = dd[j] * own.y;
-    ar = fma(dwj, own.y, ar);
-    ai = fma(-dwj, own.x, ai);
+    double ar = 0.0, ai = 0.0;
+    if (!NODIAG) {
+      double dwj, ddj;
+      diag(j, dwj, ddj);
+      if (TRANS) dwj = -dwj;
+      ar = fma(dwj, own.y, ddj * own.x);
+      ai = fma(-dwj, own.x, ddj * own.y);
+    }
 #pragma unroll
     for (int k = 0; k < Q; k++) {
       double2 xu, xd, xup, xdp;
@@ -172,8 +228,8 @@ struct ColLean {
       // T1 off-diagonal term: forward couples to (row + s, column + s), transposed to (row - s, column - s)
       double2 xl;
       if (k == L) {
-        if (TRANS) xl = j > 0 ? (BRALDS ? ld(ard[k] + (unsigned)(j - 1) * COLB) : lane_shift<false>(prev)) : ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB);
-        else xl = j < EPT - 1 ? (BRALDS ? ld(aru[k] + (unsigned)(j + 1) * COLB) : lane_shift<true>(next)) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+        if (TRANS) xl = j > 0 ? lane_shift<false>(prev) : ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB);
+        else xl = j < EPT - 1 ? lane_shift<true>(next) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
       } else {
         xl = TRANS ? ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
       }
@@ -209,19 +265,28 @@ struct ColLean {
 };
 
 // per-workgroup machinery: buffers, reductions, the Neumann solver
-template <int Q, int EPT, int FL = 0>
+template <int Q, int EPT, bool SPLIT = false>
 struct ColTeam {
-  typedef ColLean<Q, EPT, FL> ST;
+  typedef ColLean<Q, EPT, SPLIT> ST;
   ST st;
   double* red;
   float4* fred;  // two slots of 16 partial sums of the solver's fp32 norm reduction
   int redslot, nw;
+  // diagonal-split solver: P = (1 - alpha D)^-1 of the thread's elements, D = diag(M) = d - i Delta (transposed: d + i Delta),
+  // for the step size palpha (recomputed when the step size changes: composite steppers)
+  double pr[SPLIT ? EPT : 1], pi[SPLIT ? EPT : 1], palpha;
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
     st.init(S, smem);
     red = reinterpret_cast<double*>(smem + 2 * ST::bufbytes(S.N));
     redslot = 0;
     nw = (int)(blockDim.x >> 6);
+    palpha = 0.0;
+#pragma unroll
+    for (int j = 0; j < (SPLIT ? EPT : 1); j++) {
+      pr[j] = 1.0;
+      pi[j] = 0.0;
+    }
     fred = reinterpret_cast<float4*>(red + 2 * NRED * nw);
     if (threadIdx.x < 32) reinterpret_cast<float*>(fred)[threadIdx.x] = 0.f;  // (16 partial sums are read whatever the number of waves)
     __syncthreads();  // zero fill complete
@@ -259,16 +324,40 @@ struct ColTeam {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       y[j] = st.template apply<TRANS>(c, j, x[j], x[j > 0 ? j - 1 : 0], x[j + 1 < EPT ? j + 1 : j]);
-      if (!ST::NOFENCE) slot_fence<EPT>();
+      slot_fence<EPT>();
     }
   }
 
-  // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727); stopping rule on squared
-  // norms reduced in fp32 exactly as Team::neumann of qd_device.h.  Returns the number of RHS applications; y in registers.
+  template <bool TRANS>
+  __device__ __forceinline__ void set_alpha(double alpha) {
+    if (alpha == palpha) return;  // (uniform)
+    palpha = alpha;
+#pragma unroll
+    for (int j = 0; j < (SPLIT ? EPT : 0); j++) {
+      double dwj, ddj;
+      st.diag(j, dwj, ddj);
+      const double re = fma(-alpha, ddj, 1.0), im = (TRANS ? -alpha : alpha) * dwj;  // 1 - alpha D
+      const double inv = 1.0 / fma(re, re, im * im);
+      pr[j] = re * inv;
+      pi[j] = -im * inv;
+    }
+  }
+
+  // Solve (I - alpha M^{(T)}) y = b.  Returns the number of RHS applications; y in registers.
+  // SPLIT = false: the reference's Neumann iteration y <- b + alpha M y (timestepper.cpp:697-727), started at y = b.
+  // SPLIT = true: the same fixed point and the same stopping rule on the update norm, with the diagonal of M taken to the left-hand
+  // side: y <- (1 - alpha D)^-1 (b + alpha (M - D) y), started at (1 - alpha D)^-1 b.  D carries the level energies (self- and
+  // cross-Kerr shifts, detuning) and the diagonal decay: where those dominate the control Hamiltonian the contraction factor drops
+  // from ||alpha M|| to ~||alpha (M - D)|| (3 x 20 workload: 12.4 -> 8.x iterations per solve) at the same cost per iteration.
+  // The squared update norm is reduced in fp32 exactly as Team::neumann of qd_device.h.
   template <bool TRANS>
   __device__ __forceinline__ int neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&b)[EPT], double2 (&y)[EPT]) {
+    // (set_alpha<TRANS>(alpha) has been called at the top of the step: no control flow between an operator application and its use)
 #pragma unroll
-    for (int j = 0; j < EPT; j++) y[j] = b[j];
+    for (int j = 0; j < EPT; j++) {
+      if (SPLIT) y[j] = make_double2(fma(pr[SPLIT ? j : 0], b[j].x, -pi[SPLIT ? j : 0] * b[j].y), fma(pr[SPLIT ? j : 0], b[j].y, pi[SPLIT ? j : 0] * b[j].x));
+      else y[j] = b[j];
+    }
     publish(y);
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
     const float rel2 = (float)(A.reltol * A.reltol);
@@ -281,24 +370,19 @@ struct ColTeam {
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         const double2 own = y[j];
-        const double2 t = st.template apply<TRANS>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
+        const double2 t = st.template apply<TRANS, SPLIT>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
         double2 w;
         w.x = fma(alpha, t.x, b[j].x);
         w.y = fma(alpha, t.y, b[j].y);
+        if (SPLIT) w = make_double2(fma(pr[SPLIT ? j : 0], w.x, -pi[SPLIT ? j : 0] * w.y), fma(pr[SPLIT ? j : 0], w.y, pi[SPLIT ? j : 0] * w.x));
         const double dx = own.x - w.x, dy = own.y - w.y;
         dl = fma(dx, dx, fma(dy, dy, dl));
         prev = own;
         y[j] = w;
         st.st(wa + (unsigned)j * COLB, w);
-        if (!ST::NOFENCE) slot_fence<EPT>();
+        slot_fence<EPT>();
       }
-      float d;
-      if (ST::FIXIT) {
-        d = (float)dl + 2.f;
-        __syncthreads();
-      } else {
-        d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
-      }
+      const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
       st.flip();
       if (iter == 0) d0 = d;
       if (d < 1.f) { iter++; break; }
@@ -311,10 +395,10 @@ struct ColTeam {
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, int FL = 0>
+template <int Q, int EPT, bool SPLIT>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT, FL> TM;
+  typedef ColTeam<Q, EPT, SPLIT> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -353,6 +437,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
     scalarize<Q>(c, false);
+    if (SPLIT) tm.template set_alpha<false>(0.5 * c.h);
     if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
     // x is not needed during the linear solve: parked in the output buffer (L2 resident) BEFORE the right-hand side is formed, so that
     // no control flow separates the operator application from the solver that consumes it
@@ -422,10 +507,10 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT>
+template <int Q, int EPT, bool SPLIT>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT> TM;
+  typedef ColTeam<Q, EPT, SPLIT> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -477,6 +562,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
     scalarize<Q>(c, false);
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z of the sub-step was stored by the forward sweep
+    if (SPLIT) tm.template set_alpha<true>(0.5 * c.h);
     double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
     tm.template neumann<true>(A, c, 0.5 * c.h, xb, kb);
 #pragma unroll
@@ -533,11 +619,11 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
 }
 
 // single operator application (test hook = MatMult / MatMultTranspose on the shell)
-template <int Q, int EPT>
+template <int Q, int EPT, bool SPLIT>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_apply_col(const DevSys S, const double* __restrict__ ctlrow, int transpose, const double* __restrict__ xin,
                                                           double* __restrict__ yout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT> TM;
+  typedef ColTeam<Q, EPT, SPLIT> TM;
   TM tm;
   tm.init(S, smem);
   const int ic = blockIdx.x, dim = S.dim;
@@ -570,18 +656,19 @@ static hipError_t set_lds_col(K kern, size_t bytes) {
 
 // Lindblad, matrix-free, no dipole-dipole coupling, runtime level counts that are not all 2, two or three oscillators, a density
 // matrix of 33..64 rows (one lane per row), the last oscillator with stride 1 (always: post[Q-1] == 1)
-bool collean_available(const DevSys& S) {
+bool collean_available(const DevSys& S, const TuneOpts& o) {
+  if (o.no_collean) return false;
   if (!S.lindblad || S.dense || S.hasJ || (S.Q != 2 && S.Q != 3) || S.N < 33 || S.N > 64) return false;
   bool qubit = true;
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2;
   return !qubit && S.post[S.Q - 1] == 1;
 }
 
-template <int Q, int EPT, int FL>
-static hipError_t go_fwd_col_fl(const SweepArgs& a, hipStream_t st) {
+template <int Q, int EPT, bool SPLIT>
+static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  auto kf = k_forward_col<Q, EPT, FL>;
+  auto kf = k_forward_col<Q, EPT, SPLIT>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(a.nb), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
@@ -589,32 +676,28 @@ static hipError_t go_fwd_col_fl(const SweepArgs& a, hipStream_t st) {
 }
 template <int Q, int EPT>
 static hipError_t go_fwd_col(const SweepArgs& a, hipStream_t st) {
-  if constexpr (Q == 2 && (EPT == 4 || EPT == 8)) {  // measurement variants (QD_COL_X)
-    const char* e = getenv("QD_COL_X");
-    switch (e ? atoi(e) : 0) {
-      case 1: return go_fwd_col_fl<Q, EPT, 1>(a, st);
-      case 2: return go_fwd_col_fl<Q, EPT, 2>(a, st);
-      case 4: return go_fwd_col_fl<Q, EPT, 4>(a, st);
-      default: break;
-    }
-  }
-  return go_fwd_col_fl<Q, EPT, 0>(a, st);
+  return a.neumann_split ? go_fwd_col_s<Q, EPT, true>(a, st) : go_fwd_col_s<Q, EPT, false>(a, st);
 }
-template <int Q, int EPT>
-static hipError_t go_adj_col(const SweepArgs& a, hipStream_t st) {
+template <int Q, int EPT, bool SPLIT>
+static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  auto kf = k_adjoint_col<Q, EPT>;
+  auto kf = k_adjoint_col<Q, EPT, SPLIT>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(a.nb), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
   return hipGetLastError();
 }
 template <int Q, int EPT>
-static hipError_t go_app_col(const DevSys& S, const double* ctlrow, int tr, const double* x, double* y, int nb, hipStream_t st) {
+static hipError_t go_adj_col(const SweepArgs& a, hipStream_t st) {
+  return a.neumann_split ? go_adj_col_s<Q, EPT, true>(a, st) : go_adj_col_s<Q, EPT, false>(a, st);
+}
+template <int Q, int EPT>
+static hipError_t go_app_col(const DevSys& S, const double* ctlrow, int tr, const double* x, double* y, int nb, bool split, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(S.N);
-  auto kf = k_apply_col<Q, EPT>;
+  // (the option neumann_split = 1 selects the kernel family that re-derives the diagonal from its compact form: test coverage)
+  auto kf = split ? k_apply_col<Q, EPT, true> : k_apply_col<Q, EPT, false>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(nb), dim3(64 * (ST::ncols(S.N) / EPT)), lds, st, S, ctlrow, tr, x, y);
@@ -624,20 +707,15 @@ static hipError_t go_app_col(const DevSys& S, const double* ctlrow, int tr, cons
 // Columns per wave.  Measured on the 3 x 20 workload (3600 initial conditions x 100 steps, forward sweep, one lease): 4 columns
 // (15 waves, 128 VGPRs, 63 spills) 58.9 ms, 5 columns (12 waves, 168 VGPRs) 48.4 ms, 6 columns (10 waves, 59 spills) 62.9 ms,
 // 8 columns (8 waves, 234 VGPRs, no spills) 53.4 ms; the general column kernel of qd_device.h 73.1 ms.  Five columns per wave cover
-// N <= 60, eight the rest.  QD_COL_EPT overrides (measurements).
-static int col_ept(int N) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("QD_COL_EPT");
-    forced = e ? atoi(e) : 0;
-    if (forced != 4 && forced != 5 && forced != 6 && forced != 8) forced = 0;
-  }
-  if (forced) return forced;
+// N <= 60, eight the rest.  The option col_ept overrides (measurements).
+static int col_ept(int N, const TuneOpts& o) {
+  const int f = o.col_ept;
+  if (f == 4 || f == 6 || f == 8 || (f == 5 && N <= 60)) return f;
   return N <= 60 ? 5 : 8;
 }
 #define QD_COL_DISPATCH(FN, ...)                                  \
   do {                                                            \
-    const int e = col_ept(Nn);                                      \
+    const int e = col_ept(Nn, o);                                      \
     if (Qn == 2) {                                                \
       if (e == 4) return FN<2, 4>(__VA_ARGS__);                   \
       if (e == 5 && Nn <= 60) return FN<2, 5>(__VA_ARGS__);       \
@@ -653,17 +731,17 @@ static int col_ept(int N) {
     return hipErrorInvalidValue;                                  \
   } while (0)
 
-hipError_t launch_forward_col(const SweepArgs& a, hipStream_t st) {
+hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   const int Qn = a.S.Q, Nn = a.S.N;
   QD_COL_DISPATCH(go_fwd_col, a, st);
 }
-hipError_t launch_adjoint_col(const SweepArgs& a, hipStream_t st) {
+hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   const int Qn = a.S.Q, Nn = a.S.N;
   QD_COL_DISPATCH(go_adj_col, a, st);
 }
-hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
+hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, const TuneOpts& o, hipStream_t st) {
   const int Qn = S.Q, Nn = S.N;
-  QD_COL_DISPATCH(go_app_col, S, ctlrow, transpose, x, y, nb, st);
+  QD_COL_DISPATCH(go_app_col, S, ctlrow, transpose, x, y, nb, o.neumann_split == 1, st);
 }
 
 }  // namespace qd

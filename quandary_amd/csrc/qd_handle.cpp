@@ -98,6 +98,7 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
 
   qd_handle* h = new qd_handle();
   h->device = device_ordinal;
+  h->opts.load_env();  // QD_<KEY>: overrides for tests and measurements, read once
   h->tg = *tg;
   h->sol = *sol;
   // ---- system constants: src/mastereq.cpp:14-60, src/oscillator.cpp:15-23, src/main.cpp:299-307
@@ -368,6 +369,13 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   return QD_OK;
 }
 
+extern "C" int qd_set_option(qd_handle* h, const char* key, const char* value) {
+  if (!h || !key || !value) return fail(QD_ERR_INVALID, "qd_set_option: null argument");
+  if (h->opts.set(key, value) != 0) return fail(QD_ERR_INVALID, std::string("qd_set_option: unknown key or bad value: ") + key + " = " + value);
+  h->traj_valid = false;  // (a stored trajectory may have another layout under the new options)
+  return QD_OK;
+}
+
 extern "C" int qd_get_precision(const qd_handle* h) { return h ? h->precision : QD_ERR_INVALID; }
 
 extern "C" int qd_set_precision(qd_handle* h, int precision) {
@@ -494,7 +502,7 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
   QD_HIP(hipMemcpyAsync(h->d_onetime.p, tt, sizeof tt, hipMemcpyHostToDevice, h->stream));
   QD_HIP(launch_controls(h->dctl, h->d_params.p, h->d_onetime.p, h->d_onetime.p + 1, 1, h->d_onerow.p, h->cs, h->stream));
   QD_HIP(hipMemcpyAsync(h->d_x0.p, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  LaunchCfg cfg = pick_config(h->S, nb);
+  LaunchCfg cfg = pick_config(h->S, nb, h->opts);
   if ((r = check_cfg(cfg))) return r;
   if (cfg.var == 16 && (r = h->ensure_big(nb))) return r;
   qd::DevSys Sone = h->S;
@@ -503,9 +511,9 @@ extern "C" int qd_apply_rhs(qd_handle* h, double t, int transpose, const double*
     QD_HIP(launch_gmat(h->S, h->d_g0.p, h->d_onerow.p, h->cs, 1, h->d_gone.p, h->stream));
     Sone.gtab = h->d_gone.p;
   }
-  if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->stream));
-  else if (cfg.var != 16 && lean64_available(h->S)) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
-  else if (cfg.var == 9 && collean_available(h->S) && !getenv("QD_NO_COLLEAN")) QD_HIP(launch_apply_col(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
+  if (h->precision == QD_PRECISION_F32MIXED) QD_HIP(launch_apply_f32(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, 1, 0, h->opts, h->stream));
+  else if (cfg.var != 16 && lean64_available(h->S, h->opts)) QD_HIP(launch_apply_lean64(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->stream));
+  else if (cfg.var == 9 && collean_available(h->S, h->opts)) QD_HIP(launch_apply_col(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, h->opts, h->stream));
   else QD_HIP(launch_apply(Sone, h->d_onerow.p, transpose, h->d_x0.p, h->d_y.p, nb, cfg, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));
@@ -564,13 +572,12 @@ size_t qd_handle::ztraj_doubles(int nb) const {
 // sweep in forward_finish, starting at 6) where the series provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
 // sub-step, from the system constants and the CURRENT control parameters (|p_k(t)|, |q_k(t)| <= sum over carriers of
 // max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
-// by their amplitude).  QD_GMRES_POLY overrides the degree (1 = never precondition).
-int qd_handle::gmres_poly_degree() const {
-  const int want = getenv("QD_GMRES_POLY") ? std::max(1, atoi(getenv("QD_GMRES_POLY"))) : poly_cur;  // tuned in forward_finish
-  // only where the Krylov basis traffic is the cost (dim > 1024: the column / eight-elements-per-thread kernels); below
-  // that plain GMRES keeps the oracle's iteration path, and with it results that agree far below the solver tolerance
-  if (want <= 1 || S.dense || S.dim <= 1024) return 1;
-  // diagonal: |Delta| <= hmax (Schroedinger) or 2 hmax (Lindblad), hmax = max_I |h(I)|; |d| and the T1 off-diagonal row entry
+// by their amplitude).  The option gmres_poly overrides the degree (1 = never precondition).
+// Gershgorin bounds of one row of M(t) over all sub-steps, from the system constants and the CURRENT control parameters:
+// diag = |Delta| + |d| (level energies, diagonal decay), off = the T1 off-diagonal entry, the control ladder entries (|p_k(t)|,
+// |q_k(t)| <= sum over carriers of max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity,
+// src/controlbasis.cpp:81-96; pi-pulses by their amplitude) and the dipole-dipole couplings.
+void qd_handle::row_bounds(double* diag, double* off) const {
   double hmax = 0.0;
   {
     std::vector<int> dg(S.Q, 0);
@@ -586,10 +593,13 @@ int qd_handle::gmres_poly_degree() const {
       hmax = std::max(hmax, fabs(hd));
     }
   }
-  double row = S.lindblad ? 2.0 * hmax : hmax;
+  double dg = S.lindblad ? 2.0 * hmax : hmax, of = 0.0;
   for (int k = 0; k < S.Q; k++) {
     const double nm = S.n[k] - 1.0;
-    if (S.lindblad) row += fabs(S.g2[k]) * nm * nm / 2.0 + fabs(S.g1[k]) * nm + fabs(S.g1off[k]) * nm;
+    if (S.lindblad) {
+      dg += fabs(S.g2[k]) * nm * nm / 2.0 + fabs(S.g1[k]) * nm;
+      of += fabs(S.g1off[k]) * nm;
+    }
     // controls: each of the (2 or 4) ladder neighbours carries |q| + |p| times sqrt(level)
     double amp = 0.0;
     const DevOsc& o = oscs[k];
@@ -615,15 +625,41 @@ int qd_handle::gmres_poly_degree() const {
       amp = std::max(amp, a);
     }
     for (int i = 0; i < o.npulse; i++) amp = std::max(amp, fabs(pulses[(size_t)(o.pulse_begin + i) * 3 + 2]));
-    row += 2.0 * amp * (S.lindblad ? 2.0 : 1.0) * (sqrt(nm) + sqrt(std::max(nm - 1.0, 0.0)));
+    of += 2.0 * amp * (S.lindblad ? 2.0 : 1.0) * (sqrt(nm) + sqrt(std::max(nm - 1.0, 0.0)));
   }
   int pair = 0;
   for (int k = 0; k < S.Q; k++)
     for (int l = k + 1; l < S.Q; l++, pair++)
-      row += fabs(S.J[pair]) * (S.lindblad ? 4.0 : 2.0) * sqrt((S.n[k] - 1.0) * (S.n[l] - 1.0)) * 2.0;
+      of += fabs(S.J[pair]) * (S.lindblad ? 4.0 : 2.0) * sqrt((S.n[k] - 1.0) * (S.n[l] - 1.0)) * 2.0;
+  *diag = dg;
+  *off = of;
+}
+
+int qd_handle::gmres_poly_degree() const {
+  const int want = opts.gmres_poly > 0 ? opts.gmres_poly : poly_cur;  // tuned in forward_finish
+  // only where the Krylov basis traffic is the cost (dim > 1024: the column / eight-elements-per-thread kernels); below
+  // that plain GMRES keeps the oracle's iteration path, and with it results that agree far below the solver tolerance
+  if (want <= 1 || S.dense || S.dim <= 1024) return 1;
+  double dg, of;
+  row_bounds(&dg, &of);
   double amax = 0.0;
   for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
-  return amax * row <= 0.7 ? want : 1;
+  return amax * (dg + of) <= 0.7 ? want : 1;
+}
+
+bool qd_handle::use_col(const qd::LaunchCfg& cfg) const {
+  return precision == QD_PRECISION_F64 && cfg.var == 9 && !cfg.gmres && collean_available(S, opts) && sol.stepper != QD_STEPPER_EE;
+}
+
+// Diagonal-split Neumann iteration (qd_col.hip): same fixed point and stopping rule, the diagonal of M on the left-hand side.  It
+// costs nothing per iteration, so "where it pays" is wherever the diagonal (level energies, decay) is a visible share of the row
+// bound: alpha (diag + off) is the contraction bound of the plain iteration, alpha off that of the split one.
+int qd_handle::neumann_split_on() const {
+  if (opts.neumann_split >= 0) return opts.neumann_split;
+  if (S.dense) return 0;
+  double dg, of;
+  row_bounds(&dg, &of);
+  return dg >= 0.25 * of ? 1 : 0;
 }
 
 static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget* tg) {
@@ -644,6 +680,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.abstol = h->sol.abstol;
   a.reltol = h->sol.reltol;
   a.gmres_poly = h->gmres_poly_degree();
+  a.neumann_split = h->neumann_split_on();
   // penalties that need target data are only active when a target has been set
   a.gamma_penalty = h->pen.gamma_penalty;
   a.penalty_param = tg ? h->pen.penalty_param : 0.0;
@@ -681,7 +718,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     if (ztraj_doubles(nb) && (r = d_ztraj.ensure(ztraj_doubles(nb)))) return r;
   }
   {
-    LaunchCfg c0 = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+    LaunchCfg c0 = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES);
     if (c0.var == 16 && (r = ensure_big(nb))) return r;
   }
   SweepArgs a;
@@ -694,7 +731,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   a.pen_out = d_pen;
   a.dpdm_out = d_dpdm;
   a.napply = d_napply;
-  LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES);
+  LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES);
   last_var = cfg.var;
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
@@ -705,10 +742,10 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if ((r = check_cfg(cfg))) return r;
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
-  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
-  if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, stream));
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
+  if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
-  else if (cfg.var == 9 && !cfg.gmres && collean_available(S) && sol.stepper != QD_STEPPER_EE && !getenv("QD_NO_COLLEAN")) QD_HIP(launch_forward_col(a, stream));
+  else if (use_col(cfg)) QD_HIP(launch_forward_col(a, opts, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));
@@ -735,7 +772,7 @@ int qd_handle::forward_finish(double* energy) {
   // orthogonalisation, reductions and basis traffic (k = Krylov vectors; on the 3x20 workload one such round costs as much as five
   // applications), so the best p is the smallest one for which (almost) every solve needs a single Krylov vector.  k is known after
   // every forward sweep: bracket p between the largest degree seen with k > 1 and the smallest seen with k = 1, bisect, stay.
-  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && !getenv("QD_GMRES_POLY")) {
+  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && opts.gmres_poly == 0) {
     const double per_solve = (double)nap / ((double)nb * (double)nsub);
     const double k = (per_solve - 1.0) / last_poly;
     if (k > 1.02) {
@@ -852,7 +889,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   const size_t ncol = (size_t)nsub * 2 * S.Q;
   if ((r = d_coeff.ensure((size_t)nb * ncol)) || (r = d_coeffsum.ensure(ncol))) return r;
   {
-    LaunchCfg c0 = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, true);
+    LaunchCfg c0 = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES, true);
     if (c0.var == 16 && (r = ensure_big(nb))) return r;
   }
   SweepArgs a;
@@ -863,7 +900,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   a.xbarT = dxbarT;
   a.jbar = djbar;
   a.coeff = d_coeff.p;
-  LaunchCfg cfg = pick_config(S, nb, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
+  LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
@@ -872,10 +909,10 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
-  const bool lean64 = cfg.var != 16 && lean64_available(S) && sol.stepper != QD_STEPPER_EE;
-  if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, stream));
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
+  if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, stream));
-  else if (cfg.var == 9 && !cfg.gmres && collean_available(S) && sol.stepper != QD_STEPPER_EE && !getenv("QD_NO_COLLEAN")) QD_HIP(launch_adjoint_col(a, stream));
+  else if (use_col(cfg)) QD_HIP(launch_adjoint_col(a, opts, stream));
   else QD_HIP(launch_adjoint(a, cfg, stream));
   QD_HIP(hipEventRecord(ev3, stream));
   QD_HIP(launch_reduce_coeff(d_coeff.p, nb, (int)ncol, d_coeffsum.p, accumulate ? 1 : 0, stream));
@@ -949,9 +986,9 @@ extern "C" int qd_bench_apply_f32(qd_handle* h, double t, const double* x, doubl
   QD_HIP(hipMemcpyAsync(h->d_onetime.p, tt, sizeof tt, hipMemcpyHostToDevice, h->stream));
   QD_HIP(launch_controls(h->dctl, h->d_params.p, h->d_onetime.p, h->d_onetime.p + 1, 1, h->d_onerow.p, h->cs, h->stream));
   QD_HIP(hipMemcpyAsync(h->d_x0.p, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  QD_HIP(launch_apply_f32(S, h->d_onerow.p, 0, h->d_x0.p, h->d_y.p, nb, nrep, mfma, h->stream));  // warm-up
+  QD_HIP(launch_apply_f32(S, h->d_onerow.p, 0, h->d_x0.p, h->d_y.p, nb, nrep, mfma, h->opts, h->stream));  // warm-up
   QD_HIP(hipEventRecord(h->ev0, h->stream));
-  QD_HIP(launch_apply_f32(S, h->d_onerow.p, 0, h->d_x0.p, h->d_y.p, nb, nrep, mfma, h->stream));
+  QD_HIP(launch_apply_f32(S, h->d_onerow.p, 0, h->d_x0.p, h->d_y.p, nb, nrep, mfma, h->opts, h->stream));
   QD_HIP(hipEventRecord(h->ev1, h->stream));
   QD_HIP(hipMemcpyAsync(y, h->d_y.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   QD_HIP(hipStreamSynchronize(h->stream));

@@ -78,6 +78,9 @@ struct HBuf {
 struct qd_handle {
   int device = 0;
   int precision = QD_PRECISION_F64;  // qd_set_precision
+  qd::TuneOpts opts;                 // qd_set_option (+ environment overrides read at qd_create)
+  bool use_col(const qd::LaunchCfg& cfg) const;  // the sweep runs on the lean column kernels (qd_col.hip)
+  int neumann_split_on() const;      // diagonal-split Neumann iteration for the current parameters
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // forward / adjoint kernel brackets
   qd::DevSys S{};
@@ -129,6 +132,7 @@ struct qd_handle {
 
   // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
   int refresh_tables();
+  void row_bounds(double* diag, double* off) const;  // Gershgorin bounds of a row of M over all sub-steps (current parameters)
   int gmres_poly_degree() const;  // > 1 where the Neumann series provably contracts for the current parameters, else 1
   // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
   int poly_cur = 6, poly_lo = 1, poly_hi = 0, last_poly = 1, last_var = 0;

@@ -76,6 +76,7 @@ struct SweepArgs {
   double dt, Tfinal;
   int stepper_ee, linsolve, maxiter;
   int gmres_poly;  // degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (1 = none)
+  int neumann_split;  // lean column kernels (qd_col.hip): diagonal of M on the left-hand side of the Neumann iteration
   int use_gmres;  // 0: Neumann; 1: in-kernel GMRES, Krylov basis in LDS (one element per thread, small dim); 2: basis in global memory (kry)
   double abstol, reltol;
   // penalties (src/timestepper.cpp:256-480)
@@ -105,6 +106,25 @@ struct SweepArgs {
 constexpr int BIG_TEAM_MAX = 256;   // workgroups per initial condition
 constexpr int BIG_RED_NV = 16;      // doubles per member in the team reduction buffer
 constexpr int BIG_BAR_STRIDE = 16 * 9;  // per team: the team's counter and eight first-level counters, 128 B apart
+
+// Tuning and test options of a handle (qd_set_option, include/quandary_amd.h).  Every key can also be given as the environment
+// variable QD_<KEY IN CAPITALS>; the environment is read ONCE, when the handle is created, as an override for tests and measurements.
+struct TuneOpts {
+  int var = -1;            // "var": force a kernel variant of qd_device.h (-1 = automatic choice)
+  int force_neumann = 0;   // "force_neumann": ignore linearsolver_type = gmres
+  int no_mfma = 0;         // "no_mfma": dense operator on the vector kernels
+  int big_team = 0;        // "big_team": workgroups per initial condition of the global-memory sweeps (0 = automatic)
+  int big_spread = -1;     // "big_spread": team members dealt over all XCDs (1), kept on one (0), default (-1)
+  int f32_sb = -1;         // "f32_sb": slot bits of the fp32-mixed 2^4 kernel
+  int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
+  int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
+  int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
+  int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
+  int neumann_split = -1;  // "neumann_split": diagonal-split Neumann iteration (-1 = where it pays, 0 = never, 1 = wherever it is built)
+  double traj_budget_mb = 0.0;  // "traj_budget_mb": pretend the trajectory budget is this small (chunked re-propagation)
+  int set(const char* key, const char* value);  // 0 = ok, -1 = unknown key / bad value
+  void load_env();
+};
 
 struct LaunchCfg {
   int var;    // kernel variant (elements per thread, register budget, LDS double buffering; qd_device.h)
@@ -137,21 +157,21 @@ hipError_t launch_reduce_coeff(const double* coeff, int nb, int ncol, double* su
 hipError_t launch_grad(const DevCtlDesc& d, const double* params, const double* table, int cs, int nsub, const double* coeffsum,
                        const double* etable, int nstep, double ebar, double* grad, int ndesign, hipStream_t st);
 // fp32-mixed sweeps of all-qubit Lindblad systems (qd_q32.hip); the trajectory is [nsub+1][nb][dim] float2
-hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st);
-hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st);
+hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
+hipError_t launch_adjoint_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
-                            hipStream_t st);
+                            const TuneOpts& o, hipStream_t st);
 // the same lean slot kernel instantiated in fp64: Neumann sweeps of the 2^5 Lindblad system (QD_PRECISION_F64)
-bool lean64_available(const DevSys& S);
+bool lean64_available(const DevSys& S, const TuneOpts& o);
 hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st);
 hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st);
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
 // lean column kernels (qd_col.hip): Lindblad Neumann sweeps of density matrices with 33..64 rows and runtime level counts
-bool collean_available(const DevSys& S);
-hipError_t launch_forward_col(const SweepArgs& a, hipStream_t st);
-hipError_t launch_adjoint_col(const SweepArgs& a, hipStream_t st);
-hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
-LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres = false, bool adjoint = false);
+bool collean_available(const DevSys& S, const TuneOpts& o);
+hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
+hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
+hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, const TuneOpts& o, hipStream_t st);
+LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmres = false, bool adjoint = false);
 size_t krylov_doubles(const DevSys& S, int nb);
 size_t big_work_doubles(const DevSys& S, int nb);
 hipError_t launch_big_table(const DevSys& S, double* ecoef, unsigned* edig, hipStream_t st);

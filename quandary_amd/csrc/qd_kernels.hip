@@ -432,15 +432,15 @@ static const VarInfo kVar[NVARIANTS] = {var_info<0>(), var_info<1>(), var_info<2
                                         var_info<15>(), var_info<16>(), var_info<17>()};
 int variant_max_block(int var) { return (var >= 0 && var < NVARIANTS) ? kVar[var].maxb : 0; }
 
-void big_team(const DevSys& S, int nb, int& team, int& spread);
-LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
+void big_team(const DevSys& S, int nb, const TuneOpts& o, int& team, int& spread);
+LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmres, bool adjoint) {
   LaunchCfg c{};
   const int dim = S.dim;
   bool qubit = true;
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
   if (S.dense) qubit = false;
   c.qubit = S.dense ? 2 : qubit ? 1 : 0;
-  const bool gm = want_gmres && !getenv("QD_FORCE_NEUMANN");
+  const bool gm = want_gmres && !o.force_neumann;
   // column layout (V8/V9): one wave per column of rho, N <= 64 lanes used
   // V14 packs floor(64 / N) columns into one wave slot
   auto colblock = [&](int v) {
@@ -465,24 +465,24 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
   // N = 49 4.3M vs 6.7M, N = 64 3.3M vs 5.2M
   else var = (fits(QD_COL_DEFAULT) && S.N >= 44) ? QD_COL_DEFAULT : 4;
   if (S.dense) var = dim <= 64 ? 11 : dim <= 256 ? 12 : 13;  // qd_set_hamiltonian limits dim to 1024
-  // matrix cores for the dense operator and (adjoint sweep) for the gradient contraction's 2Q commutators per step; QD_NO_MFMA
+  // matrix cores for the dense operator and (adjoint sweep) for the gradient contraction's 2Q commutators per step; the option no_mfma
   // keeps the vector kernels (measurements)
-  if (S.dense && S.lindblad && S.N == 16 && !getenv("QD_NO_MFMA")) var = 15;
+  if (S.dense && S.lindblad && S.N == 16 && !o.no_mfma) var = 15;
   // (zero-padded 32 x 32 tiles pay the full 32^3 products: worth it from N = 22 on, 96.8 ms x (N / 32)^3 against 23.7 ms)
-  if (S.dense && S.lindblad && S.N >= 22 && S.N <= 32 && !getenv("QD_NO_MFMA")) var = 17;
-  if (const char* ev = getenv("QD_VAR")) {  // tuning override
-    const int v = atoi(ev);
+  if (S.dense && S.lindblad && S.N >= 22 && S.N <= 32 && !o.no_mfma) var = 17;
+  if (o.var >= 0) {  // tuning override
+    const int v = o.var;
     if (v >= 0 && v < NVARIANTS && built(v) && fits(v)) var = v;
   }
   // beyond one CU's LDS: work vectors in global memory (qd_big.h); general stencil whatever the level structure.
-  // QD_VAR=16 forces it onto small systems (parity tests of this path against everything the LDS kernels are tested on)
-  if ((S.dense ? dim > 1024 : dim > 4096) || (getenv("QD_VAR") && atoi(getenv("QD_VAR")) == 16)) {
+  // the option var = 16 forces it onto small systems (parity tests of this path against everything the LDS kernels are tested on)
+  if ((S.dense ? dim > 1024 : dim > 4096) || o.var == 16) {
     c.var = 16;
     c.qubit = S.dense ? 2 : 0;
     c.block = BIG_BLOCK;
     c.gmres = gm ? 2 : 0;
     c.lds = BigTeam<1, false>::lds_bytes(S);
-    big_team(S, nb, c.team, c.spread);
+    big_team(S, nb, o, c.team, c.spread);
     return c;
   }
   const int epe = kVar[var].ept / kVar[var].icpb;
@@ -509,8 +509,8 @@ LaunchCfg pick_config(const DevSys& S, int nb, bool want_gmres, bool adjoint) {
 // are about two per operator application, one workgroup alone needs 2-17 ns per element and application: the team grows while it
 // leaves each thread at least half an element, up to 64 members, and while all teams stay resident (one 1024-thread workgroup per
 // CU is what the register budget of these kernels allows for sure; the cooperative launch checks it).  Members dealt over all XCDs
-// by default.  QD_BIG_TEAM / QD_BIG_SPREAD override (tests, measurements: profiles/big_probe.py).
-void big_team(const DevSys& S, int nb, int& team, int& spread) {
+// by default.  the options big_team / big_spread override (tests, measurements: profiles/big_probe.py).
+void big_team(const DevSys& S, int nb, const TuneOpts& o, int& team, int& spread) {
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -518,15 +518,14 @@ void big_team(const DevSys& S, int nb, int& team, int& spread) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
   }
-  const char* es = getenv("QD_BIG_SPREAD");
-  spread = es ? atoi(es) != 0 : 1;
+  spread = o.big_spread >= 0 ? o.big_spread != 0 : 1;
   const int gmax = spread ? BIG_TEAM_MAX : 32;
   const int slots = spread ? nb : (nb + 7) / 8 * 8;
   int g = 1;
   while (g * 2 <= 64 && g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)2 * S.dim >= (size_t)BIG_BLOCK * (g * 2)) g *= 2;
   if (S.dim <= 4096) g = 1;  // (the global-memory kernels forced onto a small system)
-  if (const char* et = getenv("QD_BIG_TEAM")) {
-    const int v = atoi(et);
+  if (o.big_team > 0) {
+    const int v = o.big_team;
     if (v >= 1 && v <= gmax && (v & (v - 1)) == 0 && (long)slots * v <= ncu) g = v;
   }
   team = g;
@@ -535,6 +534,49 @@ void big_team(const DevSys& S, int nb, int& team, int& spread) {
 size_t big_work_doubles(const DevSys& S, int nb) { return (size_t)nb * BIG_NV * 2 * (size_t)S.dim; }
 
 size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G + 2) * 2 * (size_t)S.dim; }
+
+// ---------------------------------------------------------------------------------------------
+// options
+// ---------------------------------------------------------------------------------------------
+static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "f32_sb", "no_lean64", "no_collean",
+                                       "col_ept", "gmres_poly", "neumann_split", "traj_budget_mb"};
+int TuneOpts::set(const char* key, const char* value) {
+  if (!key || !value) return -1;
+  const std::string k(key), v(value);
+  char* end = nullptr;
+  if (k == "traj_budget_mb") {
+    const double d = strtod(value, &end);
+    if (end == value || d < 0.0) return -1;
+    traj_budget_mb = d;
+    return 0;
+  }
+  long iv;
+  if (v == "auto") iv = (k == "var" || k == "big_spread" || k == "f32_sb" || k == "neumann_split") ? -1 : 0;
+  else {
+    iv = strtol(value, &end, 10);
+    if (end == value) return -1;
+  }
+  if (k == "var") var = (int)iv;
+  else if (k == "force_neumann") force_neumann = iv != 0;
+  else if (k == "no_mfma") no_mfma = iv != 0;
+  else if (k == "big_team") big_team = (int)iv;
+  else if (k == "big_spread") big_spread = (int)iv;
+  else if (k == "f32_sb") f32_sb = (int)iv;
+  else if (k == "no_lean64") no_lean64 = iv != 0;
+  else if (k == "no_collean") no_collean = iv != 0;
+  else if (k == "col_ept") col_ept = (int)iv;
+  else if (k == "gmres_poly") gmres_poly = iv > 0 ? (int)iv : 0;
+  else if (k == "neumann_split") neumann_split = iv < 0 ? -1 : iv != 0;
+  else return -1;
+  return 0;
+}
+void TuneOpts::load_env() {
+  for (const char* key : kOptKeys) {
+    std::string name = "QD_";
+    for (const char* c = key; *c; c++) name += (char)toupper((unsigned char)*c);
+    if (const char* ev = getenv(name.c_str())) (void)set(key, ev);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // dispatch to the per-(Q, Lindblad, qubit) translation units (qd_inst.hip)

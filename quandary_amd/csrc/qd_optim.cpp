@@ -514,8 +514,8 @@ static bool trajectory_fits(qd_handle* h, int nb) {
   h->traj_doubles(nb, &need);
   const size_t needz = h->ztraj_doubles(nb);  // the stored primal stages travel with the trajectory
   need += needz;
-  if (const char* ev = getenv("QD_TRAJ_BUDGET_MB"))  // test hook: pretend HBM is this small
-    return (double)need * sizeof(double) <= atof(ev) * 1048576.0;
+  if (h->opts.traj_budget_mb > 0.0)  // test hook (option traj_budget_mb): pretend HBM is this small
+    return (double)need * sizeof(double) <= h->opts.traj_budget_mb * 1048576.0;
   if (need - needz <= h->d_traj.cap && needz <= h->d_ztraj.cap) return true;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;

@@ -926,11 +926,10 @@ static hipError_t set_lds32(K kern, size_t bytes) {
 }
 
 // slot bits per thread for a Q-qubit Lindblad system: 2^5 -> 4 elements per thread (256 threads); 2^4 -> one element per
-// thread (256 threads; QD_F32_SB=2 selects the one-wave, four-elements-per-thread layout for measurements)
-static int q32_slot_bits(int Q) {
+// thread (256 threads; the option f32_sb = 2 selects the one-wave, four-elements-per-thread layout for measurements)
+static int q32_slot_bits(int Q, const TuneOpts& o) {
   if (Q == 5) return 2;
-  if (const char* ev = getenv("QD_F32_SB")) return atoi(ev) == 2 ? 2 : 0;
-  return 0;
+  return o.f32_sb == 2 ? 2 : 0;
 }
 
 template <int Q, int SB, typename R, bool GM = false>
@@ -964,8 +963,8 @@ static hipError_t go_app(const DevSys& S, const double* ctlrow, int tr, const do
   return hipGetLastError();
 }
 
-hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st) {
-  const int sb = q32_slot_bits(a.S.Q);
+hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+  const int sb = q32_slot_bits(a.S.Q, o);
   if (a.use_gmres) {  // Krylov basis in global memory as float2, Hessenberg problem in fp64
     if (a.S.Q == 5) return go_fwd<5, 2, float, true>(a, st);
     if (a.S.Q == 4) return go_fwd<4, 0, float, true>(a, st);
@@ -975,8 +974,8 @@ hipError_t launch_forward_f32(const SweepArgs& a, hipStream_t st) {
   if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2, float>(a, st) : go_fwd<4, 0, float>(a, st);
   return hipErrorInvalidValue;
 }
-hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st) {
-  const int sb = q32_slot_bits(a.S.Q);
+hipError_t launch_adjoint_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+  const int sb = q32_slot_bits(a.S.Q, o);
   if (a.use_gmres) {
     if (a.S.Q == 5) return go_adj<5, 2, float, true>(a, st);
     if (a.S.Q == 4) return go_adj<4, 0, float, true>(a, st);
@@ -987,24 +986,24 @@ hipError_t launch_adjoint_f32(const SweepArgs& a, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
-                            hipStream_t st) {
+                            const TuneOpts& o, hipStream_t st) {
   if (mfma) {
     if (S.Q != 5 || transpose) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_apply_mfma32, dim3(nb), dim3(64), 0, st, S, ctlrow, x, y, nrep);
     return hipGetLastError();
   }
-  const int sb = q32_slot_bits(S.Q);
+  const int sb = q32_slot_bits(S.Q, o);
   if (S.Q == 5) return go_app<5, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   if (S.Q == 4) return sb == 2 ? go_app<4, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st) : go_app<4, 0, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   return hipErrorInvalidValue;
 }
 
 // fp64 instantiation of the lean slot kernel: the Neumann sweeps of the 2^5 Lindblad system in QD_PRECISION_F64
-bool lean64_available(const DevSys& S) {
+bool lean64_available(const DevSys& S, const TuneOpts& o) {
   if (!S.lindblad || S.dense || S.hasJ || S.Q != 5) return false;
   for (int k = 0; k < S.Q; k++)
     if (S.n[k] != 2 || S.ness[k] != 2) return false;
-  return !getenv("QD_NO_LEAN64");
+  return !o.no_lean64;
 }
 hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st) { return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st); }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st) { return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st); }

@@ -119,10 +119,11 @@ class RcclComm(TorchComm):
         super().close()
 
 
-def make_comm(backend, rank, world, local_rank=0):
+def make_comm(backend, rank, world, local_rank=0, allow_fallback=False):
     if backend == "nccl":
         # RCCL inside the library.  Should its bootstrap fail on ANY rank (decided collectively over gloo, so that every rank
-        # takes the same branch), the run continues with host-staged gloo reductions and says so in `describe()`.
+        # takes the same branch) this is an ERROR: a multi-GPU run that silently reduces through host-staged gloo is not the run
+        # that was asked for.  Only `allow_fallback` (bench.py --dist-backend auto-fallback) continues on gloo, and says so.
         comm, err = None, ""
         try:
             comm = RcclComm(rank, world, local_rank)
@@ -137,6 +138,9 @@ def make_comm(backend, rank, world, local_rank=0):
             return comm
         if comm is not None:
             comm.lib.qd_comm_destroy(comm.comm)
+        if not allow_fallback:
+            raise RuntimeError(f"RCCL bootstrap failed on at least one rank ({err or 'another rank'}); "
+                               "rerun with --dist-backend auto-fallback to reduce through host-staged gloo instead")
         fb = TorchComm("gloo", rank, world, "cpu")
         fb.fallback_reason = err or "RCCL bootstrap failed on another rank"
         return fb

@@ -63,6 +63,28 @@ def _big(levels, ntime, dt, init, linsolve="neumann", runtype="simulation"):
     return "\n".join(lines) + "\n"
 
 
+def _perf(levels, ntime, linsolve="gmres", runtype="simulation"):
+    """The reference's own performance workloads (tests/performance/configs/nlevels_4_4_4_4.cfg, nlevels_32_32_32_32.cfg): Schroedinger,
+    four oscillators, dipole-dipole coupling 0.001 GHz and cross-Kerr 0.001 GHz on all six pairs, three carrier waves, constant control
+    amplitudes 0.005 GHz, one pure initial state |1000>, dt 0.01 ns (the reference runs them on its sparse-matrix path with GMRES)."""
+    q = len(levels)
+    npairs = q * (q - 1) // 2
+    lines = [
+        "nlevels = " + ", ".join(str(n) for n in levels), f"ntime = {ntime}", "dt = 0.01",
+        "transfreq = " + ", ".join(f"{4.1 + 0.1 * k:.1f}" for k in range(q)), "rotfreq = " + ", ".join(f"{4.1 + 0.1 * k:.1f}" for k in range(q)),
+        "selfkerr = " + ", ".join(["0.2"] * q), "crosskerr = " + ", ".join(["0.001"] * npairs), "Jkl = " + ", ".join(["0.001"] * npairs),
+        "collapse_type = none", "decay_time = " + ", ".join(["0.0"] * q), "dephase_time = " + ", ".join(["0.0"] * q),
+        "initialcondition = pure, 1" + ", 0" * (q - 1), "control_enforceBC = false", "optim_target = pure" + ", 0" * q,
+        "optim_objective = Jtrace", "optim_weights = 1.0", "optim_regul = 0.00001", "optim_penalty = 0.0", "optim_penalty_param = 0.0",
+        "optim_penalty_dpdm = 0.0", "optim_penalty_energy = 0.0", "optim_penalty_variation = 0.0", f"runtype = {runtype}",
+        "usematfree = true", f"linearsolver_type = {linsolve}", "linearsolver_maxiter = 20", "timestepper = IMR", "rand_seed = 1234",
+    ]
+    for k in range(q):
+        lines += [f"control_segments{k} = spline, 15", f"control_initialization{k} = constant, 0.005", f"control_bounds{k} = 0.008",
+                  f"carrier_frequency{k} = 0.0, -0.2, -0.001"]
+    return "\n".join(lines) + "\n"
+
+
 def random_hamiltonians(n, nosc, seed=1234):
     """Synthetic user Hamiltonians for the dense-operator path: random Hermitian Hsys and Hc_k (rad/ns)."""
     import numpy as np
@@ -94,6 +116,15 @@ WORKLOADS = {
     # one pure initial state of the 20 x 20 Lindblad system (dim 160 000): a team of workgroups per state (qd_big.h)
     "l20": ("20x20 Lindblad (the reference's <20,20> template), one pure initial condition, state dimension 160 000, ntime 200",
             lambda mode: _big([20, 20], 200, 0.001, "pure, 1, 1", runtype=mode)),
+    # the coupling stencil measured - the 4-qubit open system with J_kl = 0.001 GHz on all pairs, all rotating frames at 4.1 GHz
+    "q4j": ("4-qubit open system with dipole-dipole coupling (2^4 Lindblad, J_kl = 0.001 GHz on all pairs, rotating frames at 4.1 GHz: detuned), 256 basis initial conditions, ntime 1000",
+            lambda mode: _qubits(4, True, 1000, 0.01, 30, runtype=mode).replace("Jkl = 0.0", "Jkl = 0.001").replace(
+                "rotfreq = 4.1000,4.2000,4.3000,4.4000", "rotfreq = 4.1,4.1,4.1,4.1")),
+    # the reference's own performance workloads (tests/performance/test_cases.json)
+    "n4444": ("reference performance case nlevels_4_4_4_4: 4^4 Schroedinger (dim 256), J_kl on all pairs, one pure state, ntime 500, GMRES",
+              lambda mode: _perf([4, 4, 4, 4], 500, runtype=mode)),
+    "n32": ("reference performance case nlevels_32_32_32_32: 32^4 Schroedinger (dim 1 048 576), J_kl on all pairs, one pure state, ntime 50, GMRES",
+            lambda mode: _perf([32, 32, 32, 32], 50, runtype=mode)),
     # dense user-Hamiltonian operator (hamiltonian_file_Hsys / _Hc of the reference): random Hermitian 16 x 16
     "d4": ("D4 2^4 Lindblad with user-supplied dense Hamiltonians (dim 256), 256 basis initial conditions, ntime 1000",
            lambda mode: _qubits(4, True, 1000, 0.002, 30, runtype=mode) + "synthetic_hamiltonian_seed = 1234\n"),

@@ -125,15 +125,19 @@ LEANCOL_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("split", ["auto", "0", "1"])
 @pytest.mark.parametrize("stepper", ["IMR", "IMR4"])
 @pytest.mark.parametrize("kw", LEANCOL_SHAPES)
-def test_lean_column_kernels(kw, stepper):
+def test_lean_column_kernels(kw, stepper, split):
     """qd_col.hip (Lindblad, 44 <= N <= 64 rows, two or three oscillators, Neumann): operator and transpose at 1e-13, objective
-    parts and gradient against the oracle with every Lindblad penalty (weighted J, leakage through guard levels, energy), and
-    bit-for-bit agreement of nothing: the general column kernel of qd_device.h (QD_NO_COLLEAN) must give the same numbers to
-    round-off, which pins the two implementations against each other as well."""
-    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, dt=0.001)  # (self-Kerr 0.2 GHz on up to 20 levels: the Neumann
-    assert h.dim > 1024                                                           # series needs ||h/2 M|| < 1)
+    parts and gradient against the oracle with every Lindblad penalty (weighted J, leakage through guard levels, energy).
+    split = "0": the reference's Neumann iteration, application counts as the oracle's.  split = "auto": the diagonal-split
+    iteration (these systems carry a self-Kerr ladder of up to 20 levels, so it is on) - same fixed point and stopping rule, so
+    the same tolerances hold, with fewer applications."""
+    sp = synthetic_spec(**{**kw, "ntime": 12, "penalties": True, "stepper": stepper, "dt": 0.001})  # (self-Kerr 0.2 GHz on up to 20
+    sp.options = {"neumann_split": split}                                                     # levels: the series needs ||h/2 M|| < 1)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    assert h.dim > 1024
     rng = np.random.default_rng(11)
     h.set_params(sp.params0)
     orc.set_params(sp.params0)
@@ -151,8 +155,31 @@ def test_lean_column_kernels(kw, stepper):
     orc.reset_stats()
     orc.evalF(sp.params0)
     opt.evalF(sp.params0)
-    assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    if split == "0":
+        assert abs(h.mean_applies - orc.mean_applies) < 0.25
+    else:
+        assert h.mean_applies < orc.mean_applies + 0.25
     opt.close(); h.close(); orc.close()
+
+
+def test_diagonal_split_neumann_on_the_axc_system():
+    """BASELINE config 4 (3 x 20, AxC constants): the diagonal-split iteration needs fewer applications per step than the reference's
+    Neumann iteration and gives the same objective and gradient (both stop on the update norm at abstol 1e-10)."""
+    from quandary_amd.workloads import workload_spec
+    res = {}
+    for split in ("0", "1"):
+        sp = workload_spec("c4", "gradient", {"ntime": 40, "initialcondition": "diagonal, 0"})
+        sp.options = {"neumann_split": split}
+        h = capi.Handle(sp)
+        opt = capi.Optim(h, sp)
+        val, g = opt.evalGradF(sp.params0)
+        res[split] = (val, g, h.mean_applies)
+        opt.close(); h.close()
+    (v0, g0, a0), (v1, g1, a1) = res["0"], res["1"]
+    for k in OBJ_KEYS:
+        assert v1[k] == pytest.approx(v0[k], rel=1e-9, abs=1e-12), k
+    assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 1e-8
+    assert a1 < a0 - 2.0, (a0, a1)
 
 
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[4], SHAPES[5], SHAPES[6], SHAPES[7]])
@@ -905,7 +932,7 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper,
         opt.evalF(sp.params0)
         assert abs(h.mean_applies - orc.mean_applies) < 0.25
     # same result as one workgroup per initial condition, up to the summation order of the reductions
-    monkeypatch.setenv("QD_BIG_TEAM", "1")
+    h.set_option("big_team", 1)
     val1, g1 = opt.evalGradF(sp.params0)
     assert h.last_team == 1
     assert val1["objective"] == pytest.approx(val["objective"], rel=1e-11)
