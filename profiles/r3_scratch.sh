@@ -1,2 +1,1 @@
-python profiles/col_probe.py 100 0 | head -6
-python profiles/col_probe.py 50 0 grad | head -6
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "^E|passed|failed|rror" | head -20

@@ -3,6 +3,8 @@
 // per GPU, on the handle's HIP stream.  Bootstrap needs no MPI: the ncclUniqueId of rank 0 travels as 128 plain
 // bytes through whatever the caller has (a file on a shared file system here, torch.distributed/gloo in bench.py).
 #include <chrono>
+#include <ctime>
+#include <sys/stat.h>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -56,16 +58,33 @@ extern "C" int qd_comm_create(const unsigned char* id, int rank, int nranks, int
   return QD_OK;
 }
 
-// rank 0 writes the id to `path` (atomically: temporary name + rename), the others wait for the file
+// Rank 0 writes the id to `path` (atomically: temporary name + rename), the others wait for the file.  The file carries a header
+// {magic, job nonce}: a leftover of a crashed run or the file of another job must not be mistaken for this job's id (ranks > 0 would
+// then block in ncclCommInitRank forever - the timeout only covers the wait for the file).  The nonce is a hash of the environment
+// variable QD_JOB_ID when the launcher sets one (the same for all ranks of a job); without it, files last modified more than two
+// minutes before this rank entered the call are treated as leftovers.  Rank 0 removes whatever is there before it publishes.
+static unsigned long long job_nonce() {
+  const char* j = getenv("QD_JOB_ID");
+  if (!j) return 0ull;
+  unsigned long long h = 1469598103934665603ull;  // FNV-1a
+  for (const char* c = j; *c; c++) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+  return h ? h : 1ull;
+}
+
 extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out) {
   if (!path || !out) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: null argument");
+  static const char magic[8] = {'Q', 'D', 'C', 'O', 'M', 'M', '0', '2'};
+  const unsigned long long nonce = job_nonce();
+  const time_t entered = time(nullptr);
   unsigned char id[QD_COMM_ID_BYTES];
   if (rank == 0) {
+    (void)remove(path);  // a leftover of an earlier run
     int r = qd_comm_unique_id(id);
     if (r) return r;
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) {
+    if (!f || fwrite(magic, 1, sizeof magic, f) != sizeof magic || fwrite(&nonce, 1, sizeof nonce, f) != sizeof nonce ||
+        fwrite(id, 1, sizeof id, f) != sizeof id) {
       if (f) fclose(f);
       return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot write the id file");
     }
@@ -76,12 +95,18 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
     for (;;) {
       FILE* f = fopen(path, "rb");
       if (f) {
-        const size_t n = fread(id, 1, sizeof id, f);
+        char m[8];
+        unsigned long long n2 = 0;
+        const bool ok = fread(m, 1, sizeof m, f) == sizeof m && fread(&n2, 1, sizeof n2, f) == sizeof n2 && fread(id, 1, sizeof id, f) == sizeof id;
+        struct stat sb;
+        const bool have_stat = fstat(fileno(f), &sb) == 0;
         fclose(f);
-        if (n == sizeof id) break;
+        const bool fresh = nonce ? n2 == nonce : (have_stat && difftime(entered, sb.st_mtime) <= 120.0);
+        if (ok && std::memcmp(m, magic, sizeof m) == 0 && fresh) break;
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-        return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank 0's id file");
+        return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank 0's id file (a file that is there but stale - other "
+                                  "QD_JOB_ID, or older than two minutes - does not count)");
       std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
   }

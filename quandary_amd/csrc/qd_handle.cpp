@@ -772,7 +772,10 @@ int qd_handle::forward_finish(double* energy) {
   // orthogonalisation, reductions and basis traffic (k = Krylov vectors; on the 3x20 workload one such round costs as much as five
   // applications), so the best p is the smallest one for which (almost) every solve needs a single Krylov vector.  k is known after
   // every forward sweep: bracket p between the largest degree seen with k > 1 and the smallest seen with k = 1, bisect, stay.
-  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && opts.gmres_poly == 0) {
+  // Once the bracket has closed (or after eight tuning sweeps) the degree is FROZEN for the life of the handle: from then on two
+  // evaluations at the same parameters take the same GMRES path and are bit-identical (a line search compares objectives far below
+  // the solver tolerance).  The option gmres_poly fixes the degree from the first sweep on.
+  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && opts.gmres_poly == 0 && !poly_frozen) {
     const double per_solve = (double)nap / ((double)nb * (double)nsub);
     const double k = (per_solve - 1.0) / last_poly;
     if (k > 1.02) {
@@ -784,6 +787,11 @@ int qd_handle::forward_finish(double* energy) {
       poly_hi = poly_hi ? std::min(poly_hi, last_poly) : last_poly;
       if (poly_lo >= poly_hi) poly_lo = 1;
       poly_cur = poly_hi - poly_lo > 1 ? (poly_lo + poly_hi) / 2 : poly_hi;
+    }
+    poly_steps++;
+    if ((poly_hi && poly_hi - poly_lo <= 1) || poly_steps >= 8 || poly_cur >= 32) {
+      if (poly_hi) poly_cur = poly_hi;
+      poly_frozen = true;
     }
   }
   last_nb = nb;

@@ -135,7 +135,8 @@ struct qd_handle {
   void row_bounds(double* diag, double* off) const;  // Gershgorin bounds of a row of M over all sub-steps (current parameters)
   int gmres_poly_degree() const;  // > 1 where the Neumann series provably contracts for the current parameters, else 1
   // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
-  int poly_cur = 6, poly_lo = 1, poly_hi = 0, last_poly = 1, last_var = 0;
+  int poly_cur = 6, poly_lo = 1, poly_hi = 0, last_poly = 1, last_var = 0, poly_steps = 0;
+  bool poly_frozen = false;  // the bracket has closed: the degree no longer changes (reproducible evaluations)
   int traj_doubles(int nb, size_t* n) const;
   size_t ztraj_doubles(int nb) const;  // 0 for explicit Euler
   // forward sweep on device-resident states; results stay on the device (d_pen, d_dpdm, d_xT, d_out4)

@@ -38,6 +38,7 @@ struct qd_optim {
   // state between forward_local and adjoint_local
   std::vector<double> last_alpha;
   bool stored = false, forward_done = false;
+  int dist_fits = -1;  // qd_optim_evalGradF_dist: -1 undecided, 1 fused device path, 0 host-staged fallback (decided collectively)
 };
 
 // ---- index helpers (src/util.cpp:150-278) ------------------------------------------------------
@@ -734,7 +735,14 @@ extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* al
   PenaltyScope ps(h, o->pen);
   const int nl = o->nlocal, nd = h->ndesign;
   int r;
-  if (!trajectory_fits(h, nl)) {
+  // Fused device path or host-staged fallback: the two issue DIFFERENT collectives, and trajectory_fits() looks at this rank's own free
+  // memory - so the choice is made collectively (any rank that does not fit sends every rank down the fallback), once per objective.
+  if (o->dist_fits < 0) {
+    double nofit = trajectory_fits(h, nl) ? 0.0 : 1.0;
+    if (c->nranks > 1 && (r = qd_comm_allreduce(c, &nofit, 1, 1))) return r;
+    o->dist_fits = nofit > 0.5 ? 0 : 1;
+  }
+  if (!o->dist_fits) {
     // the shard's trajectory exceeds HBM: host-staged path (chunked re-propagation), collectives through the same communicator
     double sums[QD_NSUMS];
     if ((r = qd_optim_forward_local(o, alpha, 0, sums))) return r;

@@ -614,6 +614,7 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, const Evaluato
   const double g0 = pgnorm(x, g);
   double gnorm = g0, step = 1.0;
   int nfev = 1;
+  bool retry = false;  // the line search of this iteration is repeated from steepest descent: no second history row / controls file
   for (int it = 0;; it++) {
     const char* why = nullptr;
     if (1.0 - v.fidelity <= inftol) why = "Optimization converged with small infidelity.";
@@ -622,7 +623,7 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, const Evaluato
     else if (gnorm < gatol) why = "Optimization converged with small gradient norm.";
     else if (gnorm / g0 < grtol) why = "Optimization converged with small relative gradient norm.";
     // history row every optim_monitor_frequency iterations and on the last one (src/optimproblem.cpp:634-645)
-    if (root && (it % out.optim_monitor_freq == 0 || why)) {
+    if (root && !retry && (it % out.optim_monitor_freq == 0 || why)) {
       out.optim_row(it, v, gnorm, step);
       if (!quiet) printf("%d  %1.14e + %1.14e + %1.14e + %1.14e + %1.14e + %1.14e  Fidelity = %1.14e  ||Grad|| = %1.14e\n", it, v.cost, v.regul,
                          v.penalty, v.penalty_dpdm, v.penalty_energy, v.penalty_variation, v.fidelity, gnorm);
@@ -631,7 +632,8 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, const Evaluato
       if (root && !quiet) printf("%s (%d function/gradient evaluations)\n", why, nfev);
       break;
     }
-    if (root && it % out.optim_monitor_freq == 0) write_controls(P, out, h, x);
+    if (root && !retry && it % out.optim_monitor_freq == 0) write_controls(P, out, h, x);
+    retry = false;
     // active set and masked gradient
     for (int i = 0; i < n; i++) {
       const bool act = (x[i] <= -P.bounds[i] && g[i] > 0.0) || (x[i] >= P.bounds[i] && g[i] < 0.0);
@@ -728,6 +730,7 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, const Evaluato
       S.clear();
       Y.clear();
       it--;  // retry this iteration from steepest descent
+      retry = true;
       continue;
     }
     step = a;

@@ -23,7 +23,9 @@ from quandary_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-APPLY_TOL, OBJ_RTOL, FID_ATOL, GRAD_TOL = 5e-7, 1e-8, 1e-8, 2e-6
+# measured (profiles/r2_f32_errors.jsonl, ntime 1000): gradient 2.3e-8 ... 4.4e-8 of its norm with Neumann, 5e-8 ... 1.2e-7 with GMRES -
+# the assertion sits within 3 x of the largest measurement; the short trajectory-file case below has a tiny gradient (5.3e-7 measured)
+APPLY_TOL, OBJ_RTOL, FID_ATOL, GRAD_TOL, GRAD_TOL_SHORT = 5e-7, 1e-8, 1e-8, 3e-7, 1.5e-6
 
 
 def _spec(q, init, ntime, penalties=False, stepper="IMR", linsolve="neumann"):
@@ -110,7 +112,7 @@ def test_f32_compositional_stepper_and_trajectory():
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     assert val["objective"] == pytest.approx(oval["objective"], rel=OBJ_RTOL)
-    assert np.linalg.norm(g - og) <= GRAD_TOL * np.linalg.norm(og)
+    assert np.linalg.norm(g - og) <= GRAD_TOL_SHORT * np.linalg.norm(og)
     x0 = np.stack([opt.initial_state(i)[0] for i in range(opt.ninit_local)])
     h.set_params(sp.params0)
     res = h.forward(x0, store_trajectory=True)
