@@ -351,7 +351,8 @@ CHECK_TOL = {"f64": 1e-9, "f32mixed": 2e-5}
 # the other workloads reported next to the headline on one GPU: (name, mode, linsolve, dtype, config overrides, timed steps, options)
 EXTRA = [
     ("c4", "fwd", "neumann", "f64", {"ntime": 250}, 2, {"neumann_split": 0}),  # the reference's Neumann iteration on the same kernels
-    ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1, {}),
+    ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 2, {}),  # gmres request served by the diagonal-split iteration under GMRES's stopping rule
+    ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1, {"gmres_split": 0}),  # the Krylov kernel (polynomial preconditioner, basis in L2 / HBM)
     ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1, {}),  # = the 1-GPU point of the `--gpus N` strong-scaling series
     ("c2", "fwd", "neumann", "f64", {}, 20, {}),  # BASELINE configs[1] (the round-1/2 headline): 64 single-wave workgroups
     ("q4", "fwd", "neumann", "f64", {}, 20, {}),  # (3-8 ms per step: enough steps that one host hiccup does not halve the rate)

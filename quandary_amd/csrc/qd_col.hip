@@ -358,9 +358,18 @@ struct ColTeam {
       if (SPLIT) y[j] = make_double2(fma(pr[SPLIT ? j : 0], b[j].x, -pi[SPLIT ? j : 0] * b[j].y), fma(pr[SPLIT ? j : 0], b[j].y, pi[SPLIT ? j : 0] * b[j].x));
       else y[j] = b[j];
     }
-    publish(y);
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
-    const float rel2 = (float)(A.reltol * A.reltol);
+    float rel2 = (float)(A.reltol * A.reltol), thr = 1.f;
+    if (A.stop_residual) {
+      // in place of GMRES (qd_handle::gmres_as_split): stop when kappa^2 ||y_{m+1} - y_m||^2 <= max(rtol^2 ||b||^2, abstol^2)
+      double nb2[1] = {0.0};
+#pragma unroll
+      for (int j = 0; j < EPT; j++) nb2[0] = fma(b[j].x, b[j].x, fma(b[j].y, b[j].y, nb2[0]));
+      sum<1>(nb2);
+      thr = (float)fmin(fmax(A.reltol * A.reltol * nb2[0] * inv_abs2, 1.0) / A.kappa2, 1e30);
+      rel2 = 0.f;
+    }
+    publish(y);
     float d0 = 1.f;
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
@@ -385,7 +394,7 @@ struct ColTeam {
       const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
       st.flip();
       if (iter == 0) d0 = d;
-      if (d < 1.f) { iter++; break; }
+      if (d < thr) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
     }
     return iter;

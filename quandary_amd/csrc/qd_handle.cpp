@@ -651,6 +651,26 @@ bool qd_handle::use_col(const qd::LaunchCfg& cfg) const {
   return precision == QD_PRECISION_F64 && cfg.var == 9 && !cfg.gmres && collean_available(S, opts) && sol.stepper != QD_STEPPER_EE;
 }
 
+// linearsolver_type = gmres on the systems of the lean column kernels.  A Krylov basis of 57.6 KB vectors per initial condition has no
+// room on the chip next to the exchange buffers (the column kernel's GMRES streams it through L2 / HBM: 8.6 x the algorithmic bytes,
+// 3.8 x the time of the Neumann sweep on the 3 x 20 workload), while the diagonal-split stationary iteration contracts by
+// ~alpha ||M - D|| per application and needs no vector besides the iterate.  Where that contraction is provably fast - Gershgorin
+// bound alpha x (off-diagonal row sum) <= 0.3 for every sub-step - the request is served by that iteration under GMRES's own stopping
+// rule: residual <= max(rtol ||b||, abstol) (KSPGMRES defaults as set in src/timestepper.cpp:541-550), checked through the bound
+// ||b - (I - alpha M) y_m|| = ||(1 - alpha D)(y_{m+1} - y_m)|| <= kappa ||y_{m+1} - y_m||.  Same linear system, same tolerance, hence
+// results that agree with GMRES at solver-tolerance level; the option gmres_split = 0 keeps the Krylov kernels.
+bool qd_handle::gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const {
+  if (precision != QD_PRECISION_F64 || cfg.var != 9 || !cfg.gmres || !collean_available(S, opts) || sol.stepper == QD_STEPPER_EE ||
+      opts.gmres_split == 0)
+    return false;
+  double dg, of;
+  row_bounds(&dg, &of);
+  double amax = 0.0;
+  for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
+  if (kappa2) *kappa2 = (1.0 + amax * dg) * (1.0 + amax * dg);
+  return opts.gmres_split == 1 || amax * of <= 0.3;
+}
+
 // Diagonal-split Neumann iteration (qd_col.hip): same fixed point and stopping rule, the diagonal of M on the left-hand side.  It
 // costs nothing per iteration, so "where it pays" is wherever the diagonal (level energies, decay) is a visible share of the row
 // bound: alpha (diag + off) is the contraction bound of the plain iteration, alpha off that of the split one.
@@ -735,6 +755,13 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   last_var = cfg.var;
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
+  if (gmres_as_split(cfg, &a.kappa2)) {  // GMRES request served by the diagonal-split iteration of the lean column kernels
+    cfg.gmres = 0;
+    a.use_gmres = 0;
+    a.neumann_split = 1;
+    a.stop_residual = 1;
+    cfg.lds = pick_config(S, nb, opts, false).lds;
+  }
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
@@ -911,6 +938,13 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
+  if (gmres_as_split(cfg, &a.kappa2)) {
+    cfg.gmres = 0;
+    a.use_gmres = 0;
+    a.neumann_split = 1;
+    a.stop_residual = 1;
+    cfg.lds = pick_config(S, nb, opts, false, true).lds;
+  }
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;

@@ -81,6 +81,9 @@ struct qd_handle {
   qd::TuneOpts opts;                 // qd_set_option (+ environment overrides read at qd_create)
   bool use_col(const qd::LaunchCfg& cfg) const;  // the sweep runs on the lean column kernels (qd_col.hip)
   int neumann_split_on() const;      // diagonal-split Neumann iteration for the current parameters
+  // linearsolver_type = gmres served by the diagonal-split iteration of the lean column kernels under GMRES's stopping rule;
+  // *kappa2 = (1 + max alpha |D|)^2, the factor between the squared update norm and the bound of the squared residual
+  bool gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // forward / adjoint kernel brackets
   qd::DevSys S{};

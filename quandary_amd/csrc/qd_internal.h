@@ -77,6 +77,10 @@ struct SweepArgs {
   int stepper_ee, linsolve, maxiter;
   int gmres_poly;  // degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (1 = none)
   int neumann_split;  // lean column kernels (qd_col.hip): diagonal of M on the left-hand side of the Neumann iteration
+  // ... run in place of GMRES under GMRES's stopping rule: stop when kappa ||y_{m+1} - y_m|| <= max(rtol ||b||, abstol), where
+  // kappa >= |1 - alpha D_ii| bounds the true residual ||b - (I - alpha M) y_m|| = ||(1 - alpha D)(y_{m+1} - y_m)|| from above
+  int stop_residual;
+  double kappa2;
   int use_gmres;  // 0: Neumann; 1: in-kernel GMRES, Krylov basis in LDS (one element per thread, small dim); 2: basis in global memory (kry)
   double abstol, reltol;
   // penalties (src/timestepper.cpp:256-480)
@@ -120,6 +124,8 @@ struct TuneOpts {
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
   int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
+  int gmres_split = -1;    // "gmres_split": linearsolver_type = gmres served by the diagonal-split iteration under GMRES's stopping rule where that
+                           // iteration contracts fast (-1 = there, 0 = never: always the Krylov kernels, 1 = wherever it is built)
   int neumann_split = -1;  // "neumann_split": diagonal-split Neumann iteration (-1 = where it pays, 0 = never, 1 = wherever it is built)
   double traj_budget_mb = 0.0;  // "traj_budget_mb": pretend the trajectory budget is this small (chunked re-propagation)
   int set(const char* key, const char* value);  // 0 = ok, -1 = unknown key / bad value

@@ -539,7 +539,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // options
 // ---------------------------------------------------------------------------------------------
 static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "f32_sb", "no_lean64", "no_collean",
-                                       "col_ept", "gmres_poly", "neumann_split", "traj_budget_mb"};
+                                       "col_ept", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
   const std::string k(key), v(value);
@@ -551,7 +551,7 @@ int TuneOpts::set(const char* key, const char* value) {
     return 0;
   }
   long iv;
-  if (v == "auto") iv = (k == "var" || k == "big_spread" || k == "f32_sb" || k == "neumann_split") ? -1 : 0;
+  if (v == "auto") iv = (k == "var" || k == "big_spread" || k == "f32_sb" || k == "neumann_split" || k == "gmres_split") ? -1 : 0;
   else {
     iv = strtol(value, &end, 10);
     if (end == value) return -1;
@@ -567,6 +567,7 @@ int TuneOpts::set(const char* key, const char* value) {
   else if (k == "col_ept") col_ept = (int)iv;
   else if (k == "gmres_poly") gmres_poly = iv > 0 ? (int)iv : 0;
   else if (k == "neumann_split") neumann_split = iv < 0 ? -1 : iv != 0;
+  else if (k == "gmres_split") gmres_split = iv < 0 ? -1 : iv != 0;
   else return -1;
   return 0;
 }

@@ -183,10 +183,11 @@ def test_diagonal_split_neumann_on_the_axc_system():
 
 
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[4], SHAPES[5], SHAPES[6], SHAPES[7]])
-def test_gmres_solver_vs_oracle_gmres(kw):
+def test_gmres_solver_vs_oracle_gmres(kw, monkeypatch):
     """linearsolver_type = gmres: in-kernel GMRES against the oracle's GMRES.  Small systems keep the Krylov
     basis in LDS; the 3x20 (column kernel, 8 elements/thread) and 2^5 (4 elements/thread) systems keep it
-    in global memory."""
+    in global memory (option gmres_split = 0: the Krylov kernels, not the stationary iteration that serves such requests by default)."""
+    monkeypatch.setenv("QD_GMRES_SPLIT", "0")
     if kw["nlevels"] == [3, 20]:
         kw = {**kw, "init": "basis, 0"}
     if kw["nlevels"] == [2, 2, 2, 2, 2]:
@@ -215,6 +216,7 @@ def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
     stopping rule on the same true residual, so objective and gradient agree with the oracle either way."""
     from quandary_amd.workloads import workload_spec
     monkeypatch.setenv("QD_GMRES_POLY", poly)
+    monkeypatch.setenv("QD_GMRES_SPLIT", "0")
     sp = workload_spec("c4", "gradient", {"ntime": 20, "linearsolver_type": "gmres", "initialcondition": "basis, 0"})
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
@@ -230,6 +232,27 @@ def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
         assert abs(h.mean_applies - orc.mean_applies) < 0.25
     else:
         assert orc.mean_applies < h.mean_applies < 2.0 * orc.mean_applies  # 1 + 3 x p + 3 applications against ~10
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[1], LEANCOL_SHAPES[3]])
+def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
+    """linearsolver_type = gmres on the systems of the lean column kernels (default: option gmres_split = auto): the diagonal-split
+    stationary iteration under GMRES's stopping rule - residual <= max(rtol ||b||, abstol), bounded from the update norm - against
+    the oracle's GMRES: same linear systems, same tolerance, so objective and gradient agree as for every other solver pairing; it
+    never needs more applications than the oracle's un-preconditioned GMRES on these systems."""
+    sp = synthetic_spec(**{**kw, "ntime": 12, "penalties": True, "linsolve": "gmres", "dt": 0.001})
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    orc.reset_stats()
+    orc.evalF(sp.params0)
+    opt.evalF(sp.params0)
+    assert h.mean_applies < orc.mean_applies + 0.25
     opt.close(); h.close(); orc.close()
 
 
@@ -430,6 +453,7 @@ def test_options_and_reproducible_gmres_evaluations():
     are bit-identical."""
     from quandary_amd.workloads import workload_spec
     sp = workload_spec("c4", "simulation", {"ntime": 6, "initialcondition": "diagonal, 0", "linearsolver_type": "gmres"})
+    sp.options = {"gmres_split": 0}  # the Krylov kernels with their polynomial preconditioner
     h = capi.Handle(sp)
     with pytest.raises(capi.QuandaryAmdError):
         h.set_option("no_such_key", 1)
@@ -440,7 +464,7 @@ def test_options_and_reproducible_gmres_evaluations():
     assert vals[-1] == vals[-2] == vals[-3]  # frozen: bit-identical
     assert vals[-1] == pytest.approx(vals[0], rel=1e-9)  # the tuning sweeps differ at solver-tolerance level only
     opt.close(); h.close()
-    sp.options = {"gmres_poly": 9}
+    sp.options = {"gmres_poly": 9, "gmres_split": 0}
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     v = [opt.evalF(sp.params0)["objective"] for _ in range(3)]
