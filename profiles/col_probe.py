@@ -9,6 +9,9 @@ sys.path.insert(0, _r)
 from quandary_amd import capi  # noqa: E402
 from quandary_amd.workloads import workload_spec  # noqa: E402
 
+if os.environ.get("QD_LIB"):  # A/B of two builds of the library in one lease
+    capi.LIB_PATH = os.environ["QD_LIB"]
+
 ntime, ninit = int(sys.argv[1]), int(sys.argv[2])
 grad = len(sys.argv) > 3 and sys.argv[3] == "grad"
 over = {"ntime": ntime}

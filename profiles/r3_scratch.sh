@@ -1,2 +1,7 @@
-python -m pytest tests/test_gpu_parity.py -m gpu -q -k "user_hamiltonian or dense" 2>&1 | grep -E "^E|passed|failed|rror" | head -5
-python -m pytest tests/test_driver_regression.py -m gpu -q 2>&1 | grep -E "passed|failed|FAILED" | head -20
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "lean_column or diagonal_split or column_layout or split_iteration" 2>&1 | grep -E "passed|failed" | head -5
+for i in 1 2; do
+python profiles/col_probe.py 100 0 | grep "lean+split" | tail -1
+QD_LIB=$PWD/profiles/libqd_variant.so python profiles/col_probe.py 100 0 | grep "lean+split" | tail -1 | sed 's/^/HEAD /'
+done
+python profiles/col_probe.py 50 0 grad | grep "lean+split" | tail -1
+QD_LIB=$PWD/profiles/libqd_variant.so python profiles/col_probe.py 50 0 grad | grep "lean+split" | tail -1 | sed 's/^/HEAD /'

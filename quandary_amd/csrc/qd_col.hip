@@ -450,11 +450,14 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
     // x is not needed during the linear solve: parked in the output buffer (L2 resident) BEFORE the right-hand side is formed, so that
     // no control flow separates the operator application from the solver that consumes it
+#ifndef QD_COL_NOSTASH
     store_state(xpark, x, false);
+#endif
     tm.publish(x);
     double2 rhs[EPT], k[EPT];
     tm.template apply_all<false>(c, x, rhs);  // rhs = M x (ImplMidpoint::evolveFWD, timestepper.cpp:594)
     napply += 1 + tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
+#ifndef QD_COL_NOSTASH
 #pragma unroll
     for (int j = 0; j < EPT; j++) x[j] = make_double2(0.0, 0.0);
     if (tm.st.rowok) {
@@ -465,6 +468,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
           x[j] = make_double2(xpark[e], xpark[dim + e]);
         }
     }
+#endif
     if (A.ztraj) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
       double2 z[EPT];
 #pragma unroll
@@ -483,13 +487,20 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
       if (wj_on) {
         const double a = (tstop - A.Tfinal) / A.penalty_param;
         const double weight = 1.0 / A.penalty_param * exp(-(a * a));
-        if (tm.st.rowok) {
+        // finalizeJ is affine for Lindblad: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Jtrace).  Jmeasure only sees the diagonal of rho,
+        // which the column layout has at hand (the generic routine divides the vectorised index by N per element and step: ~12 % of
+        // the 3 x 20 forward sweep)
+        if (A.tg.objective_type == QD_OBJ_JMEASURE) {
+          const double wrow = weight * A.dt * fabs((double)(tm.st.row - A.tg.purestate_id));
+#pragma unroll
+          for (int j = 0; j < EPT; j++)
+            if (tm.st.rowok && tm.st.colof(j) == tm.st.row) pen_local = fma(wrow, x[j].x, pen_local);
+        } else if (tm.st.rowok) {
 #pragma unroll
           for (int j = 0; j < EPT; j++)
             if (tm.st.colok(j)) {
               double jr = 0.0, ji = 0.0;
               evalJ_part<true>(S, A.tg, ic, opaque(tm.st.elem(j)), x[j], jr, ji);
-              // finalizeJ is affine for Lindblad: J = jr (Jfrobenius, Jmeasure) or 1 - jr (Jtrace)
               pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
             }
         }
@@ -554,9 +565,16 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
         const double weight = 1.0 / A.penalty_param * exp(-(a * a));
         double rb, ib;
         finalizeJ_diff<true>(A.tg, 0.0, 0.0, rb, ib);
+        if (A.tg.objective_type == QD_OBJ_JMEASURE) {
+          const double wrow = weight * rb * jbar_pen * A.dt * fabs((double)(tm.st.row - A.tg.purestate_id));
 #pragma unroll
-        for (int j = 0; j < EPT; j++)
-          if (tm.st.ok(j)) evalJ_diff_elem<true>(S, A.tg, ic, opaque(tm.st.elem(j)), xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+          for (int j = 0; j < EPT; j++)
+            if (tm.st.rowok && tm.st.colof(j) == tm.st.row) xb[j].x += wrow;
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPT; j++)
+            if (tm.st.ok(j)) evalJ_diff_elem<true>(S, A.tg, ic, opaque(tm.st.elem(j)), xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+        }
       }
       if (leak) {
 #pragma unroll
