@@ -1,7 +1,2 @@
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "lean_column or diagonal_split or column_layout or split_iteration" 2>&1 | grep -E "passed|failed" | head -5
-for i in 1 2; do
-python profiles/col_probe.py 100 0 | grep "lean+split" | tail -1
-QD_LIB=$PWD/profiles/libqd_variant.so python profiles/col_probe.py 100 0 | grep "lean+split" | tail -1 | sed 's/^/HEAD /'
-done
-python profiles/col_probe.py 50 0 grad | grep "lean+split" | tail -1
-QD_LIB=$PWD/profiles/libqd_variant.so python profiles/col_probe.py 50 0 grad | grep "lean+split" | tail -1 | sed 's/^/HEAD /'
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "performance_workloads or team" 2>&1 | grep -E "^E|passed|failed|rror" | head -8
+python bench.py --workload n32 --linsolve gmres --steps 2 --warmup 1 --no-cpu-baseline --no-workloads > /tmp/o.txt 2>/tmp/e.txt; grep -o '"ms_per_step": [0-9.]*\|"kernel_ms_per_launch": [0-9.]*' /tmp/o.txt | tr '\n' ' '; echo

@@ -1013,8 +1013,27 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper,
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("name,ntime,team", [("n4444", 25, 1), ("n32", 2, 256)])
+def test_reference_performance_workloads_vs_oracle(name, ntime, team):
+    """The reference's own performance cases (tests/performance/test_cases.json): nlevels_4_4_4_4 and nlevels_32_32_32_32 - Schroedinger,
+    four oscillators, dipole-dipole coupling on all six pairs, one pure state, GMRES; the second has a state of dimension 2^20 (a team
+    of 256 workgroups through L2, qd_big.h).  Objective parts and gradient against the oracle at a small number of steps."""
+    from quandary_amd.workloads import workload_spec
+    sp = workload_spec(name, "gradient", {"ntime": ntime})
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_team == team
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    opt.close(); h.close(); orc.close()
+
+
 def test_team_size_follows_batch_and_dimension():
-    """The selection rule (big_team, qd_kernels.hip): at least half an element per thread, at most 64 members, every team resident."""
+    """The selection rule (big_team, qd_kernels.hip): at least half an element per thread, at most 64 members (256 for states of a
+    million elements, previous test), every team resident."""
     for nl, init, want in (([10, 10], "pure, 0, 1", 16), ([9, 9], "pure, 0, 1", 8), ([10, 10], "basis, 0", 2)):
         sp = synthetic_spec(nl, lindblad=True, ntime=2, nspline=5, target="pure", objective="Jfrobenius", init=init)
         h = capi.Handle(sp)
