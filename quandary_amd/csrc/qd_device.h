@@ -24,6 +24,14 @@
 
 #include "qd_internal.h"
 
+// Measurement builds only (profiles/ablate.sh): QD_ABLATE removes phases of the small-system solver iteration so that their cost can
+// be read off timing differences - bit 0: no stopping test (four iterations per solve, no norm reduction), bit 1: no neighbour reads
+// (the element itself stands in for its neighbours), bit 2: no stencil arithmetic (a sum of the neighbours instead).  The results of
+// such builds are meaningless; the product is built with QD_ABLATE = 0.
+#ifndef QD_ABLATE
+#define QD_ABLATE 0
+#endif
+
 namespace qd {
 
 // ---------------------------------------------------------------------------------------------
@@ -733,6 +741,21 @@ struct QubitStencil {
     const double2* xb = n.xb;
     const double2* xk = n.xk;
     const double2* xl = n.xl;
+    double2 own[Q];
+    if (QD_ABLATE & 2) {  // no neighbour reads: the element itself stands in
+#pragma unroll
+      for (int k = 0; k < Q; k++) own[k] = xs;
+      xb = xk = xl = own;
+    }
+    if (QD_ABLATE & 4) {  // no stencil arithmetic: a sum of the neighbours keeps the reads alive
+      double2 acc = xs;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        acc.x += xb[k].x + (LIND ? xk[k].x + xl[k].x : 0.0);
+        acc.y += xb[k].y + (LIND ? xk[k].y + xl[k].y : 0.0);
+      }
+      return make_double2(1e-3 * acc.x, 1e-3 * acc.y);
+    }
     // control part with the digit signs folded into q:  q A.x + p B.y = (+-q) xb.x + (+-q) xk.x + p (xb.y - xk.y);
     // two accumulator pairs shorten the dependent fp64 chain (the small-system kernels are latency bound)
     double hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0.0, gi = 0.0;
@@ -1907,6 +1930,10 @@ struct Team {
         if (ok(0)) bufp(cur)[lidx(0)] = w;
         team_sync<true>();
         st.fetch(vec(), 0, nb);
+        if (QD_ABLATE & 1) {  // no stopping test: four iterations per solve
+          if (iter == 3) { iter++; break; }
+          continue;
+        }
         const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));
         if (iter == 0) d0 = d;
         if (d < 1.f) { iter++; break; }
@@ -1927,6 +1954,17 @@ struct Team {
       // initial conditions per workgroup all of them iterate until the slowest has converged (the others
       // only get more accurate).
       float d = 0.f;
+      if (QD_ABLATE & 1) {  // no stopping test: four iterations per solve; the barrier that publishes the iterate stays
+        team_sync<V::ONEWAVE>();
+        if (!V::DBUF) {
+#pragma unroll
+          for (int j = 0; j < EPT; j++)
+            if (ok(j)) bufp(cur)[lidx(j)] = y[j];
+          team_sync<V::ONEWAVE>();
+        }
+        if (iter == 3) { iter++; break; }
+        continue;
+      }
       if (ICPB == 1) {
         d = sum_f32((float)fmin(dloc[0] * inv_abs2, 1e30));  // contains the barrier (multi-wave)
       } else {
