@@ -578,8 +578,11 @@ size_t qd_handle::ztraj_doubles(int nb) const {
 // |q_k(t)| <= sum over carriers of max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity,
 // src/controlbasis.cpp:81-96; pi-pulses by their amplitude) and the dipole-dipole couplings.
 void qd_handle::row_bounds(double* diag, double* off) const {
-  double hmax = 0.0;
-  {
+  // max |h(I)| over the level combinations: a constant of the system (a million combinations for the reference's nlevels_32_32_32_32
+  // case - 15 ms of host time per sweep when it was recomputed there)
+  double hmax = hmax_cache;
+  if (hmax < 0.0) {
+    hmax = 0.0;
     std::vector<int> dg(S.Q, 0);
     for (long long I = 0; I < S.N; I++) {
       long long r = I;
@@ -592,6 +595,7 @@ void qd_handle::row_bounds(double* diag, double* off) const {
       }
       hmax = std::max(hmax, fabs(hd));
     }
+    hmax_cache = hmax;
   }
   double dg = S.lindblad ? 2.0 * hmax : hmax, of = 0.0;
   for (int k = 0; k < S.Q; k++) {

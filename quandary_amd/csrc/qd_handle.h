@@ -135,6 +135,7 @@ struct qd_handle {
 
   // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
   int refresh_tables();
+  mutable double hmax_cache = -1.0;  // max |h(I)| over the level combinations (system constant, computed on first use)
   void row_bounds(double* diag, double* off) const;  // Gershgorin bounds of a row of M over all sub-steps (current parameters)
   int gmres_poly_degree() const;  // > 1 where the Neumann series provably contracts for the current parameters, else 1
   // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
