@@ -675,6 +675,21 @@ bool qd_handle::gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const {
   return opts.gmres_split == 1 || amax * of <= 0.3;
 }
 
+// The same for every other kernel family: where the reference's own Neumann iteration provably contracts fast - Gershgorin bound
+// alpha x (whole row sum) <= 0.3 for every sub-step - a gmres request is served by it.  Its update IS the residual of the previous
+// iterate (r_m = b - (I - alpha M) y_m = y_{m+1} - y_m), so its stopping rule "update norm < abstol" is GMRES's "residual <= abstol"
+// (the rtol ||b|| branch of KSP's rule can only stop GMRES earlier, i.e. less accurately); at such contraction both need the same ~4
+// applications per step, and the stationary iteration has no orthogonalisation, no Hessenberg problem and one fp32 reduction per
+// iteration instead of two fp64 ones (4-qubit system: 2.7 ms against 7.6 ms per 1000 steps, 2^5: 15 against 34).
+bool qd_handle::gmres_as_neumann(const qd::LaunchCfg& cfg) const {
+  if (!cfg.gmres || sol.stepper == QD_STEPPER_EE || opts.gmres_split != -1) return false;  // (gmres_split = 1 only forces the column path)
+  double dg, of;
+  row_bounds(&dg, &of);
+  double amax = 0.0;
+  for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
+  return amax * (dg + of) <= 0.3;
+}
+
 // Diagonal-split Neumann iteration (qd_col.hip): same fixed point and stopping rule, the diagonal of M on the left-hand side.  It
 // costs nothing per iteration, so "where it pays" is wherever the diagonal (level energies, decay) is a visible share of the row
 // bound: alpha (diag + off) is the contraction bound of the plain iteration, alpha off that of the split one.
@@ -764,7 +779,14 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     a.use_gmres = 0;
     a.neumann_split = 1;
     a.stop_residual = 1;
+    last_poly = 1;
     cfg.lds = pick_config(S, nb, opts, false).lds;
+  } else if (gmres_as_neumann(cfg)) {
+    cfg = pick_config(S, nb, opts, false);
+    a.use_gmres = 0;
+    a.gmres_poly = 1;
+    last_poly = 1;
+    last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
@@ -947,7 +969,14 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     a.use_gmres = 0;
     a.neumann_split = 1;
     a.stop_residual = 1;
+    last_poly = 1;
     cfg.lds = pick_config(S, nb, opts, false, true).lds;
+  } else if (gmres_as_neumann(cfg)) {
+    cfg = pick_config(S, nb, opts, false, true);
+    a.use_gmres = 0;
+    a.gmres_poly = 1;
+    last_poly = 1;
+    last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
     if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;

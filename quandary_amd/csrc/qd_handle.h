@@ -84,6 +84,7 @@ struct qd_handle {
   // linearsolver_type = gmres served by the diagonal-split iteration of the lean column kernels under GMRES's stopping rule;
   // *kappa2 = (1 + max alpha |D|)^2, the factor between the squared update norm and the bound of the squared residual
   bool gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const;
+  bool gmres_as_neumann(const qd::LaunchCfg& cfg) const;  // ... by the plain Neumann iteration of any other kernel family
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // forward / adjoint kernel brackets
   qd::DevSys S{};

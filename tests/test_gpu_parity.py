@@ -242,6 +242,7 @@ def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
     the oracle's GMRES: same linear systems, same tolerance, so objective and gradient agree as for every other solver pairing; it
     never needs more applications than the oracle's un-preconditioned GMRES on these systems."""
     sp = synthetic_spec(**{**kw, "ntime": 12, "penalties": True, "linsolve": "gmres", "dt": 0.001})
+    sp.options = {"gmres_split": "auto"}
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
@@ -253,6 +254,36 @@ def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
     orc.evalF(sp.params0)
     opt.evalF(sp.params0)
     assert h.mean_applies < orc.mean_applies + 0.25
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [SHAPES[1], SHAPES[2], SHAPES[4], SHAPES[6],
+                                pytest.param(dict(nlevels=[10, 10], lindblad=True, target="pure", objective="Jfrobenius", init="pure, 0, 1"), id="10x10-team")])
+def test_gmres_request_served_by_the_neumann_iteration(kw):
+    """linearsolver_type = gmres with the default options on systems where the reference's Neumann iteration provably contracts fast
+    (Gershgorin bound h/2 x row sum <= 0.3): served by that iteration, whose update is the residual of the previous iterate, i.e.
+    GMRES's stopping rule.  Same tolerances against the oracle's GMRES as for the Krylov kernels; a stationary iteration is not the
+    optimal polynomial, so it may need a few applications more (at most a quarter more on these shapes)."""
+    if kw["nlevels"] == [2, 2, 2, 2, 2]:
+        kw = {**kw, "init": "diagonal, 0, 1"}
+    sp = synthetic_spec(**{**kw, "ntime": 16, "penalties": True, "linsolve": "gmres", "dt": 0.01})
+    sp.options = {"gmres_split": "auto"}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    orc.reset_stats()
+    orc.evalF(sp.params0)
+    opt.evalF(sp.params0)
+    assert h.mean_applies < 1.25 * orc.mean_applies + 0.5
+    # the Krylov kernels on the same problem give the same answer
+    h.set_option("gmres_split", 0)
+    val2, g2 = opt.evalGradF(sp.params0)
+    assert val2["objective"] == pytest.approx(val["objective"], rel=1e-9)
+    assert np.linalg.norm(g2 - g) <= 1e-8 * np.linalg.norm(g) + SOLVER_NOISE_ABS
     opt.close(); h.close(); orc.close()
 
 
