@@ -2504,8 +2504,12 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
       if (pen_on) {
         double weight = 0.0;
         if (wj_on) {
-          const double a = (tstop - A.Tfinal) / A.penalty_param;
-          weight = 1.0 / A.penalty_param * exp(-(a * a));
+          if (A.wjw) {  // tabulated per time step (qd_handle::ensure_wj_weights): no exp() next to the state registers
+            weight = to_scalar(A.wjw[n]);
+          } else {
+            const double a = (tstop - A.Tfinal) / A.penalty_param;
+            weight = 1.0 / A.penalty_param * exp(-(a * a));
+          }
         }
         if (wj_reduce) {
           double v[2 * ICPB];
@@ -2721,8 +2725,13 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       }
       if (pen_on) {  // penaltyIntegral_diff (timestepper.cpp:300-339)
         if (wj_on) {
-          const double a = (tstop - A.Tfinal) / A.penalty_param;
-          const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+          double weight;
+          if (A.wjw) {
+            weight = to_scalar(A.wjw[n - 1]);
+          } else {
+            const double a = (tstop - A.Tfinal) / A.penalty_param;
+            weight = 1.0 / A.penalty_param * exp(-(a * a));
+          }
           double rb[ICPB], ib[ICPB];
           if (wj_reduce) {
             double v[2 * ICPB];

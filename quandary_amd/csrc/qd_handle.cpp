@@ -701,6 +701,23 @@ int qd_handle::neumann_split_on() const {
   return dg >= 0.25 * of ? 1 : 0;
 }
 
+// weights of the weighted-J penalty, tabulated per time step (constants of the handle: time grid, Tfinal, optim_penalty_param)
+int qd_handle::ensure_wj_weights() {
+  if (!(pen.gamma_penalty > 1e-13 && pen.penalty_param > 1e-13)) return QD_OK;
+  if (wjw_param == pen.penalty_param && d_wjw.p) return QD_OK;
+  std::vector<double> w(tg.ntime);
+  for (int n = 0; n < tg.ntime; n++) {
+    const double a = ((n + 1) * tg.dt - dctl.Tfinal) / pen.penalty_param;
+    w[n] = 1.0 / pen.penalty_param * exp(-(a * a));
+  }
+  int r;
+  if ((r = d_wjw.ensure(w.size()))) return r;
+  QD_HIP(hipMemcpyAsync(d_wjw.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, stream));
+  QD_HIP(hipStreamSynchronize(stream));  // (w is a local)
+  wjw_param = pen.penalty_param;
+  return QD_OK;
+}
+
 static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget* tg) {
   std::memset(&a, 0, sizeof a);
   a.S = h->S;
@@ -723,6 +740,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   // penalties that need target data are only active when a target has been set
   a.gamma_penalty = h->pen.gamma_penalty;
   a.penalty_param = tg ? h->pen.penalty_param : 0.0;
+  a.wjw = (tg && h->wjw_param == h->pen.penalty_param) ? h->d_wjw.p : nullptr;
   a.gamma_dpdm = h->pen.gamma_penalty_dpdm;
   a.leak_on = 0;
   for (int k = 0; k < h->S.Q; k++)
@@ -760,6 +778,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     LaunchCfg c0 = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES);
     if (c0.var == 16 && (r = ensure_big(nb))) return r;
   }
+  if ((r = ensure_wj_weights())) return r;
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   last_poly = a.gmres_poly;
@@ -953,6 +972,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     LaunchCfg c0 = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES, true);
     if (c0.var == 16 && (r = ensure_big(nb))) return r;
   }
+  if ((r = ensure_wj_weights())) return r;
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   last_poly = a.gmres_poly;

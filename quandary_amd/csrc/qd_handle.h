@@ -122,6 +122,9 @@ struct qd_handle {
   int target_nb = 0;
   // sweep buffers
   qd::DBuf d_ztraj;  // stored primal stages (SweepArgs::ztraj)
+  qd::DBuf d_wjw;    // Gaussian weights of the weighted-J penalty per time step (SweepArgs::wjw)
+  double wjw_param = -1.0;
+  int ensure_wj_weights();
   qd::DBuf d_x0, d_xT, d_traj, d_res, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
   qd::DBuf d_ecoef, d_edig, d_work;  // large states (qd_big.h): element table, work vectors
   int ensure_big(int nb);            // no-op unless the launch configuration is the large-state variant

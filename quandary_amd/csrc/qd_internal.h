@@ -81,6 +81,9 @@ struct SweepArgs {
   // kappa >= |1 - alpha D_ii| bounds the true residual ||b - (I - alpha M) y_m|| = ||(1 - alpha D)(y_{m+1} - y_m)|| from above
   int stop_residual;
   double kappa2;
+  // Gaussian weights of the weighted-J penalty, one per time step: wjw[n] = exp(-((n + 1) dt - T)^2 / param^2) / param
+  // (timestepper.cpp:262-270, :304-315); tabulated once per handle so that the sweep kernels of qd_col.hip need no exp() per step
+  const double* wjw;
   int use_gmres;  // 0: Neumann; 1: in-kernel GMRES, Krylov basis in LDS (one element per thread, small dim); 2: basis in global memory (kry)
   double abstol, reltol;
   // penalties (src/timestepper.cpp:256-480)

@@ -625,7 +625,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
       const int n = (s + 1) / A.nstages - 1;
       const double tstop = (n + 1) * A.dt;
       const double a = (tstop - A.Tfinal) / A.penalty_param;
-      const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+      const double weight = A.wjw ? to_scalar(A.wjw[n]) : 1.0 / A.penalty_param * exp(-(a * a));  // (tabulated per time step)
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         double jr = 0.0, ji = 0.0;
@@ -685,7 +685,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
       const int n = (s + 1) / A.nstages;
       const double tstop = n * A.dt;
       const double a = (tstop - A.Tfinal) / A.penalty_param;
-      const double weight = 1.0 / A.penalty_param * exp(-(a * a));
+      const double weight = A.wjw ? to_scalar(A.wjw[n - 1]) : 1.0 / A.penalty_param * exp(-(a * a));
       double rb, ib;
       finalizeJ_diff<true>(A.tg, 0.0, 0.0, rb, ib);
 #pragma unroll
