@@ -58,6 +58,9 @@ struct ColLean {
   __device__ __forceinline__ bool colok(int j) const { return col0 + j < N; }
   __device__ __forceinline__ bool ok(int j) const { return rowok && colok(j); }
   __device__ __forceinline__ int elem(int j) const { return (col0 + j) * N + row; }  // vectorised index (valid slots only)
+  // the same, re-derived at the point of use: hoisted out of the time loop the per-slot indices are spilt and every global access
+  // of a step starts with a scratch reload
+  __device__ __forceinline__ int elem_now(int j) const { return (col0 + j) * N + opaque(row); }
   static __host__ __device__ int ncols(int N) { return (N + EPT - 1) / EPT * EPT; }
   static __host__ __device__ unsigned bufbytes(int N) { return (unsigned)ncols(N) * COLB; }
   static __host__ __device__ unsigned tab_off(int N) { return 2 * bufbytes(N) + 2 * (unsigned)sizeof(double) * NRED * (unsigned)(ncols(N) / EPT) + 128; }
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (tm.st.colok(j)) {
-          const int e = opaque(tm.st.elem(j));
+          const int e = tm.st.elem_now(j);
           if (nt) {
             __builtin_nontemporal_store(v[j].x, dst + e);
             __builtin_nontemporal_store(v[j].y, dst + dim + e);
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (tm.st.colok(j)) {
-          const int e = opaque(tm.st.elem(j));
+          const int e = tm.st.elem_now(j);
           x[j] = make_double2(xpark[e], xpark[dim + e]);
         }
     }
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
           for (int j = 0; j < EPT; j++)
             if (tm.st.colok(j)) {
               double jr = 0.0, ji = 0.0;
-              evalJ_part<true>(S, A.tg, ic, opaque(tm.st.elem(j)), x[j], jr, ji);
+              evalJ_part<true>(S, A.tg, ic, tm.st.elem_now(j), x[j], jr, ji);
               pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
             }
         }
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     const double* src = base + ((size_t)s * A.nb + ic) * 2 * dim;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-      dst[j] = tm.st.ok(j) ? make_double2(__builtin_nontemporal_load(src + opaque(tm.st.elem(j))), __builtin_nontemporal_load(src + dim + opaque(tm.st.elem(j))))
+      dst[j] = tm.st.ok(j) ? make_double2(__builtin_nontemporal_load(src + tm.st.elem_now(j)), __builtin_nontemporal_load(src + dim + tm.st.elem_now(j)))
                            : make_double2(0.0, 0.0);
   };
 
@@ -585,7 +588,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
         } else {
 #pragma unroll
           for (int j = 0; j < EPT; j++)
-            if (tm.st.ok(j)) evalJ_diff_elem<true>(S, A.tg, ic, opaque(tm.st.elem(j)), xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
+            if (tm.st.ok(j)) evalJ_diff_elem<true>(S, A.tg, ic, tm.st.elem_now(j), xn[j], xb[j], weight * rb * jbar_pen * A.dt, weight * ib * jbar_pen * A.dt);
         }
       }
       if (leak) {
