@@ -126,6 +126,7 @@ struct TuneOpts {
   int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
+  int col_min_n = 33;      // "col_min_n": smallest density-matrix dimension N the lean column kernels take over from the eight-elements-per-thread kernel
   int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
   int gmres_split = -1;    // "gmres_split": linearsolver_type = gmres served by the diagonal-split iteration under GMRES's stopping rule where that
                            // iteration contracts fast (-1 = there, 0 = never: always the Krylov kernels, 1 = wherever it is built)

@@ -463,7 +463,8 @@ LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmre
   else if (dim <= 1024) var = fits(14) ? 14 : 2;  // packed column layout for non-qubit Lindblad (3x3x3: 18.7M vs 12.4M units/s)
   // column layout when most of its 64 lanes (= rows) are used; measured: N = 36 V4 8.6M vs V9 7.2M units/s,
   // N = 49 4.3M vs 6.7M, N = 64 3.3M vs 5.2M
-  else var = (fits(QD_COL_DEFAULT) && S.N >= 44) ? QD_COL_DEFAULT : 4;
+  // ... the lean column kernels (qd_col.hip) already from N = 33 (measured below), the general column kernel from N = 44
+  else var = (fits(QD_COL_DEFAULT) && (S.N >= 44 || (!gm && S.N >= o.col_min_n && collean_available(S, o)))) ? QD_COL_DEFAULT : 4;
   if (S.dense) var = dim <= 64 ? 11 : dim <= 256 ? 12 : 13;  // qd_set_hamiltonian limits dim to 1024
   // matrix cores for the dense operator and (adjoint sweep) for the gradient contraction's 2Q commutators per step; the option no_mfma
   // keeps the vector kernels (measurements)
@@ -542,7 +543,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // options
 // ---------------------------------------------------------------------------------------------
 static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "f32_sb", "no_lean64", "no_collean",
-                                       "col_ept", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb"};
+                                       "col_ept", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
   const std::string k(key), v(value);
@@ -568,6 +569,7 @@ int TuneOpts::set(const char* key, const char* value) {
   else if (k == "no_lean64") no_lean64 = iv != 0;
   else if (k == "no_collean") no_collean = iv != 0;
   else if (k == "col_ept") col_ept = (int)iv;
+  else if (k == "col_min_n") col_min_n = iv > 0 ? (int)iv : 33;
   else if (k == "gmres_poly") gmres_poly = iv > 0 ? (int)iv : 0;
   else if (k == "neumann_split") neumann_split = iv < 0 ? -1 : iv != 0;
   else if (k == "gmres_split") gmres_split = iv < 0 ? -1 : iv != 0;

@@ -122,6 +122,9 @@ LEANCOL_SHAPES = [
     pytest.param(dict(nlevels=[3, 3, 5], lindblad=True, nessential=[2, 3, 4], target="pure", objective="Jmeasure", init="diagonal, 2"), id="3x3x5-N45"),
     pytest.param(dict(nlevels=[2, 4, 7], lindblad=True, target="pure", objective="Jfrobenius", init="diagonal, 0"), id="2x4x7-N56"),
     pytest.param(dict(nlevels=[7, 9], lindblad=True, detuned=True, target="pure", objective="Jmeasure", init="diagonal, 1"), id="7x9-N63"),
+    # 33 <= N < 44: lanes 33..43 of 64 in use, still ahead of the eight-elements-per-thread kernel (1.1-1.8 x)
+    pytest.param(dict(nlevels=[2, 20], lindblad=True, nessential=[2, 18], target="pure", objective="Jtrace", init="diagonal, 1"), id="2x20-N40"),
+    pytest.param(dict(nlevels=[5, 7], lindblad=True, target="pure", objective="Jfrobenius", init="diagonal, 0"), id="5x7-N35"),
 ]
 
 
@@ -129,7 +132,7 @@ LEANCOL_SHAPES = [
 @pytest.mark.parametrize("stepper", ["IMR", "IMR4"])
 @pytest.mark.parametrize("kw", LEANCOL_SHAPES)
 def test_lean_column_kernels(kw, stepper, split):
-    """qd_col.hip (Lindblad, 44 <= N <= 64 rows, two or three oscillators, Neumann): operator and transpose at 1e-13, objective
+    """qd_col.hip (Lindblad, 33 <= N <= 64 rows, two or three oscillators, Neumann): operator and transpose at 1e-13, objective
     parts and gradient against the oracle with every Lindblad penalty (weighted J, leakage through guard levels, energy).
     split = "0": the reference's Neumann iteration, application counts as the oracle's.  split = "auto": the diagonal-split
     iteration (these systems carry a self-Kerr ladder of up to 20 levels, so it is on) - same fixed point and stopping rule, so
@@ -877,6 +880,33 @@ def test_bench_two_ranks_matches_one_rank():
     assert res[2]["config"]["ninit_per_gpu"] * 2 == res[1]["config"]["ninit"]
     assert res[2]["config"]["objective"] == pytest.approx(res[1]["config"]["objective"], rel=1e-12)
     assert set(res[2]["allreduce_ms_per_step"]) == {"objective_sums", "gradient"}
+
+
+@pytest.mark.parametrize("workload,extra", [("c2", []), ("c3", []), ("c4", ["--set", "initialcondition=basis, 0", "--ntime", "40"])])
+def test_two_ranks_over_rccl_match_one_rank(workload, extra):
+    """The fused multi-GPU path with REAL collectives (needs two GPUs: skipped on one-GPU boxes, where RCCL refuses two ranks on one
+    device): `bench.py --gpus 2 --dist-backend nccl` - one merged all-reduce of 7 sums + gradient (Lindblad: c2, c4) and the
+    two-collective structure of Schroedinger + Jtrace (c3) - against the one-GPU run; the line must say rccl = true."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    if capi.load_library().qd_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    common = ["--workload", workload, "--mode", "grad", "--steps", "1", "--warmup", "1", "--no-workloads", "--no-cpu-baseline"] + extra
+    if "--ntime" not in extra:
+        common += ["--ntime", "200"]
+    res = {}
+    for n in (1, 2):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "nccl"] + common,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[n] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res[2]["rccl"] is True and res[2]["ranks_seen"] == 2
+    assert res[2]["config"]["objective"] == pytest.approx(res[1]["config"]["objective"], rel=1e-12)
 
 
 @pytest.mark.parametrize("name,ninit", [("c4", 3600), ("c5", 1024)])
