@@ -585,6 +585,34 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
   const int ntime = A.ntime;
   tm.tsync();
+  if (A.stepper_ee && !LIND) {
+    // Explicit Euler in Schroedinger mode [r3: also beyond dim 4096]: the reference re-computes the primal backwards with the FORWARD
+    // stepper and a negative step (src/timestepper.cpp:229-231 with ExplEuler::evolveFWD :496-507), and its gradient is defined on
+    // that chain - reproduce it by overwriting the stored trajectory (k_adjoint of qd_device.h does the same in registers).
+    double* trajw = const_cast<double*>(traj);
+    for (int e = tid; e < dim; e += nt) Ya[e] = state(A.nsub, e);
+    tm.tsync();
+    for (int s = A.nsub - 1; s >= 0; s--) {
+      StepC<Q> c1;
+      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);  // M(tstop of step s) = row s + 1
+      scalarize<Q>(c1, jpairs);
+      c1.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
+      const double hneg = -to_scalar(A.ctl[(size_t)s * A.cs]);
+      for (int e = tid; e < dim; e += nt) KB[e] = tm.template apply<false>(S, c1, Ya, e);
+      tm.tsync();
+      double* dst = trajw + ((size_t)s * A.nb + ic) * 2 * dim;
+      for (int e = tid; e < dim; e += nt) {
+        const double2 t = KB[e];
+        double2 v = Ya[e];
+        v.x = fma(hneg, t.x, v.x);
+        v.y = fma(hneg, t.y, v.y);
+        Ya[e] = v;
+        dst[e] = v.x;
+        dst[dim + e] = v.y;
+      }
+      tm.tsync();
+    }
+  }
   for (int s = A.nsub - 1; s >= 0; s--) {
     // ---- penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227)
     if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {
@@ -639,6 +667,45 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     double cf[2 * Q];
 #pragma unroll
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
+    if (A.stepper_ee) {
+      // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt x_adj against x_{n-1}, then x_adj += dt M(tstop)^T x_adj;
+      // M(tstop) is table row s + 1 (the last row is followed by one extra row for t = T)
+      for (int e = tid; e < dim; e += nt) Z[e] = state(s, e);
+      tm.tsync();
+      for (int e = tid; e < dim; e += nt) {
+        tm.at(e);
+        const double2 xb = XB[e];
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+          double2 Av, Bv;
+          tm.st.ladder(S, tm.L, Z, k, 0, Av, Bv);
+          cf[2 * k] += c.h * (Bv.y * xb.x - Bv.x * xb.y);
+          cf[2 * k + 1] += c.h * (Av.x * xb.x + Av.y * xb.y);
+        }
+      }
+      tm.template sum<2 * Q>(cf);
+      {
+        double* co = A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q;
+#pragma unroll
+        for (int i = 0; i < 2 * Q; i++)
+          if (tid == i) co[i] = cf[i];
+      }
+      StepC<Q> c1;
+      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
+      scalarize<Q>(c1, jpairs);
+      c1.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
+      for (int e = tid; e < dim; e += nt) KB[e] = tm.template apply<true>(S, c1, XB, e);
+      tm.tsync();
+      for (int e = tid; e < dim; e += nt) {
+        const double2 t = KB[e];
+        double2 xb = XB[e];
+        xb.x = fma(c.h, t.x, xb.x);
+        xb.y = fma(c.h, t.y, xb.y);
+        XB[e] = xb;
+      }
+      tm.tsync();
+      continue;
+    }
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z = x + h/2 k (:640-652) was stored by the forward sweep
     {
       const double* zsrc = A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim;

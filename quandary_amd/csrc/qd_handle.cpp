@@ -127,10 +127,6 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
     delete h;
     return fail(QD_ERR_UNSUPPORTED, "qd_create: state dimension above QD_MAX_DIM (2^22)");
   }
-  if (dim > 4096 && sol->stepper == QD_STEPPER_EE) {
-    delete h;
-    return fail(QD_ERR_UNSUPPORTED, "qd_create: the explicit-Euler debug stepper is not built for state dimensions > 4096");
-  }
   {  // packed digits (qd_device.h: packed_digit_bits)
     const int maxlev = S.Q <= 4 ? 256 : S.Q == 5 ? 64 : S.Q == 6 ? 32 : 16;
     if (S.maxn > maxlev) {

@@ -790,21 +790,42 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(capi.QuandaryAmdError, match="QD_MAX_DIM"):
         capi.Handle(sp)
     sp = synthetic_spec([9, 9], lindblad=True, ntime=2, target="pure", objective="Jmeasure", init="pure, 0, 0", stepper="EE")
-    with pytest.raises(capi.QuandaryAmdError, match="explicit-Euler"):
+    sp.precision = "f32mixed"
+    with pytest.raises(capi.QuandaryAmdError):
         capi.Handle(sp)
+
+
+@pytest.mark.parametrize("kw", [BIG_SHAPES[0], BIG_SHAPES[3]])
+@pytest.mark.parametrize("team", [1, 8])
+def test_explicit_euler_beyond_lds(kw, team):
+    """ExplEuler for dim > 4096 (was QD_ERR_UNSUPPORTED through round 2; the reference's debug stepper works at any size,
+    src/timestepper.cpp:484-520): Lindblad on the stored trajectory, Schroedinger on the backward-recomputed chain (all penalties incl.
+    dpdm), one workgroup and a team of eight per state."""
+    sp = synthetic_spec(**{**kw, "ntime": 6, "nspline": 5, "penalties": True, "stepper": "EE", "dt": 0.002})
+    sp.options = {"big_team": team}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    assert h.dim > 4096
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_team == team
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
 
 
 def test_chunked_adjoint_when_trajectory_does_not_fit(monkeypatch):
     """A shard whose stored trajectory exceeds HBM is re-propagated and reversed in chunks
-    (qd_optim_adjoint_local); the budget is faked through QD_TRAJ_BUDGET_MB."""
+    (qd_optim_adjoint_local); the budget is faked through the option traj_budget_mb."""
     sp = synthetic_spec([2, 2], lindblad=True, ntime=20, penalties=True)
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     # one trajectory = 21 states x 16 initial conditions x 32 doubles = 86 kB; allow ~5 initial conditions
-    monkeypatch.setenv("QD_TRAJ_BUDGET_MB", str(21 * 5 * 32 * 8 / 1048576.0))
+    h.set_option("traj_budget_mb", 21 * 5 * 32 * 8 / 1048576.0)
     val2, g2 = opt.evalGradF(sp.params0)
-    monkeypatch.delenv("QD_TRAJ_BUDGET_MB")
+    h.set_option("traj_budget_mb", 0)
     for k in OBJ_KEYS:
         assert val2[k] == pytest.approx(val[k], rel=1e-13, abs=1e-15), k
     np.testing.assert_allclose(g2, g, rtol=1e-11, atol=1e-15)
