@@ -379,9 +379,9 @@ extern "C" int qd_set_precision(qd_handle* h, int precision) {
   if (precision != QD_PRECISION_F64 && precision != QD_PRECISION_F32MIXED) return fail(QD_ERR_INVALID, "qd_set_precision: unknown precision");
   if (precision == QD_PRECISION_F32MIXED) {
     const DevSys& S = h->S;
-    bool qubits = S.lindblad && !S.dense && (S.Q == 4 || S.Q == 5);
+    bool qubits = S.lindblad && !S.dense && (S.Q == 3 || S.Q == 4 || S.Q == 5);
     for (int k = 0; k < S.Q; k++) qubits = qubits && S.n[k] == 2 && S.ness[k] == 2;
-    if (!qubits || S.hasJ) return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps are built for all-qubit Lindblad systems with 4 or 5 oscillators without dipole-dipole coupling");
+    if (!qubits || S.hasJ) return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps are built for all-qubit Lindblad systems with 3, 4 or 5 oscillators without dipole-dipole coupling");
     if (h->sol.stepper == QD_STEPPER_EE)
       return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps need a stepper of the IMR family");
   }

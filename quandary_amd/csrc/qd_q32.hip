@@ -968,10 +968,12 @@ hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t
   if (a.use_gmres) {  // Krylov basis in global memory as float2, Hessenberg problem in fp64
     if (a.S.Q == 5) return go_fwd<5, 2, float, true>(a, st);
     if (a.S.Q == 4) return go_fwd<4, 0, float, true>(a, st);
+    if (a.S.Q == 3) return go_fwd<3, 0, float, true>(a, st);
     return hipErrorInvalidValue;
   }
   if (a.S.Q == 5) return go_fwd<5, 2, float>(a, st);
   if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2, float>(a, st) : go_fwd<4, 0, float>(a, st);
+  if (a.S.Q == 3) return go_fwd<3, 0, float>(a, st);  // [r3] 2x2x2 (BASELINE config 2): one wave per initial condition
   return hipErrorInvalidValue;
 }
 hipError_t launch_adjoint_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
@@ -979,10 +981,12 @@ hipError_t launch_adjoint_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t
   if (a.use_gmres) {
     if (a.S.Q == 5) return go_adj<5, 2, float, true>(a, st);
     if (a.S.Q == 4) return go_adj<4, 0, float, true>(a, st);
+    if (a.S.Q == 3) return go_adj<3, 0, float, true>(a, st);
     return hipErrorInvalidValue;
   }
   if (a.S.Q == 5) return go_adj<5, 2, float>(a, st);
   if (a.S.Q == 4) return sb == 2 ? go_adj<4, 2, float>(a, st) : go_adj<4, 0, float>(a, st);
+  if (a.S.Q == 3) return go_adj<3, 0, float>(a, st);
   return hipErrorInvalidValue;
 }
 hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, int nrep, int mfma,
@@ -995,6 +999,7 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
   const int sb = q32_slot_bits(S.Q, o);
   if (S.Q == 5) return go_app<5, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   if (S.Q == 4) return sb == 2 ? go_app<4, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st) : go_app<4, 0, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
+  if (S.Q == 3) return go_app<3, 0, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   return hipErrorInvalidValue;
 }
 

@@ -33,7 +33,7 @@ def _spec(q, init, ntime, penalties=False, stepper="IMR", linsolve="neumann"):
     return sp
 
 
-@pytest.mark.parametrize("q", [4, 5])
+@pytest.mark.parametrize("q", [3, 4, 5])
 def test_f32_operator_application(q):
     sp = _spec(q, "diagonal, 0", 10)
     sp.precision = "f32mixed"
@@ -49,7 +49,7 @@ def test_f32_operator_application(q):
     h.close(); orc.close()
 
 
-@pytest.mark.parametrize("q,init,penalties", [(4, "basis, 0, 1", False), (4, "diagonal, 0, 1", True), (5, "diagonal, 0", False), (5, "basis, 4", True)])
+@pytest.mark.parametrize("q,init,penalties", [(3, "basis", True), (3, "diagonal, 0", False), (4, "basis, 0, 1", False), (4, "diagonal, 0, 1", True), (5, "diagonal, 0", False), (5, "basis, 4", True)])
 def test_f32_objective_and_gradient_budget_ntime1000(q, init, penalties):
     """The stated budget over ntime = 1000 (the length of the C5 / q4 workloads) against the fp64 oracle."""
     sp = _spec(q, init, 1000, penalties)
@@ -74,7 +74,7 @@ def test_f32_objective_and_gradient_budget_ntime1000(q, init, penalties):
     opt.close(); h.close(); orc.close()
 
 
-@pytest.mark.parametrize("q,init,penalties", [(4, "basis, 0, 1", True), (5, "diagonal, 0", False), (5, "basis, 4", True)])
+@pytest.mark.parametrize("q,init,penalties", [(3, "basis", True), (4, "basis, 0, 1", True), (5, "diagonal, 0", False), (5, "basis, 4", True)])
 def test_f32_gmres_objective_and_gradient_budget_ntime1000(q, init, penalties):
     """The reference's default solver in fp32-mixed: Krylov basis as float2 in global memory, Hessenberg problem in fp64, recurrence
     residual floored at 2^-22 ||b|| (where the true fp32 residual stalls).  Same error budget against the fp64 oracle (GMRES) as the
@@ -123,7 +123,7 @@ def test_f32_compositional_stepper_and_trajectory():
 
 
 def test_f32_is_opt_in_and_rejected_where_not_built():
-    sp = synthetic_spec([2, 2, 2], lindblad=True, ntime=5)  # three qubits: not built
+    sp = synthetic_spec([2, 2], lindblad=True, ntime=5)  # two qubits: not built (three to five are)
     sp.precision = "f32mixed"
     with pytest.raises(capi.QuandaryAmdError, match="fp32-mixed"):
         capi.Handle(sp)
