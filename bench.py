@@ -373,7 +373,9 @@ EXTRA = [
     ("l20", "fwd", "gmres", "f64", {}, 2, {"gmres_split": 0}),
     # the reference's own performance workloads (tests/performance/test_cases.json): Schroedinger, J_kl on all pairs, GMRES
     ("n4444", "fwd", "gmres", "f64", {}, 5, {}),
-    ("n32", "fwd", "gmres", "f64", {}, 1, {}),
+    ("n32", "fwd", "gmres", "f64", {}, 2, {}),  # served by the diagonal-split iteration of the global-memory kernels (exact residual rule)
+    ("n32", "fwd", "gmres", "f64", {}, 1, {"gmres_split": 0}),  # the Krylov kernel: 12 basis vectors of 16 MB through HBM
+    ("n32", "grad", "gmres", "f64", {}, 1, {}),
     # small systems: no chip-filling possible (4 / 16 single-wave workgroups); reported so that the bench line says it
     ("c1", "grad", "gmres", "f64", {}, 3, {}),
     ("c3", "grad", "neumann", "f64", {}, 3, {}),

@@ -65,13 +65,19 @@ template <int Q, bool LIND, bool DENSE = false>
 struct BigTeam {
   // one slot, table-driven (non-hoisted) formulation; DENSE: user-supplied Hamiltonians, G(t) read from the table in global memory
   typedef typename std::conditional<DENSE, DenseStencil<Q, LIND, 1, 2>, GenStencil<Q, LIND, 1, 2>>::type ST;
+#ifndef QD_BIG_BATCH_SCHR
+#define QD_BIG_BATCH_SCHR 0
+#endif
+  static constexpr bool kBatch = LIND || QD_BIG_BATCH_SCHR;  // neighbour reads in batches (GenStencil::apply_batched)
   ST st;
   Lds L;
   int dim, redslot;
   const double2* coef;
   const uint2* dig;
-  // team of G workgroups on one initial condition: element loops run e = gtid, gtid + gnt, ...
-  int G, member, ic, gtid, gnt, gslot;
+  // team of G workgroups on one initial condition: element loops run e = gtid, gtid + gnt, ... < gend.  Blocked (default): member m
+  // owns the contiguous elements [m chunk, (m + 1) chunk) - its own elements and most stencil neighbours (strides 1, n_Q, n_Q n_{Q-1},
+  // ...) stay in the L2 of its XCD.  Strided (big_blocked = 0): every member walks the whole vector.
+  int G, member, ic, gtid, gnt, gend, gslot;
   unsigned long long* bar;
   unsigned long long bar_target, sub_target;  // (thread 0 only)
   double2* scratch;  // one more work vector of the state (polynomial preconditioner of gmres)
@@ -89,7 +95,7 @@ struct BigTeam {
     if (G == 1) {
       ic = blockIdx.x;
       member = 0;
-    } else if (S.team_spread) {
+    } else if (S.team_spread & 1) {
       ic = blockIdx.x / G;
       member = blockIdx.x % G;
     } else {
@@ -98,8 +104,18 @@ struct BigTeam {
       member = r % G;
     }
     if (ic >= nb) return false;
-    gtid = member * blockDim.x + threadIdx.x;
-    gnt = G * blockDim.x;
+    if (G > 1 && (S.team_spread & 6)) {
+      const int chunk = ((dim + G - 1) / G + 63) & ~63;
+      // (4): the members of one XCD (equal member % 8 under round-robin dispatch) own neighbouring blocks
+      const int blk = ((S.team_spread & 4) && G >= 8 && (S.team_spread & 1)) ? (member & 7) * (G >> 3) + (member >> 3) : member;
+      gtid = blk * chunk + threadIdx.x;
+      gnt = blockDim.x;
+      gend = min(dim, (blk + 1) * chunk);
+    } else {
+      gtid = member * blockDim.x + threadIdx.x;
+      gnt = G * blockDim.x;
+      gend = dim;
+    }
     gslot = 0;
     bar = S.tbar + (size_t)ic * BIG_BAR_STRIDE;
     bar_target = 0;
@@ -174,7 +190,8 @@ struct BigTeam {
   template <bool TRANS>
   __device__ __forceinline__ double2 apply(const DevSys& S, const StepC<Q>& c, const double2* __restrict__ src, int e) {
     at(e);
-    return st.template apply<TRANS>(S, L, src, c, 0, src[e]);
+    if constexpr (DENSE || !kBatch) return st.template apply<TRANS>(S, L, src, c, 0, src[e]);
+    else return st.template apply_batched<TRANS>(S, L, src, c, 0, src[e]);
   }
   template <int NV>
   __device__ __forceinline__ void sum(double (&v)[NV]) {
@@ -223,36 +240,101 @@ struct BigTeam {
     return block_sum_f32<false>(v, red);
   }
 
+  // the off-diagonal part of the operator at element e: the stencil takes the element's own value as a separate argument and uses it
+  // for the diagonal terms only
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply_off(const DevSys& S, const StepC<Q>& c, const double2* __restrict__ src, int e) {
+    at(e);
+    if constexpr (DENSE || !kBatch) return st.template apply<TRANS>(S, L, src, c, 0, make_double2(0.0, 0.0));
+    else return st.template apply_batched<TRANS>(S, L, src, c, 0, make_double2(0.0, 0.0));
+  }
+
   // Neumann iteration (timestepper.cpp:697-727): (I - alpha M^{(T)}) y = b, b in Bv; iterates alternate between Ya and Yb.
   // Returns the vector that holds the solution; *iters = RHS applications.
+  // A.neumann_split (not for user-supplied dense Hamiltonians, whose diagonal sits inside G(t)): the diagonal-split form of qd_col.hip,
+  // y <- (1 - alpha D)^-1 (b + alpha (M - D) y) from y_0 = (1 - alpha D)^-1 b, D = d -+ i Delta from the per-element table - same fixed
+  // point, same stopping rule on the update norm.  A.stop_residual (a GMRES request served by this iteration, qd_handle::gmres_as_split):
+  // stop on the residual of the iterate, ||b - (I - alpha M) y_m|| = ||(1 - alpha D)(y_{m+1} - y_m)|| <= max(rtol ||b||, abstol), which
+  // is KSPGMRES's rule (src/timestepper.cpp:541-550); the factor is applied element by element, so the norm is exact.
+  // y0_ready: the caller has produced y_0 in Yb (split_y0 in the loop that wrote b) and the team sum of |b|^2 in nb2s.
+  __device__ __forceinline__ bool split_on(const SweepArgs& A) const { return !DENSE && A.neumann_split; }
+  // (1 - alpha D)^-1 v at the element of the last at() / apply()
+  template <bool TRANS>
+  __device__ __forceinline__ double2 split_y0(double alpha, const double2 v) const {
+    const double re = fma(-alpha, st.dd[0], 1.0), im = (TRANS ? -alpha : alpha) * st.dw[0];
+    const double inv = 1.0 / fma(re, re, im * im);
+    const double pr = re * inv, pi = -im * inv;
+    return make_double2(fma(pr, v.x, -pi * v.y), fma(pr, v.y, pi * v.x));
+  }
   template <bool TRANS>
   __device__ __forceinline__ double2* neumann(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
-                                              double2* Yb, int* iters) {
+                                              double2* Yb, int* iters, bool y0_ready = false, double nb2s = 0.0) {
     // y_0 = b is read in place (the caller has put a team barrier behind the last write to Bv); the iterates alternate Ya / Yb
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
-    const float rel2 = (float)(A.reltol * A.reltol);
+    float rel2 = (float)(A.reltol * A.reltol), thr = 1.f;
     float d0 = 1.f;
     int iter, wb = 0;
     double2* const bufs[2] = {Ya, Yb};
     const double2* cur = Bv;
+    const bool split = !DENSE && A.neumann_split;
+    const bool resid = split && A.stop_residual;
+    const double sal = TRANS ? -alpha : alpha;
+    if (split) {
+      double nb2[1] = {nb2s};
+      if (!y0_ready) {
+        for (int e = gtid; e < gend; e += gnt) {
+          const double2 cf = coef[e], bj = Bv[e];
+          const double re = fma(-alpha, cf.y, 1.0), im = sal * cf.x;  // 1 - alpha D
+          const double inv = 1.0 / fma(re, re, im * im);
+          const double pr = re * inv, pi = -im * inv;
+          Yb[e] = make_double2(fma(pr, bj.x, -pi * bj.y), fma(pr, bj.y, pi * bj.x));
+          nb2[0] = fma(bj.x, bj.x, fma(bj.y, bj.y, nb2[0]));
+        }
+        if (resid) sum<1>(nb2);  // (contains the team barrier)
+        else tsync();
+      }
+      if (resid) {
+        thr = (float)fmin(fmax(A.reltol * A.reltol * nb2[0] * inv_abs2, 1.0), 1e30);
+        rel2 = 0.f;
+      }
+      cur = Yb;
+    }
     for (iter = 0; iter < A.maxiter; iter++) {
       double2* nxt = bufs[wb];
       double dl = 0.0;
-      for (int e = gtid; e < dim; e += gnt) {
-        const double2 t = apply<TRANS>(A.S, c, cur, e);
-        const double2 bj = Bv[e], yo = cur[e];
-        double2 w;
-        w.x = fma(alpha, t.x, bj.x);
-        w.y = fma(alpha, t.y, bj.y);
-        const double dx = yo.x - w.x, dy = yo.y - w.y;
-        dl += dx * dx + dy * dy;
-        nxt[e] = w;
+      if (split) {
+        for (int e = gtid; e < gend; e += gnt) {
+          const double2 t = apply_off<TRANS>(A.S, c, cur, e);
+          const double2 bj = Bv[e], yo = cur[e];
+          const double re = fma(-alpha, st.dd[0], 1.0), im = sal * st.dw[0];
+          const double n2 = fma(re, re, im * im), inv = 1.0 / n2;
+          const double pr = re * inv, pi = -im * inv;
+          const double ux = fma(alpha, t.x, bj.x), uy = fma(alpha, t.y, bj.y);
+          double2 w;
+          w.x = fma(pr, ux, -pi * uy);
+          w.y = fma(pr, uy, pi * ux);
+          const double dx = yo.x - w.x, dy = yo.y - w.y;
+          const double d2 = dx * dx + dy * dy;
+          dl += resid ? n2 * d2 : d2;
+          nxt[e] = w;
+        }
+      } else {
+        for (int e = gtid; e < gend; e += gnt) {
+          const double2 t = apply<TRANS>(A.S, c, cur, e);
+          const double2 bj = Bv[e], yo = cur[e];
+          double2 w;
+          w.x = fma(alpha, t.x, bj.x);
+          w.y = fma(alpha, t.y, bj.y);
+          const double dx = yo.x - w.x, dy = yo.y - w.y;
+          dl += dx * dx + dy * dy;
+          nxt[e] = w;
+        }
       }
       const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the (team) barrier and its fences
       cur = nxt;
       wb ^= 1;
       if (iter == 0) d0 = d;
-      if (d < 1.f) { iter++; break; }
+      if (d < thr) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
     }
     *iters = iter;
@@ -267,7 +349,7 @@ struct BigTeam {
   __device__ __forceinline__ double2* gmres(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ysol,
                                             double2* Wv, int* iters) {
     constexpr int MR = GMRES_MR_G;
-    const int nt = gnt, tid = gtid;
+    const int nt = gnt, tid = gtid, eend = gend;
     double2* Vg = reinterpret_cast<double2*>(A.kry) + (size_t)ic * (MR + 2) * dim;
     double* hc = L.ksc;
     double* cs = hc + (MR + 2);
@@ -282,14 +364,14 @@ struct BigTeam {
     const int MRE = poly > 1 ? (MR - 2) / 2 : MR;
     double2* Zg = Vg + (size_t)(MRE + 1) * dim;
     const double2* Sg = poly > 1 ? Zg : Vg;
-    for (int e = tid; e < dim; e += nt) Ysol[e] = make_double2(0.0, 0.0);
+    for (int e = tid; e < eend; e += nt) Ysol[e] = make_double2(0.0, 0.0);
     int its = 0, napp = 0;
     double ttol = 0.0;
     for (int cycle = 0;; cycle++) {
       // residual: b on the first cycle, b - (I - alpha M) y afterwards (left in Wv by the restart code below)
       const double2* r = cycle == 0 ? Bv : Wv;
       double t1[1] = {0.0};
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 v = r[e];
         t1[0] += v.x * v.x + v.y * v.y;
       }
@@ -298,7 +380,7 @@ struct BigTeam {
       const double beta = t1[0] * ibeta;
       if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
       if (beta <= ttol || its >= A.maxiter) break;
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 v = r[e];
         Vg[e] = make_double2(v.x * ibeta, v.y * ibeta);
       }
@@ -312,7 +394,7 @@ struct BigTeam {
         const double2* z = vj;
         for (int i = 1; i < poly; i++) {
           double2* dst = ((poly - 1 - i) & 1) ? scratch : Zg + (size_t)jj * dim;
-          for (int e = tid; e < dim; e += nt) {
+          for (int e = tid; e < eend; e += nt) {
             const double2 t = apply<TRANS>(A.S, c, z, e);
             const double2 v = vj[e];
             dst[e] = make_double2(fma(alpha, t.x, v.x), fma(alpha, t.y, v.y));
@@ -321,7 +403,7 @@ struct BigTeam {
           tsync();
           z = dst;
         }
-        for (int e = tid; e < dim; e += nt) {  // w = (I - alpha M) z
+        for (int e = tid; e < eend; e += nt) {  // w = (I - alpha M) z
           const double2 t = apply<TRANS>(A.S, c, z, e);
           const double2 v = z[e];
           Wv[e] = make_double2(v.x - alpha * t.x, v.y - alpha * t.y);
@@ -330,7 +412,7 @@ struct BigTeam {
         for (int k0 = 0; k0 <= jj; k0 += 4) {  // classical Gram-Schmidt, four projections per pass and reduction
           double h4[4] = {0.0, 0.0, 0.0, 0.0};
           const int nk = min(4, jj + 1 - k0);
-          for (int e = tid; e < dim; e += nt) {
+          for (int e = tid; e < eend; e += nt) {
             const double2 w = Wv[e];
             for (int q = 0; q < nk; q++) {
               const double2 vk = Vg[(size_t)(k0 + q) * dim + e];
@@ -341,7 +423,7 @@ struct BigTeam {
           for (int q = 0; q < nk; q++) hc[k0 + q] = h4[q];
         }
         double nn[1] = {0.0};
-        for (int e = tid; e < dim; e += nt) {
+        for (int e = tid; e < eend; e += nt) {
           double2 w = Wv[e];
           for (int k = 0; k <= jj; k++) {
             const double h = hc[k];
@@ -376,7 +458,7 @@ struct BigTeam {
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
         if (its >= A.maxiter || jj >= MRE) break;
         // the next basis vector is only formed and stored when another iteration follows
-        for (int e = tid; e < dim; e += nt) {
+        for (int e = tid; e < eend; e += nt) {
           const double2 w = Wv[e];
           Vg[(size_t)jj * dim + e] = make_double2(w.x * ihn, w.y * ihn);
         }
@@ -387,7 +469,7 @@ struct BigTeam {
         for (int cc = rw + 1; cc < jj; cc++) sacc -= Rm[rw * MR + cc] * yk[cc];
         yk[rw] = sacc * Rm[rw * MR + rw];
       }
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         double2 y = Ysol[e];
         for (int cc = 0; cc < jj; cc++) {
           const double f = yk[cc];
@@ -399,7 +481,7 @@ struct BigTeam {
       }
       tsync();
       if (conv || its >= A.maxiter) break;
-      for (int e = tid; e < dim; e += nt) {  // restart: r = b - (I - alpha M) y
+      for (int e = tid; e < eend; e += nt) {  // restart: r = b - (I - alpha M) y
         const double2 t = apply<TRANS>(A.S, c, Ysol, e);
         const double2 y = Ysol[e], b = Bv[e];
         Wv[e] = make_double2(b.x - (y.x - alpha * t.x), b.y - (y.y - alpha * t.y));
@@ -413,9 +495,9 @@ struct BigTeam {
 
   template <bool TRANS>
   __device__ __forceinline__ double2* solve(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
-                                            double2* Yb, int* iters) {
+                                            double2* Yb, int* iters, bool y0_ready = false, double nb2s = 0.0) {
     if (A.use_gmres) return gmres<TRANS>(A, c, alpha, Bv, Ya, Yb, iters);
-    return neumann<TRANS>(A, c, alpha, Bv, Ya, Yb, iters);
+    return neumann<TRANS>(A, c, alpha, Bv, Ya, Yb, iters, y0_ready, nb2s);
   }
 };
 
@@ -426,7 +508,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   const DevSys& S = A.S;
   TM tm;
   if (!tm.init(S, smem, A.nb)) return;
-  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
+  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid, eend = tm.gend;
   double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
   double2 *X = W, *B = W + dim, *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *XM1 = W + 4 * (size_t)dim, *XM2 = W + 5 * (size_t)dim;
   const bool pen_on = A.gamma_penalty > 1e-13;
@@ -436,7 +518,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   const bool jpairs = S.npairs > 0;
   {
     const double* x0 = A.x0 + (size_t)ic * 2 * dim;
-    for (int e = tid; e < dim; e += nt) {
+    for (int e = tid; e < eend; e += nt) {
       const double2 v = make_double2(x0[e], x0[dim + e]);
       X[e] = v;
       if (dpdm_on) XM1[e] = XM2[e] = v;
@@ -453,17 +535,30 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
     c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     if (A.traj) {
       double* dst = A.traj + ((size_t)s * A.nb + ic) * 2 * dim;
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 v = X[e];
         dst[e] = v.x;
         dst[dim + e] = v.y;
       }
     }
-    for (int e = tid; e < dim; e += nt) B[e] = tm.template apply<false>(S, c, X, e);  // rhs = M x
+    // rhs = M x; diagonal-split iteration: its first iterate (1 - h/2 D)^-1 rhs (and |rhs|^2 for the residual rule) from the same loop
+    const bool y0 = !A.stepper_ee && !A.use_gmres && tm.split_on(A);
+    double nb2[1] = {0.0};
+    if (y0) {
+      for (int e = tid; e < eend; e += nt) {
+        const double2 b = tm.template apply<false>(S, c, X, e);
+        B[e] = b;
+        Yb[e] = tm.template split_y0<false>(0.5 * c.h, b);
+        nb2[0] = fma(b.x, b.x, fma(b.y, b.y, nb2[0]));
+      }
+    } else {
+      for (int e = tid; e < eend; e += nt) B[e] = tm.template apply<false>(S, c, X, e);
+    }
     napply++;
-    tm.tsync();
+    if (y0 && A.stop_residual) tm.template sum<1>(nb2);  // (contains the team barrier)
+    else tm.tsync();
     if (A.stepper_ee) {
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 r = B[e];
         double2 v = X[e];
         v.x = fma(c.h, r.x, v.x);
@@ -472,10 +567,10 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       }
     } else {
       int its;
-      const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its);
+      const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its, y0, nb2[0]);
       napply += its;
       double* zdst = A.ztraj ? A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim : nullptr;
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 k = K[e];
         double2 v = X[e];
         if (zdst) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
@@ -500,11 +595,11 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
         }
         if (wj_reduce) {
           double v[2] = {0.0, 0.0};
-          for (int e = tid; e < dim; e += nt) evalJ_part<LIND>(S, A.tg, ic, e, X[e], v[0], v[1]);
+          for (int e = tid; e < eend; e += nt) evalJ_part<LIND>(S, A.tg, ic, e, X[e], v[0], v[1]);
           tm.template sum<2>(v);
           pen_uniform += weight * finalizeJ<LIND>(A.tg, v[0], v[1]) * A.dt;
         } else if (wj_on) {
-          for (int e = tid; e < dim; e += nt) {
+          for (int e = tid; e < eend; e += nt) {
             double jr = 0.0, ji = 0.0;
             evalJ_part<LIND>(S, A.tg, ic, e, X[e], jr, ji);
             pen_local += (A.tg.objective_type == QD_OBJ_JTRACE ? -1.0 : 1.0) * weight * A.dt * jr;
@@ -512,7 +607,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
           if (A.tg.objective_type == QD_OBJ_JTRACE) pen_uniform += weight * A.dt;
         }
         if (A.leak_on) {
-          for (int e = tid; e < dim; e += nt) {
+          for (int e = tid; e < eend; e += nt) {
             tm.at(e);
             if (tm.st.is_guard(S, 0)) {
               const double2 v = X[e];
@@ -522,7 +617,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
         }
       }
       if (dpdm_on) {
-        for (int e = tid; e < dim; e += nt) {
+        for (int e = tid; e < eend; e += nt) {
           const double2 v = X[e], m1 = XM1[e], m2 = XM2[e];
           if (n > 0) {
             const double t1 = v.x * v.x - 2.0 * m1.x * m1.x + m2.x * m2.x;
@@ -538,7 +633,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   {
     double* xT = A.xT + (size_t)ic * 2 * dim;
     double* dst = A.traj ? A.traj + ((size_t)A.nsub * A.nb + ic) * 2 * dim : nullptr;
-    for (int e = tid; e < dim; e += nt) {
+    for (int e = tid; e < eend; e += nt) {
       const double2 v = X[e];
       xT[e] = v.x;
       xT[dim + e] = v.y;
@@ -564,7 +659,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   const DevSys& S = A.S;
   TM tm;
   if (!tm.init(S, smem, A.nb)) return;
-  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
+  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid, eend = tm.gend;
   double2* W = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
   double2 *Ya = W + 2 * (size_t)dim, *Yb = W + 3 * (size_t)dim, *Z = W + 6 * (size_t)dim, *KB = W + 7 * (size_t)dim, *XB = W + 8 * (size_t)dim;
   const double* traj = A.traj;
@@ -574,7 +669,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   };
   {
     const double* xbT = A.xbarT + (size_t)ic * 2 * dim;
-    for (int e = tid; e < dim; e += nt) XB[e] = make_double2(xbT[e], xbT[dim + e]);
+    for (int e = tid; e < eend; e += nt) XB[e] = make_double2(xbT[e], xbT[dim + e]);
   }
   const double jbar_pen = A.jbar[ic * 3 + 0], jbar_dpdm = A.jbar[ic * 3 + 1];
   const bool pen_on = A.gamma_penalty > 1e-13;
@@ -590,7 +685,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     // stepper and a negative step (src/timestepper.cpp:229-231 with ExplEuler::evolveFWD :496-507), and its gradient is defined on
     // that chain - reproduce it by overwriting the stored trajectory (k_adjoint of qd_device.h does the same in registers).
     double* trajw = const_cast<double*>(traj);
-    for (int e = tid; e < dim; e += nt) Ya[e] = state(A.nsub, e);
+    for (int e = tid; e < eend; e += nt) Ya[e] = state(A.nsub, e);
     tm.tsync();
     for (int s = A.nsub - 1; s >= 0; s--) {
       StepC<Q> c1;
@@ -598,10 +693,10 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
       scalarize<Q>(c1, jpairs);
       c1.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
       const double hneg = -to_scalar(A.ctl[(size_t)s * A.cs]);
-      for (int e = tid; e < dim; e += nt) KB[e] = tm.template apply<false>(S, c1, Ya, e);
+      for (int e = tid; e < eend; e += nt) KB[e] = tm.template apply<false>(S, c1, Ya, e);
       tm.tsync();
       double* dst = trajw + ((size_t)s * A.nb + ic) * 2 * dim;
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 t = KB[e];
         double2 v = Ya[e];
         v.x = fma(hneg, t.x, v.x);
@@ -624,14 +719,14 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
         weight = 1.0 / A.penalty_param * exp(-(a * a));
         if (wj_reduce) {
           double v[2] = {0.0, 0.0};
-          for (int e = tid; e < dim; e += nt) evalJ_part<LIND>(S, A.tg, ic, e, state(s + 1, e), v[0], v[1]);
+          for (int e = tid; e < eend; e += nt) evalJ_part<LIND>(S, A.tg, ic, e, state(s + 1, e), v[0], v[1]);
           tm.template sum<2>(v);
           finalizeJ_diff<LIND>(A.tg, v[0], v[1], rb, ib);
         } else {
           finalizeJ_diff<LIND>(A.tg, 0.0, 0.0, rb, ib);
         }
       }
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 xn = state(s + 1, e);
         double2 xb = XB[e];
         if (dpdm_on) {  // penaltyDpDm_diff (timestepper.cpp:372-442)
@@ -670,9 +765,9 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     if (A.stepper_ee) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt x_adj against x_{n-1}, then x_adj += dt M(tstop)^T x_adj;
       // M(tstop) is table row s + 1 (the last row is followed by one extra row for t = T)
-      for (int e = tid; e < dim; e += nt) Z[e] = state(s, e);
+      for (int e = tid; e < eend; e += nt) Z[e] = state(s, e);
       tm.tsync();
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         tm.at(e);
         const double2 xb = XB[e];
 #pragma unroll
@@ -694,9 +789,9 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
       load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
       scalarize<Q>(c1, jpairs);
       c1.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
-      for (int e = tid; e < dim; e += nt) KB[e] = tm.template apply<true>(S, c1, XB, e);
+      for (int e = tid; e < eend; e += nt) KB[e] = tm.template apply<true>(S, c1, XB, e);
       tm.tsync();
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 t = KB[e];
         double2 xb = XB[e];
         xb.x = fma(c.h, t.x, xb.x);
@@ -709,18 +804,18 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z = x + h/2 k (:640-652) was stored by the forward sweep
     {
       const double* zsrc = A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim;
-      for (int e = tid; e < dim; e += nt) Z[e] = make_double2(zsrc[e], zsrc[dim + e]);
+      for (int e = tid; e < eend; e += nt) Z[e] = make_double2(zsrc[e], zsrc[dim + e]);
     }
     int its;
     {
       const double2* K = tm.template solve<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
-      for (int e = tid; e < dim; e += nt) {
+      for (int e = tid; e < eend; e += nt) {
         const double2 k = K[e];
         KB[e] = make_double2(c.h * k.x, c.h * k.y);
       }
     }
     tm.tsync();
-    for (int e = tid; e < dim; e += nt) {  // gradient coefficients (mastereq.hpp:553-604) and xbar += M^T kbar
+    for (int e = tid; e < eend; e += nt) {  // gradient coefficients (mastereq.hpp:553-604) and xbar += M^T kbar
       tm.at(e);
       const double2 kb = KB[e];
 #pragma unroll
@@ -730,7 +825,9 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
         cf[2 * k] += Bv.y * kb.x - Bv.x * kb.y;
         cf[2 * k + 1] += Av.x * kb.x + Av.y * kb.y;
       }
-      const double2 t = tm.st.template apply<true>(S, tm.L, KB, c, 0, kb);
+      double2 t;
+      if constexpr (DENSE || !BigTeam<Q, LIND, DENSE>::kBatch) t = tm.st.template apply<true>(S, tm.L, KB, c, 0, kb);
+      else t = tm.st.template apply_batched<true>(S, tm.L, KB, c, 0, kb);
       double2 xb = XB[e];
       xb.x += t.x;
       xb.y += t.y;
@@ -747,7 +844,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   }
   if (A.xbar0) {
     double* d0 = A.xbar0 + (size_t)ic * 2 * dim;
-    for (int e = tid; e < dim; e += nt) {
+    for (int e = tid; e < eend; e += nt) {
       const double2 v = XB[e];
       d0[e] = v.x;
       d0[dim + e] = v.y;
@@ -761,17 +858,17 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_apply_big(const DevSys S, const d
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   BigTeam<Q, LIND, DENSE> tm;
   if (!tm.init(S, smem, nb)) return;
-  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid;
+  const int dim = S.dim, ic = tm.ic, nt = tm.gnt, tid = tm.gtid, eend = tm.gend;
   double2* X = reinterpret_cast<double2*>(S.work) + (size_t)ic * BIG_NV * dim;
   const double* x0 = xin + (size_t)ic * 2 * dim;
-  for (int e = tid; e < dim; e += nt) X[e] = make_double2(x0[e], x0[dim + e]);
+  for (int e = tid; e < eend; e += nt) X[e] = make_double2(x0[e], x0[dim + e]);
   tm.tsync();
   StepC<Q> c;
   load_step<Q>(ctlrow, c, S.npairs > 0);
   scalarize<Q>(c, S.npairs > 0);
   c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) : nullptr;  // one-row table of the test hook
   double* yo = yout + (size_t)ic * 2 * dim;
-  for (int e = tid; e < dim; e += nt) {
+  for (int e = tid; e < eend; e += nt) {
     const double2 y = transpose ? tm.template apply<true>(S, c, X, e) : tm.template apply<false>(S, c, X, e);
     yo[e] = y.x;
     yo[dim + e] = y.y;

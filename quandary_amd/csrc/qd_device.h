@@ -605,6 +605,118 @@ struct GenStencil {
     return make_double2(yr, yi);
   }
 
+  // The same operator for vectors in GLOBAL memory (qd_big.h): the neighbours of the element are requested in batches of eight to ten
+  // before any arithmetic on them - the ladder (and T1) neighbours of two (Lindblad) or all oscillators, the dipole-dipole neighbours of
+  // two (Lindblad) or four pairs; scheduling barriers keep the batches apart (all of them at once does not fit 128 registers) - because a round trip to L2 costs 5-10 x an LDS access and the four waves per SIMD of those kernels cannot hide one per oscillator
+  // and per coupling pair (apply() above: ten dependent round trips per element on the reference's nlevels_32_32_32_32 case).  No
+  // branches on zero coefficients: a zero coefficient multiplies a clamped, valid read.
+  template <bool TRANS>
+  __device__ __forceinline__ double2 apply_batched(const DevSys& S, const Lds& L, const double2* __restrict__ sx, const StepC<Q>& c, int j,
+                                                   const double2 xs) const {
+    const int i0 = opaque(it[j]), top = S.dim - 1;
+    const unsigned db = opaque(dbra[j]), dk = opaque(dket[j]);
+    double hr = dw[j] * xs.y, hi = -dw[j] * xs.x;
+    double l1r = 0.0, l1i = 0.0;
+    constexpr int KC = LIND ? 2 : Q;  // oscillators per batch: at most ten reads in flight
+#pragma unroll
+    for (int k0 = 0; k0 < Q; k0 += KC) {
+      double2 xu[KC], xd[KC], xup[KC], xdp[KC], xl[KC];
+#pragma unroll
+      for (int u = 0; u < KC; u++) {
+        if (k0 + u >= Q) break;
+        const int st = S.post[k0 + u];
+        xu[u] = sx[min(i0 + st, top)];
+        xd[u] = sx[max(i0 - st, 0)];
+        if (LIND) {
+          const int stp = S.N * st;
+          xup[u] = sx[min(i0 + stp, top)];
+          xdp[u] = sx[max(i0 - stp, 0)];
+          xl[u] = sx[TRANS ? max(i0 - st - stp, 0) : min(i0 + st + stp, top)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KC; u++) {
+        if (k0 + u >= Q) break;
+        const int k = k0 + u, a = dig(db, k);
+        const double su = L.tup[ofs[k] + a], sd = L.tdn[ofs[k] + a];
+        double er = su * xu[u].x, ei = su * xu[u].y;
+        double fr = -sd * xd[u].x, fi = -sd * xd[u].y;
+        if (LIND) {
+          const int ap = dig(dk, k);
+          const double sup = L.tup[ofs[k] + ap], sdp = L.tdn[ofs[k] + ap];
+          er = fma(-sdp, xdp[u].x, er);
+          ei = fma(-sdp, xdp[u].y, ei);
+          fr = fma(sup, xup[u].x, fr);
+          fi = fma(sup, xup[u].y, fi);
+          const double l1 = S.g1off[k] * (TRANS ? sd * sdp : su * sup);
+          l1r = fma(l1, xl[u].x, l1r);
+          l1i = fma(l1, xl[u].y, l1i);
+        }
+        hr = fma(c.q[k], er + fr, fma(c.p[k], ei - fi, hr));
+        hi = fma(c.q[k], ei + fi, fma(-c.p[k], er - fr, hi));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (S.hasJ) {
+      constexpr int NP = Q * (Q - 1) / 2 > 0 ? Q * (Q - 1) / 2 : 1, CH = LIND ? 2 : 4;  // pairs per batch: eight reads
+      int pk[NP], pl[NP];
+      {
+        int pair = 0;
+#pragma unroll
+        for (int k = 0; k < Q; k++)
+#pragma unroll
+          for (int l = k + 1; l < Q; l++, pair++) {
+            pk[pair] = k;
+            pl[pair] = l;
+          }
+      }
+#pragma unroll
+      for (int p0 = 0; p0 < Q * (Q - 1) / 2; p0 += CH) {
+        double2 x1[CH], x2[CH], x3[CH], x4[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+          if (p0 + u >= Q * (Q - 1) / 2) break;
+          const int sk = S.post[pk[p0 + u]], sl = S.post[pl[p0 + u]];
+          x1[u] = sx[min(max(i0 - sk + sl, 0), top)];
+          x2[u] = sx[min(max(i0 + sk - sl, 0), top)];
+          if (LIND) {
+            const int skp = S.N * sk, slp = S.N * sl;
+            x3[u] = sx[min(max(i0 - skp + slp, 0), top)];
+            x4[u] = sx[min(max(i0 + skp - slp, 0), top)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+          if (p0 + u >= Q * (Q - 1) / 2) break;
+          const int pair = p0 + u, k = pk[pair], l = pl[pair];
+          const double Jkl = S.J[pair];
+          const int a = dig(db, k), b = dig(db, l);
+          const double s1 = L.tdn[ofs[k] + a] * L.tup[ofs[l] + b], s2 = L.tdn[ofs[l] + b] * L.tup[ofs[k] + a];
+          double ar = s1 * x1[u].x - s2 * x2[u].x, ai = s1 * x1[u].y - s2 * x2[u].y;  // T1 - T2
+          double br = s1 * x1[u].x + s2 * x2[u].x, bi = s1 * x1[u].y + s2 * x2[u].y;  // T1 + T2
+          if (LIND) {
+            const int ap = dig(dk, k), bp = dig(dk, l);
+            const double s3 = L.tdn[ofs[k] + ap] * L.tup[ofs[l] + bp], s4 = L.tdn[ofs[l] + bp] * L.tup[ofs[k] + ap];
+            ar += s3 * x3[u].x - s4 * x4[u].x;
+            ai += s3 * x3[u].y - s4 * x4[u].y;
+            br -= s3 * x3[u].x + s4 * x4[u].x;
+            bi -= s3 * x3[u].y + s4 * x4[u].y;
+          }
+          const double co = c.cs[pair], si = c.sn[pair];
+          hr += Jkl * (si * ar + co * bi);
+          hi += Jkl * (si * ai - co * br);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    double yr = TRANS ? -hr : hr, yi = TRANS ? -hi : hi;
+    if (LIND) {
+      yr = fma(dd[j], xs.x, yr) + l1r;
+      yi = fma(dd[j], xs.y, yi) + l1i;
+    }
+    return make_double2(yr, yi);
+  }
+
   // isGuardLevel (util.cpp:259-278) for a diagonal element
   __device__ __forceinline__ bool is_guard(const DevSys& S, int j) const {
     if (!valid[j]) return false;

@@ -660,8 +660,10 @@ bool qd_handle::use_col(const qd::LaunchCfg& cfg) const {
 // ||b - (I - alpha M) y_m|| = ||(1 - alpha D)(y_{m+1} - y_m)|| <= kappa ||y_{m+1} - y_m||.  Same linear system, same tolerance, hence
 // results that agree with GMRES at solver-tolerance level; the option gmres_split = 0 keeps the Krylov kernels.
 bool qd_handle::gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const {
-  if (precision != QD_PRECISION_F64 || cfg.var != 9 || !cfg.gmres || !collean_available(S, opts) || sol.stepper == QD_STEPPER_EE ||
-      opts.gmres_split == 0)
+  // ... and on the states beyond LDS (qd_big.h), where the Krylov basis streams through HBM (the reference's nlevels_32_32_32_32 case:
+  // 12 vectors of 16 MB per initial condition) and the level energies of high levels dominate the row
+  const bool col_ok = cfg.var == 9 && collean_available(S, opts), big_ok = cfg.var == 16 && !S.dense;
+  if (precision != QD_PRECISION_F64 || !(col_ok || big_ok) || !cfg.gmres || sol.stepper == QD_STEPPER_EE || opts.gmres_split == 0)
     return false;
   double dg, of;
   row_bounds(&dg, &of);

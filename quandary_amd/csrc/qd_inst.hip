@@ -54,7 +54,7 @@ static hipError_t set_lds(K kern, size_t bytes) {
 [[maybe_unused]] static hipError_t launch_big(const void* kern, const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   SweepArgs b = a;
   b.S.team = cfg.team > 1 ? cfg.team : 1;
-  b.S.team_spread = cfg.spread;
+  b.S.team_spread = (cfg.spread ? 1 : 0) | (cfg.blocked == 1 ? 2 : cfg.blocked == 2 ? 4 : 0);
   void* args[] = {&b};
   if (b.S.team == 1) return hipLaunchKernel(kern, dim3(a.nb), dim3(cfg.block), args, cfg.lds, st);
   hipError_t e = hipMemsetAsync(b.S.tbar, 0, sizeof(unsigned long long) * BIG_BAR_STRIDE * (size_t)a.nb, st);

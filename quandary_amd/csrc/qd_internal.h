@@ -122,6 +122,7 @@ struct TuneOpts {
   int no_mfma = 0;         // "no_mfma": dense operator on the vector kernels
   int big_team = 0;        // "big_team": workgroups per initial condition of the global-memory sweeps (0 = automatic)
   int big_spread = -1;     // "big_spread": team members dealt over all XCDs (1), kept on one (0), default (-1)
+  int big_blocked = 2;     // "big_blocked": a team member owns a contiguous block of the state (1; 2: the members of an XCD own neighbouring blocks) or every 'team'th row of 1024 elements (0)
   int f32_sb = -1;         // "f32_sb": slot bits of the fp32-mixed 2^4 kernel
   int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
@@ -143,6 +144,7 @@ struct LaunchCfg {
   int gmres;  // 0 Neumann, 1 GMRES with the Krylov basis in LDS, 2 GMRES with the basis in global memory
   int team;   // workgroups per initial condition (qd_big.h; 1 everywhere else)
   int spread; // team members dealt over all XCDs instead of one
+  int blocked; // team members own contiguous blocks of the state
   size_t lds;
 };
 

@@ -1060,15 +1060,16 @@ TEAM_CASES = [
 
 
 @pytest.mark.parametrize("kw", TEAM_CASES)
-@pytest.mark.parametrize("team,spread", [(2, 0), (8, 0), (32, 0), (4, 1), (64, 1)])
+@pytest.mark.parametrize("team,spread,blocked", [(2, 0, 1), (8, 0, 0), (32, 0, 1), (4, 1, 2), (64, 1, 2), (64, 1, 0), (16, 1, 1)])
 @pytest.mark.parametrize("stepper,linsolve", [("IMR", "neumann"), ("IMR4", "gmres")])
-def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper, linsolve, monkeypatch):
+def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, blocked, stepper, linsolve, monkeypatch):
     """Several workgroups per initial condition (qd_big.h: team barriers and team reductions through global memory, members on one
     XCD or dealt over all of them), forced onto small systems so that every penalty, guard levels, couplings and both solvers run
-    through the team path; compared with the oracle like every other kernel."""
+    through the team path, with the three element-to-member maps (big_blocked); compared with the oracle like every other kernel."""
     monkeypatch.setenv("QD_VAR", "16")
     monkeypatch.setenv("QD_BIG_TEAM", str(team))
     monkeypatch.setenv("QD_BIG_SPREAD", str(spread))
+    monkeypatch.setenv("QD_BIG_BLOCKED", str(blocked))
     sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
     opt = capi.Optim(h, sp)
     nb = opt.ninit
@@ -1092,6 +1093,35 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, stepper,
     assert h.last_team == 1
     assert val1["objective"] == pytest.approx(val["objective"], rel=1e-11)
     assert np.linalg.norm(g - g1) / np.linalg.norm(g1) < 1e-9
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", TEAM_CASES + [BIG_SHAPES[0], BIG_SHAPES[3]])
+@pytest.mark.parametrize("stepper,linsolve", [("IMR", "neumann"), ("IMR4", "gmres")])
+def test_diagonal_split_iteration_of_the_global_memory_kernels(kw, stepper, linsolve):
+    """qd_big.h's stationary iteration with the diagonal of M on the left-hand side (options neumann_split / gmres_split = 1): as the
+    Neumann solver (same fixed point, same stopping rule) and in place of GMRES (stop on the exact residual norm, KSP's rule) - forward
+    and adjoint sweeps against the oracle's solver of that name, on small systems forced onto these kernels in teams of four and on two
+    states beyond LDS; where the level energies dominate it needs no more applications than the oracle."""
+    big = np.prod(kw["nlevels"]) ** (2 if kw.get("lindblad", True) else 1) > 4096
+    sp = synthetic_spec(**{**kw, "ntime": 4 if big else 12, "nspline": 5 if big else 10, "penalties": True, "stepper": stepper,
+                           "linsolve": linsolve, "dt": 0.05 if linsolve == "gmres" and not big else 0.01})
+    sp.options = {"neumann_split": "1", "gmres_split": "1"} if big else {"var": "16", "big_team": "4", "neumann_split": "1", "gmres_split": "1"}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    if not big:
+        assert h.last_team == 4  # (the global-memory kernels are the only ones that run in teams)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    # the same sweeps with the plain iteration / the Krylov kernel
+    h.set_option("neumann_split", "0")
+    h.set_option("gmres_split", "0")
+    val0, g0 = opt.evalGradF(sp.params0)
+    assert val0["objective"] == pytest.approx(val["objective"], rel=REF_RTOL)
+    assert np.linalg.norm(g - g0) <= 1e-8 * np.linalg.norm(g0) + SOLVER_NOISE_ABS
     opt.close(); h.close(); orc.close()
 
 
