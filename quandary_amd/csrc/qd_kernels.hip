@@ -155,19 +155,30 @@ __global__ void k_controls(const DevCtlDesc d, const double* __restrict__ params
 // ---------------------------------------------------------------------------------------------
 // final-time objective and adjoint seed (one block per initial condition, runtime Q)
 // ---------------------------------------------------------------------------------------------
+// grid (nb, P): P > 1 (one large state, launch_objective) - every block writes its share to part[b][p][4], k_objective_sum adds the
+// shares in a fixed order
 template <bool LIND>
-__global__ void k_objective(const DevSys S, const DevTarget tg, const double* __restrict__ x, double* __restrict__ out4) {
+__global__ void k_objective(const DevSys S, const DevTarget tg, const double* __restrict__ x, double* __restrict__ out4, double* __restrict__ part) {
   __shared__ double red[4 * 16];
-  const int b = blockIdx.x, dim = S.dim;
+  const int b = blockIdx.x, dim = S.dim, P = gridDim.y;
   const double* xs = x + (size_t)b * 2 * dim;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int it = threadIdx.x; it < dim; it += blockDim.x) {
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < dim; it += blockDim.x * P) {
     const double2 xv = make_double2(xs[it], xs[dim + it]);
     evalJ_part<LIND>(S, tg, b, it, xv, v[0], v[1]);
     fidelity_part<LIND>(S, tg, b, it, xv, v[2], v[3]);
   }
   block_sum<4, false>(v, red);
-  if (threadIdx.x < 4) out4[b * 4 + threadIdx.x] = v[threadIdx.x];
+  if (threadIdx.x < 4) (P > 1 ? part + ((size_t)b * P + blockIdx.y) * 4 : out4 + (size_t)b * 4)[threadIdx.x] = v[threadIdx.x];
+}
+
+__global__ void k_objective_sum(const double* __restrict__ part, int P, double* __restrict__ out4) {
+  const int b = blockIdx.x;
+  if (threadIdx.x < 4) {
+    double s = 0.0;
+    for (int p = 0; p < P; p++) s += part[((size_t)b * P + p) * 4 + threadIdx.x];
+    out4[(size_t)b * 4 + threadIdx.x] = s;
+  }
 }
 
 template <bool LIND>
@@ -177,7 +188,7 @@ __global__ void k_seed(const DevSys S, const DevTarget tg, const double* __restr
   const double* xs = x + (size_t)b * 2 * dim;
   double* xo = xbar + (size_t)b * 2 * dim;
   const double rbar = rbib[2 * b], ibar = rbib[2 * b + 1];
-  for (int it = threadIdx.x; it < dim; it += blockDim.x) {
+  for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < dim; it += blockDim.x * gridDim.y) {
     double2 xb = make_double2(0.0, 0.0);
     evalJ_diff_elem<LIND>(S, tg, b, it, make_double2(xs[it], xs[dim + it]), xb, rbar, ibar);
     xo[it] = xb.x;
@@ -527,7 +538,9 @@ void big_team(const DevSys& S, int nb, const TuneOpts& o, int& team, int& spread
   while (g * 2 <= 64 && g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)2 * S.dim >= (size_t)BIG_BLOCK * (g * 2)) g *= 2;
   // very large states (the reference's nlevels_32_32_32_32: dim 2^20): beyond 64 members while every thread keeps at least four
   // elements - measured on that case (GMRES, 50 steps): 64 members 118 ms, 128: 75 ms, 256: 65 ms (20 x 20, dim 160 000: 11.3 / 11.3 / 12.1)
-  while (g >= 64 && g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)S.dim >= (size_t)4 * BIG_BLOCK * (g * 2)) g *= 2;
+  // ... and 128 members from one element per thread on: 20 x 20 Lindblad with batched neighbour reads, 100 steps: 64 members 9.4 ms forward /
+  // 27.4 ms gradient, 128: 9.1 / 25.0, 256: 11.6 / 29.7
+  while (g >= 64 && g * 2 <= gmax && (long)slots * (g * 2) <= ncu && (size_t)S.dim >= (size_t)(g == 64 ? 1 : 4) * BIG_BLOCK * (g * 2)) g *= 2;
   if (S.dim <= 4096) g = 1;  // (the global-memory kernels forced onto a small system)
   if (o.big_team > 0) {
     const int v = o.big_team;
@@ -664,16 +677,28 @@ hipError_t launch_gmat(const DevSys& S, const double* g0, const double* table, i
   return hipGetLastError();
 }
 
+// blocks per initial condition of the objective / seed kernels: one, except for a few large states (the team reduction buffer of
+// qd_big.h, idle between the sweeps, takes the shares: [nb][P][4] <= [nb][2][BIG_TEAM_MAX][BIG_RED_NV])
+static int objective_blocks(const DevSys& S, int nb) {
+  if (S.dim < (1 << 16) || !S.tred) return 1;
+  int p = 1;
+  while (p < 128 && (long)nb * p * 2 <= 1024 && (long)S.dim >= (long)4096 * p) p *= 2;
+  return p;
+}
+
 hipError_t launch_objective(const DevSys& S, const DevTarget& tg, const double* x, int nb, double* out4, hipStream_t st) {
-  if (S.lindblad) hipLaunchKernelGGL(k_objective<true>, dim3(nb), dim3(256), 0, st, S, tg, x, out4);
-  else hipLaunchKernelGGL(k_objective<false>, dim3(nb), dim3(256), 0, st, S, tg, x, out4);
+  const int P = objective_blocks(S, nb);
+  if (S.lindblad) hipLaunchKernelGGL(k_objective<true>, dim3(nb, P), dim3(256), 0, st, S, tg, x, out4, S.tred);
+  else hipLaunchKernelGGL(k_objective<false>, dim3(nb, P), dim3(256), 0, st, S, tg, x, out4, S.tred);
+  if (P > 1) hipLaunchKernelGGL(k_objective_sum, dim3(nb), dim3(64), 0, st, S.tred, P, out4);
   return hipGetLastError();
 }
 
 hipError_t launch_seed(const DevSys& S, const DevTarget& tg, const double* x, const double* rbar_ibar, int nb, double* xbar,
                        hipStream_t st) {
-  if (S.lindblad) hipLaunchKernelGGL(k_seed<true>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
-  else hipLaunchKernelGGL(k_seed<false>, dim3(nb), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
+  const int P = objective_blocks(S, nb);
+  if (S.lindblad) hipLaunchKernelGGL(k_seed<true>, dim3(nb, P), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
+  else hipLaunchKernelGGL(k_seed<false>, dim3(nb, P), dim3(256), 0, st, S, tg, x, rbar_ibar, xbar);
   return hipGetLastError();
 }
 

@@ -1144,9 +1144,9 @@ def test_reference_performance_workloads_vs_oracle(name, ntime, team):
 
 
 def test_team_size_follows_batch_and_dimension():
-    """The selection rule (big_team, qd_kernels.hip): at least half an element per thread, at most 64 members (256 for states of a
-    million elements, previous test), every team resident."""
-    for nl, init, want in (([10, 10], "pure, 0, 1", 16), ([9, 9], "pure, 0, 1", 8), ([10, 10], "basis, 0", 2)):
+    """The selection rule (big_team, qd_kernels.hip): at least half an element per thread up to 64 members, 128 from one element per thread on
+    (256 for states of a million elements, previous test), every team resident."""
+    for nl, init, want in (([10, 10], "pure, 0, 1", 16), ([9, 9], "pure, 0, 1", 8), ([10, 10], "basis, 0", 2), ([20, 20], "pure, 0, 1", 128)):
         sp = synthetic_spec(nl, lindblad=True, ntime=2, nspline=5, target="pure", objective="Jfrobenius", init=init)
         h = capi.Handle(sp)
         opt = capi.Optim(h, sp)
