@@ -568,8 +568,16 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     if (pen_on && (s + 1) % A.nstages == 0 && (wj_on || leak)) {
       const int n = (s + 1) / A.nstages;
       const double tstop = n * A.dt;
+      // (the weighted Jmeasure's adjoint is a constant per row: without guard levels this sweep never reads the states, and the
+      // forward sweep of a gradient evaluation has not stored them - qd_handle::adjoint_reads_states)
+      const bool need_xn = leak || (wj_on && A.tg.objective_type != QD_OBJ_JMEASURE);
       double2 xn[EPT];
-      load_state(A.traj, s + 1, xn);
+      if (need_xn) {
+        load_state(A.traj, s + 1, xn);
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) xn[j] = make_double2(0.0, 0.0);
+      }
       if (wj_on) {
         double weight;
         if (A.wjw) {

@@ -699,6 +699,26 @@ int qd_handle::neumann_split_on() const {
   return dg >= 0.25 * of ? 1 : 0;
 }
 
+// Does the adjoint sweep that follows a forward sweep of nb states read the stored states x_n (SweepArgs::traj), or only the primal
+// stages z?  States: explicit Euler (no stages), the dpdm penalty (second differences of x), the leakage penalty and the weighted-J
+// penalty (their adjoints are functions of x_n; on the lean column kernels the weighted Jmeasure's adjoint is a constant per row) -
+// and every kernel family whose adjoint kernel has not been written to do without (general / global-memory kernels).
+bool qd_handle::adjoint_reads_states(int nb, const qd::DevTarget* tgp) const {
+  if (sol.stepper == QD_STEPPER_EE || pen.gamma_penalty_dpdm > 1e-13) return true;
+  LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES);
+  if (gmres_as_split(cfg, nullptr)) cfg.gmres = 0;
+  else if (gmres_as_neumann(cfg)) cfg = pick_config(S, nb, opts, false);
+  const bool pen_on = pen.gamma_penalty > 1e-13;
+  const bool wj = pen_on && tgp && pen.penalty_param > 1e-13;
+  bool leak = false;
+  for (int k = 0; k < S.Q; k++)
+    if (pen_on && S.ness[k] < S.n[k]) leak = true;
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts);
+  if (precision == QD_PRECISION_F32MIXED || lean64) return wj || leak;
+  if (use_col(cfg)) return (wj && tgp->objective_type != QD_OBJ_JMEASURE) || leak;
+  return true;
+}
+
 // weights of the weighted-J penalty, tabulated per time step (constants of the handle: time grid, Tfinal, optim_penalty_param)
 int qd_handle::ensure_wj_weights() {
   if (!(pen.gamma_penalty > 1e-13 && pen.penalty_param > 1e-13)) return QD_OK;
@@ -766,10 +786,11 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   napply_zeroed = false;
   if ((r = refresh_tables())) return r;
   traj_valid = false;
+  const bool full = store && stores_full(nb, tgp);
   if (store) {
     size_t nt;
     traj_doubles(nb, &nt);
-    if ((r = d_traj.ensure(nt))) return r;
+    if (full && (r = d_traj.ensure(nt))) return r;
     if (ztraj_doubles(nb) && (r = d_ztraj.ensure(ztraj_doubles(nb)))) return r;
   }
   {
@@ -782,7 +803,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   last_poly = a.gmres_poly;
   a.x0 = dx0;
   a.xT = d_xT.p;
-  a.traj = store ? d_traj.p : nullptr;
+  a.traj = full ? d_traj.p : nullptr;
   a.ztraj = store && ztraj_doubles(nb) ? d_ztraj.p : nullptr;
   a.pen_out = d_pen;
   a.dpdm_out = d_dpdm;
@@ -824,6 +845,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   QD_HIP(hipMemcpyAsync(h_res.p, d_res.p, sizeof(double) * (6 * (size_t)nb + 1), hipMemcpyDeviceToHost, stream));
   last_nb = nb;
   pending_store = store;
+  pending_full = full;
   return QD_OK;
 }
 
@@ -866,7 +888,9 @@ int qd_handle::forward_finish(double* energy) {
   }
   last_nb = nb;
   traj_valid = store;
+  traj_full = store && pending_full;
   pending_store = false;
+  pending_full = false;
   if (energy) *energy = energy_penalty_host();
   return QD_OK;
 }
@@ -901,7 +925,7 @@ extern "C" int qd_forward(qd_handle* h, const double* x0, int nb, int store_traj
 
 extern "C" int qd_get_state(qd_handle* h, int timestep, double* x) {
   if (!h || !x) return fail(QD_ERR_INVALID, "qd_get_state: null argument");
-  if (!h->traj_valid) return fail(QD_ERR_STATE, "qd_get_state: no stored trajectory (call qd_forward with store_trajectory=1)");
+  if (!h->traj_valid || !h->traj_full) return fail(QD_ERR_STATE, "qd_get_state: no stored trajectory (call qd_forward with store_trajectory=1)");
   if (timestep < 0 || timestep > h->tg.ntime) return fail(QD_ERR_INVALID, "qd_get_state: time step out of range");
   QD_HIP(qd::use_device(h->device));
   const size_t n = (size_t)h->last_nb * 2 * h->S.dim;
@@ -923,7 +947,7 @@ extern "C" int qd_get_state(qd_handle* h, int timestep, double* x) {
 extern "C" int qd_get_observables(qd_handle* h, int stride, double* expected, double* population, double* expected_composite,
                                   double* population_composite) {
   if (!h || stride < 1) return fail(QD_ERR_INVALID, "qd_get_observables: bad argument");
-  if (!h->traj_valid) return fail(QD_ERR_STATE, "qd_get_observables: no stored trajectory (forward sweep with store_trajectory=1 first)");
+  if (!h->traj_valid || !h->traj_full) return fail(QD_ERR_STATE, "qd_get_observables: no stored trajectory (forward sweep with store_trajectory=1 first)");
   QD_HIP(qd::use_device(h->device));
   const DevSys& S = h->S;
   const int nb = h->last_nb, nout = h->tg.ntime / stride + 1;
@@ -974,7 +998,10 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   last_poly = a.gmres_poly;
-  a.traj = d_traj.p;
+  const bool have_states = pending_store ? pending_full : traj_full;
+  if (!have_states && adjoint_reads_states(nb, tgp))
+    return fail(QD_ERR_STATE, "qd_adjoint: the forward sweep stored the primal stages only, this adjoint sweep needs the states");
+  a.traj = have_states ? d_traj.p : nullptr;
   a.ztraj = ztraj_doubles(nb) ? d_ztraj.p : nullptr;
   a.xbarT = dxbarT;
   a.jbar = djbar;

@@ -157,6 +157,13 @@ struct qd_handle {
   int adjoint_finish(bool accumulate);
   int gradient_launch(double ebar, double* dgrad);  // k_grad into a device buffer [ndesign]
   bool pending_store = false;
+  // Gradient evaluations of the objective level (qd_optim.cpp) set stages_only: the forward sweep then stores the primal stages z only
+  // (SweepArgs::ztraj) wherever the adjoint sweep of the same kernel family reads nothing else - half the store traffic and half the
+  // trajectory memory.  traj_full: d_traj holds the states x_n of the last stored sweep (qd_get_state, qd_get_observables, penalties
+  // with state-dependent adjoints, explicit Euler).
+  bool stages_only = false, traj_full = false, pending_full = false;
+  bool adjoint_reads_states(int nb, const qd::DevTarget* tg) const;
+  bool stores_full(int nb, const qd::DevTarget* tg) const { return !stages_only || adjoint_reads_states(nb, tg); }
   // adjoint sweep; dxbarT/djbar device pointers; coefficient sums accumulate into d_coeffsum
   int adjoint_dev(const double* dxbarT, const double* djbar, int nb, const qd::DevTarget* tg, bool accumulate);
   // gradient from d_coeffsum (+ energy term ebar); writes host grad[ndesign]

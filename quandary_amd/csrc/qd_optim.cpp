@@ -510,9 +510,10 @@ static double control_variation(const qd_handle* h, const double* alpha, double*
   return var;
 }
 
-static bool trajectory_fits(qd_handle* h, int nb) {
+static bool trajectory_fits(qd_handle* h, int nb, const DevTarget* tg) {
   size_t need;
   h->traj_doubles(nb, &need);
+  if (!h->stores_full(nb, tg)) need = 0;      // (a gradient evaluation whose adjoint sweep reads the stages only)
   const size_t needz = h->ztraj_doubles(nb);  // the stored primal stages travel with the trajectory
   need += needz;
   if (h->opts.traj_budget_mb > 0.0)  // test hook (option traj_budget_mb): pretend HBM is this small
@@ -523,6 +524,14 @@ static bool trajectory_fits(qd_handle* h, int nb) {
   const size_t avail = free_b + (h->d_traj.cap + h->d_ztraj.cap) * sizeof(double);
   return (double)need * sizeof(double) < 0.85 * (double)avail;
 }
+
+// forward sweeps inside this scope are followed by their adjoint sweep and by nothing else that reads the trajectory
+struct StagesScope {
+  qd_handle* h;
+  bool saved;
+  explicit StagesScope(qd_handle* hh) : h(hh), saved(hh->stages_only) { h->stages_only = true; }
+  ~StagesScope() { h->stages_only = saved; }
+};
 
 struct PenaltyScope {
   qd_handle* h;
@@ -546,7 +555,8 @@ extern "C" int qd_optim_forward_local(qd_optim* o, const double* alpha, int stor
   if ((r = qd_set_params(h, alpha, h->ndesign))) return r;
   o->last_alpha.assign(alpha, alpha + h->ndesign);
   const int nl = o->nlocal;
-  bool store = store_trajectory != 0 && trajectory_fits(h, nl);
+  PenaltyScope ps0(h, o->pen);
+  bool store = store_trajectory != 0 && trajectory_fits(h, nl, &o->tg);
   double energy = 0.0;
   {
     PenaltyScope ps(h, o->pen);  // the objective's penalty block, for this call only (operator-level calls keep theirs)
@@ -622,9 +632,10 @@ extern "C" int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const do
   } else {
     // The trajectory of the whole shard does not fit in HBM: redo the forward sweep chunk by chunk
     // with storage and reverse each chunk at once (the seeds only need the global sums).
+    StagesScope ss(h);
     int chunk = nl;
-    while (chunk > 1 && !trajectory_fits(h, chunk)) chunk = (chunk + 1) / 2;
-    if (!trajectory_fits(h, chunk)) return fail(QD_ERR_NOMEM, "qd_optim_adjoint_local: one trajectory does not fit in device memory");
+    while (chunk > 1 && !trajectory_fits(h, chunk, &o->tg)) chunk = (chunk + 1) / 2;
+    if (!trajectory_fits(h, chunk, &o->tg)) return fail(QD_ERR_NOMEM, "qd_optim_adjoint_local: one trajectory does not fit in device memory");
     bool first = true;
     for (int off = 0; off < nl; off += chunk) {
       const int nc = std::min(chunk, nl - off);
@@ -660,6 +671,7 @@ extern "C" int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective
   if (o->nranks != 1) return fail(QD_ERR_STATE, "qd_optim_evalGradF: single-rank wrapper; use the *_local entry points");
   double sums[QD_NSUMS];
   int r;
+  StagesScope ss(o->h);
   if ((r = qd_optim_forward_local(o, alpha, 1, sums))) return r;
   if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
   return qd_optim_adjoint_local(o, alpha, sums, grad);
@@ -733,12 +745,13 @@ extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* al
   qd_handle* h = o->h;
   QD_HIP(qd::use_device(h->device));
   PenaltyScope ps(h, o->pen);
+  StagesScope ss(h);
   const int nl = o->nlocal, nd = h->ndesign;
   int r;
   // Fused device path or host-staged fallback: the two issue DIFFERENT collectives, and trajectory_fits() looks at this rank's own free
   // memory - so the choice is made collectively (any rank that does not fit sends every rank down the fallback), once per objective.
   if (o->dist_fits < 0) {
-    double nofit = trajectory_fits(h, nl) ? 0.0 : 1.0;
+    double nofit = trajectory_fits(h, nl, &o->tg) ? 0.0 : 1.0;
     if (c->nranks > 1 && (r = qd_comm_allreduce(c, &nofit, 1, 1))) return r;
     o->dist_fits = nofit > 0.5 ? 0 : 1;
   }

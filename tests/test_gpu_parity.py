@@ -260,6 +260,44 @@ def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
     opt.close(); h.close(); orc.close()
 
 
+STAGE_ONLY_CASES = [
+    # (system, penalties, the gradient evaluation stores the primal stages only)
+    pytest.param(LEANCOL_SHAPES[0].values[0], False, True, id="3x20-no-penalty"),
+    pytest.param({**LEANCOL_SHAPES[0].values[0], "target": "pure", "objective": "Jmeasure", "init": "diagonal, 0, 1"}, "wj", True, id="3x20-weighted-Jmeasure"),
+    pytest.param({**LEANCOL_SHAPES[0].values[0], "target": "pure", "objective": "Jfrobenius", "init": "diagonal, 0"}, "wj", False, id="3x20-weighted-Jfrobenius"),
+    pytest.param(dict(nlevels=[4, 12], lindblad=True, nessential=[3, 10], init="diagonal, 0, 1"), "wj", False, id="4x12-guard-levels"),
+    pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True, init="diagonal, 0, 1"), False, True, id="2^5-lean64"),
+    pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True, init="diagonal, 0, 1"), "wj", False, id="2^5-lean64-weighted"),
+    pytest.param(dict(nlevels=[3, 3], lindblad=True), False, False, id="3x3-general-kernels"),
+]
+
+
+@pytest.mark.parametrize("kw,pen,stages", STAGE_ONLY_CASES)
+def test_gradient_evaluations_store_the_primal_stages_only_where_the_adjoint_reads_nothing_else(kw, pen, stages):
+    """qd_optim_evalGradF on the kernel families whose adjoint sweep reads only the primal stages z (lean column kernels, the 2^5
+    kernels; no leakage / dpdm penalty, weighted penalty only as the row-constant Jmeasure form): the forward sweep skips the states
+    x_n - the result is the one of the explicit three-call sequence with a full trajectory bit for bit and matches the oracle, and
+    qd_get_state then has nothing to offer.  Everywhere else the states are stored as before."""
+    sp = synthetic_spec(**{**kw, "ntime": 12, "dt": 0.001 if max(kw["nlevels"]) > 5 else 0.01, "penalties": bool(pen)})
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    if stages:
+        with pytest.raises(capi.QuandaryAmdError, match="no stored trajectory"):
+            h.get_state(0, opt.ninit_local)
+    else:
+        h.get_state(0, opt.ninit_local)
+    sums = opt.forward_local(sp.params0, store_trajectory=True)  # full trajectory
+    h.get_state(sp.time.ntime, opt.ninit_local)
+    g2 = opt.adjoint_local(sp.params0, sums)
+    assert np.array_equal(g, g2)
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("kw", [SHAPES[1], SHAPES[2], SHAPES[4], SHAPES[6],
                                 pytest.param(dict(nlevels=[10, 10], lindblad=True, target="pure", objective="Jfrobenius", init="pure, 0, 1"), id="10x10-team")])
 def test_gmres_request_served_by_the_neumann_iteration(kw):
