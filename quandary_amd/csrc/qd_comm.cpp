@@ -2,8 +2,13 @@
 // (src/main.cpp:133-177, src/optimproblem.cpp:292-298, :454-460, :527) as ncclAllReduce over xGMI, one process
 // per GPU, on the handle's HIP stream.  Bootstrap needs no MPI: the ncclUniqueId of rank 0 travels as 128 plain
 // bytes through whatever the caller has (a file on a shared file system here, torch.distributed/gloo in bench.py).
+#include <dlfcn.h>
+
 #include <chrono>
 #include <ctime>
+#include <mutex>
+#include <string>
+#include <vector>
 #include <sys/stat.h>
 #include <cstdio>
 #include <cstring>
@@ -18,18 +23,80 @@ static int fail(int code, const std::string& msg) {
   return code;
 }
 
-#define QD_NCCL(expr)                                                                       \
+// RCCL is loaded on first use of a communicator, not linked: the single-GPU paths of the library load and run on a ROCm installation
+// without it, and a non-default prefix is found through ROCM_PATH.  Search order: $ROCM_PATH/lib, the prefix of the build, the loader's
+// own path.  Only the seven entry points below are used (types and constants from <rccl/rccl.h> at build time).
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+#ifndef QD_ROCM_PATH
+#define QD_ROCM_PATH "/opt/rocm"
+#endif
+
+Rccl& rccl_slot() {
+  static Rccl r;
+  return r;
+}
+
+// nullptr + an error text in rccl_slot().error when the library or one of its symbols is missing
+Rccl* rccl() {
+  static std::once_flag once;
+  Rccl& r = rccl_slot();
+  std::call_once(once, [&r] {
+    std::vector<std::string> names;
+    if (const char* e = getenv("ROCM_PATH")) names.push_back(std::string(e) + "/lib/librccl.so.1");
+    names.push_back(std::string(QD_ROCM_PATH) + "/lib/librccl.so.1");
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string& n : names) {
+      r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+      if (const char* e = dlerror()) r.error += std::string(r.error.empty() ? "" : "; ") + e;
+    }
+    if (!r.lib) return;
+    r.error.clear();
+    auto sym = [&r](const char* name) -> void* {
+      void* p = dlsym(r.lib, name);
+      if (!p) r.error += std::string(r.error.empty() ? "missing symbol " : ", ") + name;
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return (r.lib && r.error.empty()) ? &r : nullptr;
+}
+}  // namespace
+
+#define QD_RCCL_OR_FAIL(R)                                                                                   \
+  Rccl* R = rccl();                                                                                          \
+  if (!R) return fail(QD_ERR_DEVICE, "RCCL is not available (librccl.so.1 under $ROCM_PATH/lib, " QD_ROCM_PATH "/lib or the loader path): " + rccl_slot().error)
+
+#define QD_NCCL(R, expr)                                                                     \
   do {                                                                                      \
     ncclResult_t _r = (expr);                                                               \
-    if (_r != ncclSuccess) return fail(QD_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
+    if (_r != ncclSuccess) return fail(QD_ERR_DEVICE, std::string(#expr) + ": " + (R)->GetErrorString(_r)); \
   } while (0)
 
 static_assert(QD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "QD_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
 
 extern "C" int qd_comm_unique_id(unsigned char* id) {
   if (!id) return fail(QD_ERR_INVALID, "qd_comm_unique_id: null argument");
+  QD_RCCL_OR_FAIL(R);
   ncclUniqueId u;
-  QD_NCCL(ncclGetUniqueId(&u));
+  QD_NCCL(R, R->GetUniqueId(&u));
   std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
   return QD_OK;
 }
@@ -37,6 +104,7 @@ extern "C" int qd_comm_unique_id(unsigned char* id) {
 extern "C" int qd_comm_create(const unsigned char* id, int rank, int nranks, int device_ordinal, qd_comm** out) {
   if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(QD_ERR_INVALID, "qd_comm_create: bad argument");
   *out = nullptr;
+  QD_RCCL_OR_FAIL(R);
   QD_HIP(qd::use_device(device_ordinal));
   qd_comm* c = new qd_comm();
   c->rank = rank;
@@ -44,13 +112,13 @@ extern "C" int qd_comm_create(const unsigned char* id, int rank, int nranks, int
   c->device = device_ordinal;
   ncclUniqueId u;
   std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
-  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+  ncclResult_t r = R->CommInitRank(&c->comm, nranks, u, rank);
   if (r != ncclSuccess) {
     delete c;
-    return fail(QD_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    return fail(QD_ERR_DEVICE, std::string("ncclCommInitRank: ") + R->GetErrorString(r));
   }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    ncclCommDestroy(c->comm);
+    R->CommDestroy(c->comm);
     delete c;
     return fail(QD_ERR_DEVICE, "qd_comm_create: stream creation failed");
   }
@@ -119,20 +187,23 @@ extern "C" void qd_comm_destroy(qd_comm* c) {
   struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   c->dbuf.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->comm)
+    if (Rccl* R = rccl()) R->CommDestroy(c->comm);
   delete c;
 }
 
 extern "C" int qd_comm_size(const qd_comm* c) {
   if (!c) return QD_ERR_INVALID;
   int n = 0;
-  if (ncclCommCount(c->comm, &n) != ncclSuccess) return QD_ERR_DEVICE;
+  Rccl* R = rccl();
+  if (!R || R->CommCount(c->comm, &n) != ncclSuccess) return QD_ERR_DEVICE;
   return n;
 }
 extern "C" int qd_comm_rank(const qd_comm* c) { return c ? c->rank : QD_ERR_INVALID; }
 
 int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_t st) {
-  QD_NCCL(ncclAllReduce(dbuf, dbuf, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st));
+  QD_RCCL_OR_FAIL(R);
+  QD_NCCL(R, R->AllReduce(dbuf, dbuf, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st));
   return QD_OK;
 }
 
