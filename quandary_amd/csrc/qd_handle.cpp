@@ -817,12 +817,15 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     a.use_gmres = 0;
     a.neumann_split = 1;
     a.stop_residual = 1;
+    a.maxiter *= 3;  // (linearsolver_maxiter caps KRYLOV iterations: at the gate's contraction bound 0.3 thirty stationary iterations
+                     // reach what ten GMRES iterations reach in the worst case; the stopping rule ends the loop long before)
     last_poly = 1;
     cfg.lds = pick_config(S, nb, opts, false).lds;
   } else if (gmres_as_neumann(cfg)) {
     cfg = pick_config(S, nb, opts, false);
     a.use_gmres = 0;
     a.gmres_poly = 1;
+    a.maxiter *= 3;
     last_poly = 1;
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
@@ -1014,12 +1017,14 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     a.use_gmres = 0;
     a.neumann_split = 1;
     a.stop_residual = 1;
+    a.maxiter *= 3;
     last_poly = 1;
     cfg.lds = pick_config(S, nb, opts, false, true).lds;
   } else if (gmres_as_neumann(cfg)) {
     cfg = pick_config(S, nb, opts, false, true);
     a.use_gmres = 0;
     a.gmres_poly = 1;
+    a.maxiter *= 3;
     last_poly = 1;
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
