@@ -65,10 +65,9 @@ template <int Q, bool LIND, bool DENSE = false>
 struct BigTeam {
   // one slot, table-driven (non-hoisted) formulation; DENSE: user-supplied Hamiltonians, G(t) read from the table in global memory
   typedef typename std::conditional<DENSE, DenseStencil<Q, LIND, 1, 2>, GenStencil<Q, LIND, 1, 2>>::type ST;
-#ifndef QD_BIG_BATCH_SCHR
-#define QD_BIG_BATCH_SCHR 0
-#endif
-  static constexpr bool kBatch = LIND || QD_BIG_BATCH_SCHR;  // neighbour reads in batches (GenStencil::apply_batched)
+  // neighbour reads in batches (GenStencil::apply_batched): Lindblad systems only - measured against the oscillator-by-oscillator form
+  // on one lease (profiles/with_lib.py): 20 x 20 Lindblad 10.7 -> 9.5 ms, but 32^4 Schroedinger with six coupling pairs 8.2 -> 8.75 ms
+  static constexpr bool kBatch = LIND;
   ST st;
   Lds L;
   int dim, redslot;
