@@ -182,6 +182,7 @@ def check_against_oracle(spec, device, k, nt, part_oracle, tol):
     sp = config.build_spec(cfg)
     attach_synthetic_hamiltonian(sp)
     sp.precision = getattr(spec, "precision", "f64")
+    sp.options = dict(getattr(spec, "options", {}) or {})  # the sample runs on the kernels and the solver path that are timed
     h = capi.Handle(sp, device=device)
     o = capi.Optim(h, sp, rank=0, nranks=spec.ninit // k)
     part = np.asarray(o.forward_local(sp.params0, False), dtype=np.float64)
