@@ -61,13 +61,15 @@ __global__ void k_big_table(const DevSys S, double2* __restrict__ coef, uint2* _
   dig[e] = make_uint2(dbra, dket);
 }
 
-template <int Q, bool LIND, bool DENSE = false>
+template <int Q, bool LIND, bool DENSE = false, bool ADJ = false>
 struct BigTeam {
   // one slot, table-driven (non-hoisted) formulation; DENSE: user-supplied Hamiltonians, G(t) read from the table in global memory
   typedef typename std::conditional<DENSE, DenseStencil<Q, LIND, 1, 2>, GenStencil<Q, LIND, 1, 2>>::type ST;
-  // neighbour reads in batches (GenStencil::apply_batched): Lindblad systems only - measured against the oscillator-by-oscillator form
-  // on one lease (profiles/with_lib.py): 20 x 20 Lindblad 10.7 -> 9.5 ms, but 32^4 Schroedinger with six coupling pairs 8.2 -> 8.75 ms
-  static constexpr bool kBatch = LIND;
+  // neighbour reads in batches (GenStencil::apply_batched) wherever the batch has the registers (the Neumann / GMRES kernels are separate
+  // instantiations for that reason): everywhere but the Schroedinger adjoint sweep, measured on one lease each - 20 x 20 Lindblad forward
+  // 8.9 -> 7.8 ms, gradient 25.0 -> 23.2; 32^4 Schroedinger with six coupling pairs forward 8.2 -> 7.3 ms, but gradient 20.9 -> 23.5
+  // with a batched adjoint sweep (207 spilt registers)
+  static constexpr bool kBatch = LIND || !ADJ;
   ST st;
   Lds L;
   int dim, redslot;
@@ -492,15 +494,16 @@ struct BigTeam {
     return Ysol;
   }
 
-  template <bool TRANS>
+  // GM: the Krylov solver - a kernel of its own (the stationary iterations keep their registers for the neighbour reads)
+  template <bool TRANS, bool GM>
   __device__ __forceinline__ double2* solve(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2* __restrict__ Bv, double2* Ya,
                                             double2* Yb, int* iters, bool y0_ready = false, double nb2s = 0.0) {
-    if (A.use_gmres) return gmres<TRANS>(A, c, alpha, Bv, Ya, Yb, iters);
-    return neumann<TRANS>(A, c, alpha, Bv, Ya, Yb, iters, y0_ready, nb2s);
+    if constexpr (GM) return gmres<TRANS>(A, c, alpha, Bv, Ya, Yb, iters);
+    else return neumann<TRANS>(A, c, alpha, Bv, Ya, Yb, iters, y0_ready, nb2s);
   }
 };
 
-template <int Q, bool LIND, bool DENSE = false>
+template <int Q, bool LIND, bool DENSE = false, bool GM = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef BigTeam<Q, LIND, DENSE> TM;
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       }
     }
     // rhs = M x; diagonal-split iteration: its first iterate (1 - h/2 D)^-1 rhs (and |rhs|^2 for the residual rule) from the same loop
-    const bool y0 = !A.stepper_ee && !A.use_gmres && tm.split_on(A);
+    const bool y0 = !GM && !A.stepper_ee && tm.split_on(A);
     double nb2[1] = {0.0};
     if (y0) {
       for (int e = tid; e < eend; e += nt) {
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       }
     } else {
       int its;
-      const double2* K = tm.template solve<false>(A, c, 0.5 * c.h, B, Ya, Yb, &its, y0, nb2[0]);
+      const double2* K = tm.template solve<false, GM>(A, c, 0.5 * c.h, B, Ya, Yb, &its, y0, nb2[0]);
       napply += its;
       double* zdst = A.ztraj ? A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim : nullptr;
       for (int e = tid; e < eend; e += nt) {
@@ -651,10 +654,10 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   }
 }
 
-template <int Q, bool LIND, bool DENSE = false>
+template <int Q, bool LIND, bool DENSE = false, bool GM = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef BigTeam<Q, LIND, DENSE> TM;
+  typedef BigTeam<Q, LIND, DENSE, true> TM;
   const DevSys& S = A.S;
   TM tm;
   if (!tm.init(S, smem, A.nb)) return;
@@ -807,7 +810,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     }
     int its;
     {
-      const double2* K = tm.template solve<true>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
+      const double2* K = tm.template solve<true, GM>(A, c, 0.5 * c.h, XB, Ya, Yb, &its);
       for (int e = tid; e < eend; e += nt) {
         const double2 k = K[e];
         KB[e] = make_double2(c.h * k.x, c.h * k.y);
@@ -825,7 +828,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
         cf[2 * k + 1] += Av.x * kb.x + Av.y * kb.y;
       }
       double2 t;
-      if constexpr (DENSE || !BigTeam<Q, LIND, DENSE>::kBatch) t = tm.st.template apply<true>(S, tm.L, KB, c, 0, kb);
+      if constexpr (DENSE || !TM::kBatch) t = tm.st.template apply<true>(S, tm.L, KB, c, 0, kb);
       else t = tm.st.template apply_batched<true>(S, tm.L, KB, c, 0, kb);
       double2 xb = XB[e];
       xb.x += t.x;

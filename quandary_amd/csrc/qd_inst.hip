@@ -66,8 +66,8 @@ static hipError_t set_lds(K kern, size_t bytes) {
 #if QD_PART == 0 || QD_PART == 2
 template <int VAR>
 static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
-    return launch_big(reinterpret_cast<const void*>(k_forward_big<QD_Q, kLind, kDense>), a, cfg, st);
+  if constexpr (VAR == 16 && variant_built<VAR>()) {
+    return launch_big(reinterpret_cast<const void*>(k_forward_big<QD_Q, kLind, kDense, kGmPart>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);
@@ -103,8 +103,8 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
 #if QD_PART == 1 || QD_PART == 3
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if constexpr (VAR == 16 && variant_built<VAR>() && !kGmPart) {
-    return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense>), a, cfg, st);
+  if constexpr (VAR == 16 && variant_built<VAR>()) {
+    return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense, kGmPart>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);
@@ -143,7 +143,7 @@ static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream
 #if QD_PART == 0
 hipError_t QD_NAME(inst_forwardgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
 hipError_t QD_NAME(inst_forward_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (cfg.gmres && cfg.var != 16) return QD_NAME(inst_forwardgm_, QD_Q, QD_L, QD_B)(a, cfg, st);  // GMRES kernels: another object
+  if (cfg.gmres) return QD_NAME(inst_forwardgm_, QD_Q, QD_L, QD_B)(a, cfg, st);  // GMRES kernels: another object
   QD_VAR_SWITCH(go_forward, a, cfg, st)
 }
 hipError_t QD_NAME(inst_apply_, QD_Q, QD_L, QD_B)(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y,
@@ -153,7 +153,7 @@ hipError_t QD_NAME(inst_apply_, QD_Q, QD_L, QD_B)(const DevSys& S, const double*
 #elif QD_PART == 1
 hipError_t QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
 hipError_t QD_NAME(inst_adjoint_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (cfg.gmres && cfg.var != 16) return QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(a, cfg, st);
+  if (cfg.gmres) return QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(a, cfg, st);
   QD_VAR_SWITCH(go_adjoint, a, cfg, st)
 }
 #elif QD_PART == 2
