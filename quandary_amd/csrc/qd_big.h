@@ -654,7 +654,8 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   }
 }
 
-template <int Q, bool LIND, bool DENSE = false, bool GM = false>
+// EE: explicit Euler (its backward chain and its step are a kernel of their own: the implicit-midpoint sweep keeps its registers)
+template <int Q, bool LIND, bool DENSE = false, bool GM = false, bool EE = false>
 __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef BigTeam<Q, LIND, DENSE, true> TM;
@@ -682,7 +683,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
   const int ntime = A.ntime;
   tm.tsync();
-  if (A.stepper_ee && !LIND) {
+  if constexpr (EE && !LIND) {
     // Explicit Euler in Schroedinger mode [r3: also beyond dim 4096]: the reference re-computes the primal backwards with the FORWARD
     // stepper and a negative step (src/timestepper.cpp:229-231 with ExplEuler::evolveFWD :496-507), and its gradient is defined on
     // that chain - reproduce it by overwriting the stored trajectory (k_adjoint of qd_device.h does the same in registers).
@@ -764,7 +765,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     double cf[2 * Q];
 #pragma unroll
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
-    if (A.stepper_ee) {
+    if constexpr (EE) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt x_adj against x_{n-1}, then x_adj += dt M(tstop)^T x_adj;
       // M(tstop) is table row s + 1 (the last row is followed by one extra row for t = T)
       for (int e = tid; e < eend; e += nt) Z[e] = state(s, e);

@@ -104,7 +104,10 @@ static hipError_t go_apply(const DevSys& S, const double* ctlrow, int transpose,
 template <int VAR>
 static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if constexpr (VAR == 16 && variant_built<VAR>()) {
-    return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense, kGmPart>), a, cfg, st);
+    if constexpr (!kGmPart) {
+      if (a.stepper_ee) return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense, false, true>), a, cfg, st);
+    }
+    return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense, kGmPart, false>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;
     hipError_t e = set_lds(kf, cfg.lds);
@@ -153,7 +156,7 @@ hipError_t QD_NAME(inst_apply_, QD_Q, QD_L, QD_B)(const DevSys& S, const double*
 #elif QD_PART == 1
 hipError_t QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st);
 hipError_t QD_NAME(inst_adjoint_, QD_Q, QD_L, QD_B)(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
-  if (cfg.gmres) return QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(a, cfg, st);
+  if (cfg.gmres && !(cfg.var == 16 && a.stepper_ee)) return QD_NAME(inst_adjointgm_, QD_Q, QD_L, QD_B)(a, cfg, st);  // (explicit Euler has no linear solve)
   QD_VAR_SWITCH(go_adjoint, a, cfg, st)
 }
 #elif QD_PART == 2
