@@ -834,12 +834,13 @@ def test_unsupported_sizes_fail_loudly():
 
 
 @pytest.mark.parametrize("kw", [BIG_SHAPES[0], BIG_SHAPES[3]])
-@pytest.mark.parametrize("team", [1, 8])
-def test_explicit_euler_beyond_lds(kw, team):
+@pytest.mark.parametrize("team,linsolve", [(1, "neumann"), (8, "neumann"), (8, "gmres")])
+def test_explicit_euler_beyond_lds(kw, team, linsolve):
     """ExplEuler for dim > 4096 (was QD_ERR_UNSUPPORTED through round 2; the reference's debug stepper works at any size,
     src/timestepper.cpp:484-520): Lindblad on the stored trajectory, Schroedinger on the backward-recomputed chain (all penalties incl.
-    dpdm), one workgroup and a team of eight per state."""
-    sp = synthetic_spec(**{**kw, "ntime": 6, "nspline": 5, "penalties": True, "stepper": "EE", "dt": 0.002})
+    dpdm), one workgroup and a team of eight per state; the linear-solver setting is irrelevant to it (the sweeps are built per solver: the
+    explicit step must be found under either)."""
+    sp = synthetic_spec(**{**kw, "ntime": 6, "nspline": 5, "penalties": True, "stepper": "EE", "dt": 0.002, "linsolve": linsolve})
     sp.options = {"big_team": team}
     h, orc = capi.Handle(sp), Oracle(sp)
     assert h.dim > 4096
