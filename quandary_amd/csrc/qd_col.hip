@@ -361,8 +361,8 @@ struct ColTeam {
       if (SPLIT) y[j] = make_double2(fma(pr[SPLIT ? j : 0], b[j].x, -pi[SPLIT ? j : 0] * b[j].y), fma(pr[SPLIT ? j : 0], b[j].y, pi[SPLIT ? j : 0] * b[j].x));
       else y[j] = b[j];
     }
-    const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
-    float rel2 = (float)(A.reltol * A.reltol), thr = 1.f;
+    const double inv_abs2 = A.inv_abs2;
+    float rel2 = A.rel2, thr = 1.f;
     if (A.stop_residual) {
       // in place of GMRES (qd_handle::gmres_as_split): stop when kappa^2 ||y_{m+1} - y_m||^2 <= max(rtol^2 ||b||^2, abstol^2)
       double nb2[1] = {0.0};

@@ -86,6 +86,8 @@ struct SweepArgs {
   const double* wjw;
   int use_gmres;  // 0: Neumann; 1: in-kernel GMRES, Krylov basis in LDS (one element per thread, small dim); 2: basis in global memory (kry)
   double abstol, reltol;
+  double inv_abs2;  // 1 / abstol^2 and reltol^2 as the solvers use them: kernel arguments are re-read from the scalar cache, values
+  float rel2;       // derived inside the kernel were hoisted out of the time loop and spilt to scratch (one round trip per solve)
   // penalties (src/timestepper.cpp:256-480)
   double gamma_penalty, penalty_param, gamma_dpdm;
   int leak_on;
