@@ -840,7 +840,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   QD_HIP(hipEventRecord(ev0, stream));
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
-  else if (lean64) QD_HIP(launch_forward_lean64(a, stream));
+  else if (lean64) QD_HIP(launch_forward_lean64(a, opts, stream));
   else if (use_col(cfg)) QD_HIP(launch_forward_col(a, opts, stream));
   else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
@@ -1038,7 +1038,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   QD_HIP(hipEventRecord(ev2, stream));
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));
-  else if (lean64) QD_HIP(launch_adjoint_lean64(a, stream));
+  else if (lean64) QD_HIP(launch_adjoint_lean64(a, opts, stream));
   else if (use_col(cfg)) QD_HIP(launch_adjoint_col(a, opts, stream));
   else QD_HIP(launch_adjoint(a, cfg, stream));
   QD_HIP(hipEventRecord(ev3, stream));

@@ -126,6 +126,8 @@ struct TuneOpts {
   int big_spread = -1;     // "big_spread": team members dealt over all XCDs (1), kept on one (0), default (-1)
   int big_blocked = 2;     // "big_blocked": a team member owns a contiguous block of the state (1; 2: the members of an XCD own neighbouring blocks) or every 'team'th row of 1024 elements (0)
   int f32_sb = -1;         // "f32_sb": slot bits of the fp32-mixed 2^4 kernel
+  int lean64_sb = 0;       // "lean64_sb": elements per thread of the fp64 2^5 kernels as a power of two (0 = automatic: 2 elements on 512 threads for batches of
+                           // at most one state per CU, else 4 on 256; 1 / 2 force)
   int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
@@ -177,8 +179,8 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
                             const TuneOpts& o, hipStream_t st);
 // the same lean slot kernel instantiated in fp64: Neumann sweeps of the 2^5 Lindblad system (QD_PRECISION_F64)
 bool lean64_available(const DevSys& S, const TuneOpts& o);
-hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st);
-hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st);
+hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
+hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
 // lean column kernels (qd_col.hip): Lindblad Neumann sweeps of density matrices with 33..64 rows and runtime level counts
 bool collean_available(const DevSys& S, const TuneOpts& o);

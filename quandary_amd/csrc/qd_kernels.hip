@@ -556,7 +556,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // ---------------------------------------------------------------------------------------------
 // options
 // ---------------------------------------------------------------------------------------------
-static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "big_blocked", "f32_sb", "no_lean64", "no_collean",
+static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "big_blocked", "f32_sb", "lean64_sb", "no_lean64", "no_collean",
                                        "col_ept", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
@@ -581,6 +581,7 @@ int TuneOpts::set(const char* key, const char* value) {
   else if (k == "big_spread") big_spread = (int)iv;
   else if (k == "big_blocked") big_blocked = v == "auto" ? 2 : (int)(iv < 0 ? 0 : iv > 2 ? 2 : iv);
   else if (k == "f32_sb") f32_sb = (int)iv;
+  else if (k == "lean64_sb") lean64_sb = (iv == 1 || iv == 2) ? (int)iv : 0;
   else if (k == "no_lean64") no_lean64 = iv != 0;
   else if (k == "no_collean") no_collean = iv != 0;
   else if (k == "col_ept") col_ept = (int)iv;

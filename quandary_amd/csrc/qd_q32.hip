@@ -47,7 +47,8 @@ struct Q32 {
   static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
   static constexpr bool ONEWAVE = NT == 64;
   static constexpr int BPC = sizeof(R) == 4 ? 4 : 2;  // workgroups per CU the register budget is set for (256-thread groups)
-  static constexpr int MINW = BPC * NT / 256 > 0 ? BPC * NT / 256 : 1;  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
+  // (the 512-thread fp64 variant of the 2^5 system runs one group per CU: two waves per SIMD, the whole register file)
+  static constexpr int MINW = (Q == 5 && SB == 1 && sizeof(R) == 8) ? 2 : (BPC * NT / 256 > 0 ? BPC * NT / 256 : 1);  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
   static constexpr unsigned EB = sizeof(f2), ESH = sizeof(R) == 4 ? 3 : 4;  // bytes per element, log2
   static constexpr unsigned SLOT_BYTES = EB << TB;  // LDS distance of consecutive slots
   static_assert(NT >= 64 && NT <= 1024, "block size");
@@ -1010,8 +1011,22 @@ bool lean64_available(const DevSys& S, const TuneOpts& o) {
     if (S.n[k] != 2 || S.ness[k] != 2) return false;
   return !o.no_lean64;
 }
-hipError_t launch_forward_lean64(const SweepArgs& a, hipStream_t st) { return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st); }
-hipError_t launch_adjoint_lean64(const SweepArgs& a, hipStream_t st) { return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st); }
+// Small batches (at most one state per CU: the shards of a multi-GPU run, BASELINE config 5 on 8 GPUs) run two elements per thread on
+// 512 threads - two waves per SIMD hide part of the latency one 256-thread group per CU leaves exposed: 128 states x 1000 steps,
+// gradient, one lease: 16.1 -> 15.0 ms (forward 5.5 -> 5.3).  Larger batches keep two 256-thread groups per CU.
+static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
+  if (a.use_gmres) return 2;
+  if (o.lean64_sb == 1 || o.lean64_sb == 2) return o.lean64_sb;
+  return a.nb <= 256 ? 1 : 2;
+}
+hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+  if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
+  return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
+}
+hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+  if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
+  return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);
+}
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
   return go_app<5, 2, double>(S, ctlrow, transpose, x, y, nb, 1, st);
 }

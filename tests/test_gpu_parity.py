@@ -260,6 +260,23 @@ def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("sb", ["1", "2"])
+@pytest.mark.parametrize("stepper,penalties", [("IMR", True), ("IMR4", False)])
+def test_five_qubit_kernels_with_two_and_four_elements_per_thread(sb, stepper, penalties):
+    """The fp64 2^5 Lindblad kernels (qd_q32.hip) in both shapes - 512 threads x 2 elements (chosen for batches of at most one state per
+    CU) and 256 threads x 4 elements (option lean64_sb): objective parts and gradient against the oracle."""
+    sp = synthetic_spec([2, 2, 2, 2, 2], lindblad=True, init="diagonal, 0, 1, 2", ntime=10, stepper=stepper, penalties=penalties)
+    sp.options = {"lean64_sb": sb}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    opt.close(); h.close(); orc.close()
+
+
 STAGE_ONLY_CASES = [
     # (system, penalties, the gradient evaluation stores the primal stages only)
     pytest.param(LEANCOL_SHAPES[0].values[0], False, True, id="3x20-no-penalty"),
