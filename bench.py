@@ -14,14 +14,15 @@ Lindblad time-steps x initial-conditions per second, whole job.
                                    the reference's own performance cases nlevels_4_4_4_4 and nlevels_32_32_32_32, one 20x20 state),
                                    each with its roofline fractions and oracle check; `workloads_legend` explains the keys.
   python bench.py --gpus N         N > 1: starts N ranks itself (torch.distributed.run, one per GPU) unless it
-                                   already runs under a launcher.  Default workload = BASELINE.json configs[3]
-                                   (C4: 3x20 Lindblad, 3600 basis initial conditions) in gradient mode, ntime
-                                   500 so that the stored trajectories fit, STRONG scaling: the initial
-                                   conditions are split evenly and contiguously over the GPUs
-                                   (iinit_global = rank*nlocal + i, src/optimproblem.cpp:248) and the seven
-                                   objective sums and the gradient are all-reduced with RCCL
-                                   (src/optimproblem.cpp:454-460, :527).  The 1-GPU point of that series is the
-                                   "c4/grad" entry of the one-GPU line's "workloads".
+                                   already runs under a launcher.  Default = the SAME workload and mode as on one GPU
+                                   (BASELINE.json configs[3], C4: 3x20 Lindblad, 3600 basis initial conditions, forward
+                                   sweep, ntime 2500), STRONG scaling: the initial conditions are split evenly and
+                                   contiguously over the GPUs (iinit_global = rank*nlocal + i, src/optimproblem.cpp:248),
+                                   the seven objective sums are all-reduced with RCCL (src/optimproblem.cpp:292-298) - so
+                                   value(N) / value(1) of the default lines is the speed-up of one workload.  The same run
+                                   also times the gradient evaluation (ntime 500 so that the stored stages fit one GPU;
+                                   sums and gradient all-reduced with RCCL, src/optimproblem.cpp:454-460, :527) and reports
+                                   it under "gradient" with its own one-GPU point; `--mode grad` makes it the timed step.
   --shard-of N                     one GPU: time shard 0 of N of the workload (ninit / N initial conditions) - the strong-scaling
                                    curve minus the two all-reduces, measurable without an N-GPU node.
   --scaling weak                   every GPU propagates one full set of the workload's initial conditions (the
@@ -435,7 +436,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 1)")
     ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "q4", "q4j", "c4", "c5", "d4", "l20", "n4444", "n32"],
                     help="default: c4 (the largest single-GPU configuration of BASELINE.json)")
-    ap.add_argument("--mode", default=None, choices=["fwd", "grad"], help="default: fwd on one GPU, grad on several")
+    ap.add_argument("--mode", default=None, choices=["fwd", "grad"], help="default: fwd (several GPUs: the gradient evaluation is timed as well and reported under \"gradient\")")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32mixed"],
                     help="f32mixed: fp32 state exchange / stencil arithmetic, fp64 accumulation (all-qubit Lindblad systems)")
     ap.add_argument("--linsolve", default=None, choices=[None, "neumann", "gmres"])
@@ -472,7 +473,11 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     multi = world > 1
     name = args.workload or "c4"
-    mode = args.mode or ("grad" if multi else "fwd")
+    # Default on ANY number of GPUs: the forward sweep of BASELINE config 4 at its full size - one series, so that value(N) / value(1) is
+    # the strong-scaling speed-up of one workload.  On several GPUs the gradient evaluation (forward + adjoint + the RCCL all-reduce of
+    # sums and gradient) is timed in the same run as well and reported under "gradient", with its own one-GPU point.
+    mode = args.mode or "fwd"
+    also_grad = multi and args.mode is None
     steps = args.steps if args.steps is not None else (3 if multi else 5)
     warmup = args.warmup if args.warmup is not None else 1
 
@@ -552,6 +557,34 @@ def main():
             out["dist_backend"] = comm.describe()
             out["allreduce_ms_per_step"] = {"objective_sums": ar_ms[0] / steps, "gradient": ar_ms[1] / steps}
     run.close()
+
+    if also_grad:
+        # the gradient evaluation of the same workload (ntime 500 for C4: the stored stages of 3600 initial conditions are 104 GB on one
+        # GPU), every rank takes part; then rank 0 alone on the whole batch as the one-GPU point of THIS series
+        gover = dict(over)
+        if name == "c4" and not args.ntime:
+            gover["ntime"] = 500
+        rg = Runner(name, "grad", gover, args.dtype, rank, world, local_rank, weak, comm, options)
+        gel, gkm, gap = rg.time(steps, warmup, sync)
+        gar = rg.obj.allreduce_ms()
+        red = comm.allreduce_max(np.array([gel, gkm] + gar, dtype=np.float64))
+        gel, gkm, gar = float(red[0]), float(red[1]), [float(red[2]), float(red[3])]
+        gval, groof, gcfg = rg.report(gel, gkm, gap, steps, fp64_peak if rank == 0 else 0.0)
+        rg.close()
+        if rank == 0:
+            g = {"mode": gcfg["mode"], "ntime": gcfg["ntime"], "value": gval, "grad_wall_ms": gel / steps * 1e3,
+                 "kernel_ms_per_launch": groof["kernel_ms_per_launch"], "hbm_frac": groof["frac"],
+                 "allreduce_ms_per_step": {"objective_sums": gar[0] / steps, "gradient": gar[1] / steps}}
+            if not weak:
+                try:
+                    r1 = Runner(name, "grad", gover, args.dtype, 0, 1, local_rank, False, None, options)
+                    el1, km1, _ = r1.time(1, 1, lambda: torch.cuda.synchronize())
+                    v1, _, _ = r1.report(el1, km1, gap, 1, 0.0)
+                    r1.close()
+                    g["same_workload_one_gpu"] = {"value": v1, "grad_wall_ms": el1 * 1e3, "speedup": gval / v1}
+                except (Exception, SystemExit) as e:  # noqa: BLE001
+                    g["same_workload_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+            out["gradient"] = g
 
     if rank == 0 and not multi and args.shard_of > 1:
         # shard 0 of N on this GPU: what one GPU of an N-GPU strong-scaling run does between the collectives

@@ -957,6 +957,15 @@ def test_bench_two_ranks_matches_one_rank():
     assert res[2]["config"]["ninit_per_gpu"] * 2 == res[1]["config"]["ninit"]
     assert res[2]["config"]["objective"] == pytest.approx(res[1]["config"]["objective"], rel=1e-12)
     assert set(res[2]["allreduce_ms_per_step"]) == {"objective_sums", "gradient"}
+    # the default invocation: the forward sweep is the timed step on any number of GPUs (one series), the gradient evaluation is
+    # timed in the same run and reported next to it with its own one-GPU point
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "1",
+                        "--ntime", "200", "--no-workloads", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["mode"].startswith("forward sweep") and d["n_gpus"] == 2
+    assert d["gradient"]["mode"].startswith("forward + adjoint") and d["gradient"]["value"] > 0.0
+    assert d["gradient"]["same_workload_one_gpu"]["speedup"] > 0.0 and d["same_workload_one_gpu"]["speedup"] > 0.0
 
 
 @pytest.mark.parametrize("workload,extra", [("c2", []), ("c3", []), ("c4", ["--set", "initialcondition=basis, 0", "--ntime", "40"])])
