@@ -48,7 +48,7 @@ struct Q32 {
   static constexpr bool ONEWAVE = NT == 64;
   static constexpr int BPC = sizeof(R) == 4 ? 4 : 2;  // workgroups per CU the register budget is set for (256-thread groups)
   // (the 512-thread fp64 variant of the 2^5 system runs one group per CU: two waves per SIMD, the whole register file)
-  static constexpr int MINW = (Q == 5 && SB == 1 && sizeof(R) == 8) ? 2 : (BPC * NT / 256 > 0 ? BPC * NT / 256 : 1);  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
+  static constexpr int MINW = (Q == 5 && SB == 1) ? 2 : (BPC * NT / 256 > 0 ? BPC * NT / 256 : 1);  // 4 workgroups of 256 threads per CU (128 VGPRs); one-wave groups: 1 wave/SIMD budget
   static constexpr unsigned EB = sizeof(f2), ESH = sizeof(R) == 4 ? 3 : 4;  // bytes per element, log2
   static constexpr unsigned SLOT_BYTES = EB << TB;  // LDS distance of consecutive slots
   static_assert(NT >= 64 && NT <= 1024, "block size");
@@ -964,6 +964,12 @@ static hipError_t go_app(const DevSys& S, const double* ctlrow, int tr, const do
   return hipGetLastError();
 }
 
+// 2^5 system, batches of at most one state per CU: 512 threads x 2 elements (see lean64_sb below; the same option)
+static bool small_batch_sb1(const SweepArgs& a, const TuneOpts& o) {
+  if (o.lean64_sb == 1 || o.lean64_sb == 2) return o.lean64_sb == 1;
+  return a.nb <= 256;
+}
+
 hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q, o);
   if (a.use_gmres) {  // Krylov basis in global memory as float2, Hessenberg problem in fp64
@@ -972,7 +978,7 @@ hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t
     if (a.S.Q == 3) return go_fwd<3, 0, float, true>(a, st);
     return hipErrorInvalidValue;
   }
-  if (a.S.Q == 5) return go_fwd<5, 2, float>(a, st);
+  if (a.S.Q == 5) return small_batch_sb1(a, o) ? go_fwd<5, 1, float>(a, st) : go_fwd<5, 2, float>(a, st);
   if (a.S.Q == 4) return sb == 2 ? go_fwd<4, 2, float>(a, st) : go_fwd<4, 0, float>(a, st);
   if (a.S.Q == 3) return go_fwd<3, 0, float>(a, st);  // [r3] 2x2x2 (BASELINE config 2): one wave per initial condition
   return hipErrorInvalidValue;
@@ -985,7 +991,7 @@ hipError_t launch_adjoint_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t
     if (a.S.Q == 3) return go_adj<3, 0, float, true>(a, st);
     return hipErrorInvalidValue;
   }
-  if (a.S.Q == 5) return go_adj<5, 2, float>(a, st);
+  if (a.S.Q == 5) return small_batch_sb1(a, o) ? go_adj<5, 1, float>(a, st) : go_adj<5, 2, float>(a, st);
   if (a.S.Q == 4) return sb == 2 ? go_adj<4, 2, float>(a, st) : go_adj<4, 0, float>(a, st);
   if (a.S.Q == 3) return go_adj<3, 0, float>(a, st);
   return hipErrorInvalidValue;
