@@ -247,6 +247,15 @@ double qd_last_adjoint_ms(const qd_handle* h);
 /* Workgroups per initial condition in the last sweep: 1, or the team size when a large state (dim > 4096) with few
  * initial conditions was spread over several CUs. */
 int qd_last_team(const qd_handle* h);
+/* Which iteration solved the linear systems of the last sweep: QD_SOLVER_NEUMANN (requested), QD_SOLVER_KRYLOV (the in-kernel GMRES,
+ * KSPGMRES iteration for iteration, src/timestepper.cpp:541-550), QD_SOLVER_GMRES_AS_SPLIT / QD_SOLVER_GMRES_AS_NEUMANN (a gmres
+ * request served by a stationary iteration under GMRES's stopping rule: option gmres_split), QD_SOLVER_NONE (explicit Euler). */
+#define QD_SOLVER_NONE 0
+#define QD_SOLVER_NEUMANN 1
+#define QD_SOLVER_KRYLOV 2
+#define QD_SOLVER_GMRES_AS_SPLIT 3
+#define QD_SOLVER_GMRES_AS_NEUMANN 4
+int qd_last_solver(const qd_handle* h);
 /* Measurement hook for the secondary (fp64 vector) roofline: runs a register-only
  * v_fma_f64 micro-benchmark on the device and returns the sustained TFLOP/s in
  * *tflops (the fp64 peak is to be measured, not quoted). */
@@ -330,8 +339,20 @@ typedef struct qd_comm qd_comm;
 /* rank 0: generate the id (ncclGetUniqueId) and hand its bytes to every rank by any means */
 int qd_comm_unique_id(unsigned char id[QD_COMM_ID_BYTES]);
 int qd_comm_create(const unsigned char id[QD_COMM_ID_BYTES], int rank, int nranks, int device_ordinal, qd_comm** out);
-/* MPI-free bootstrap through a file every rank can see: rank 0 writes the id, the others wait up to timeout_s */
+/* MPI-free bootstrap through a path every rank can see.  RCCL backend: rank 0 writes the id file, every other rank echoes the token it read
+ * (path.ack<rank>) and rank 0 confirms with path.go before anyone calls ncclCommInitRank - a leftover file of a crashed run is never used;
+ * QD_JOB_ID (when the launcher sets one) additionally separates jobs.  Host backend (below): the path only names the shared-memory segment.
+ * Backend: environment QD_COMM_BACKEND = rccl | host | auto (default auto: host when nranks exceeds the number of visible GPUs, i.e. when
+ * ranks share a device, which RCCL refuses). */
 int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out);
+/* HOST backend: the ranks of ONE node reduce through a POSIX shared-memory segment named after `name` (the same string on every rank of a
+ * job, different for concurrent jobs).  Same call sites and buffers as the RCCL backend (qd_optim_evalF_dist / evalGradF_dist,
+ * qd_comm_allreduce), summation in rank order on every rank (bit-identical results on all ranks); the reduction buffer makes one round
+ * trip HBM -> pinned host -> HBM per collective.  For ranks that share a GPU (mpirun -np 4 on a one-GPU box) and nodes without RCCL.
+ * Replaces the same MPI_Allreduce calls (src/optimproblem.cpp:292-298, :454-460, :527).  At most 64 ranks. */
+int qd_comm_create_host(const char* name, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out);
+/* 0 = RCCL, 1 = host shared memory */
+int qd_comm_backend(const qd_comm* c);
 void qd_comm_destroy(qd_comm* c);
 int qd_comm_size(const qd_comm* c);
 int qd_comm_rank(const qd_comm* c);

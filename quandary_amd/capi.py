@@ -174,10 +174,10 @@ EXPORTS = [
     "qd_last_error", "qd_version", "qd_device_count", "qd_create", "qd_destroy", "qd_dim", "qd_dim_rho",
     "qd_dim_ess", "qd_ndesign", "qd_set_hamiltonian", "qd_set_params", "qd_eval_controls", "qd_apply_rhs", "qd_get_state",
     "qd_set_target", "qd_set_penalty", "qd_forward", "qd_adjoint", "qd_last_mean_applies",
-    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_last_team", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
+    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_last_team", "qd_last_solver", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
-    "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
+    "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_create_host", "qd_comm_backend", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
     "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables", "qd_set_option",
 ]
 COMM_ID_BYTES = 128
@@ -227,6 +227,7 @@ def load_library(path=None):
         getattr(lib, f).argtypes = [vp]
         getattr(lib, f).restype = C.c_double
     lib.qd_last_team.argtypes = [vp]
+    lib.qd_last_solver.argtypes = [vp]
     lib.qd_measure_fp64_peak.argtypes = [C.c_int, C.POINTER(C.c_double)]
     lib.qd_optim_create.argtypes = [vp, C.POINTER(qd_objective), C.c_int, C.c_int, C.POINTER(vp)]
     lib.qd_optim_destroy.argtypes = [vp]
@@ -243,6 +244,8 @@ def load_library(path=None):
     lib.qd_comm_unique_id.argtypes = [c_u8p]
     lib.qd_comm_create.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qd_comm_create_from_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
+    lib.qd_comm_create_host.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
+    lib.qd_comm_backend.argtypes = [vp]
     lib.qd_comm_destroy.argtypes = [vp]
     lib.qd_comm_destroy.restype = None
     lib.qd_comm_size.argtypes = [vp]
@@ -422,6 +425,14 @@ class Handle:
     def last_team(self):
         """Workgroups per initial condition in the last sweep (1 unless a large state with few initial conditions ran as a team)."""
         return self.lib.qd_last_team(self._h)
+
+    SOLVER_NAMES = {0: "none", 1: "neumann", 2: "krylov", 3: "gmres_as_split", 4: "gmres_as_neumann"}
+
+    @property
+    def last_solver(self):
+        """Which iteration solved the linear systems of the last sweep (qd_last_solver): 'neumann', 'krylov' (the in-kernel GMRES),
+        'gmres_as_split' / 'gmres_as_neumann' (a gmres request served by a stationary iteration), 'none' (explicit Euler)."""
+        return self.SOLVER_NAMES[self.lib.qd_last_solver(self._h)]
 
     @property
     def forward_ms(self):

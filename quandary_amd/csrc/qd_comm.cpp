@@ -2,7 +2,19 @@
 // (src/main.cpp:133-177, src/optimproblem.cpp:292-298, :454-460, :527) as ncclAllReduce over xGMI, one process
 // per GPU, on the handle's HIP stream.  Bootstrap needs no MPI: the ncclUniqueId of rank 0 travels as 128 plain
 // bytes through whatever the caller has (a file on a shared file system here, torch.distributed/gloo in bench.py).
+//
+// Second backend, HOST: the ranks of one node reduce through a POSIX shared-memory segment - the same call sites
+// (qd_comm_allreduce_dev on the handle's stream, qd_comm_allreduce), the same [7 | ndesign] buffers, a fixed summation order that is
+// the same on every rank.  It exists for ranks that SHARE a GPU (mpirun -np 4 on a one-GPU box: RCCL refuses two ranks on one device) and
+// for nodes without RCCL; the reduction buffer then makes one round trip HBM -> pinned host -> HBM per collective.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <random>
 
 #include <chrono>
 #include <ctime>
@@ -90,6 +102,225 @@ Rccl* rccl() {
     if (_r != ncclSuccess) return fail(QD_ERR_DEVICE, std::string(#expr) + ": " + (R)->GetErrorString(_r)); \
   } while (0)
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// HOST backend: all-reduce through a shared-memory segment
+// ---------------------------------------------------------------------------------------------------------------
+namespace qd {
+constexpr int kHostMaxRanks = 64;
+constexpr size_t kHostSlot = 1u << 16;  // doubles per rank and round (512 KiB); longer buffers go in rounds
+struct alignas(64) HostFlag {
+  std::atomic<unsigned long long> v;
+};
+struct HostSeg {
+  std::atomic<unsigned long long> magic;  // published last by rank 0
+  unsigned long long token;               // random, rank 0
+  int nranks;
+  int pad_;
+  HostFlag hello[kHostMaxRanks], ack[kHostMaxRanks];    // bootstrap handshake
+  HostFlag arrive[kHostMaxRanks], done[kHostMaxRanks];  // per-round sequence numbers
+  // followed by nranks slots of kHostSlot doubles
+  double* slot(int r) { return reinterpret_cast<double*>(reinterpret_cast<char*>(this) + sizeof(HostSeg)) + (size_t)r * kHostSlot; }
+};
+struct HostRing {
+  HostSeg* seg = nullptr;
+  size_t bytes = 0;
+  std::string name;
+  unsigned long long seq = 0;
+  int rank = 0, nranks = 1;
+  double timeout_s = 600.0;
+};
+}  // namespace qd
+
+static constexpr unsigned long long kHostMagic = 0x51444853484d3031ull;  // "QDHSHM01"
+
+static size_t host_seg_bytes(int nranks) { return sizeof(qd::HostSeg) + sizeof(double) * qd::kHostSlot * (size_t)nranks; }
+
+static std::string host_shm_name(const char* name) {
+  // shm names: one leading slash, no others
+  std::string s = "/qdcomm_";
+  for (const char* c = name; *c; c++) s += (isalnum((unsigned char)*c) || *c == '-' || *c == '.') ? *c : '_';
+  if (s.size() > 200) {
+    unsigned long long h = 1469598103934665603ull;
+    for (const char* c = name; *c; c++) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+    s = "/qdcomm_" + std::to_string(h);
+  }
+  return s;
+}
+
+static unsigned long long random_token() {
+  std::random_device rd;
+  unsigned long long t = ((unsigned long long)rd() << 32) ^ rd() ^ ((unsigned long long)getpid() << 17) ^
+                         (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+  return t ? t : 1ull;
+}
+
+// wait until pred() holds; false on timeout
+template <class P>
+static bool spin_until(P pred, double timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    if (pred()) return true;
+    if (spins < 2000) continue;
+    if ((spins & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+    if (spins < 20000) sched_yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
+static qd::HostSeg* host_map(int fd, size_t bytes) {
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  return p == MAP_FAILED ? nullptr : static_cast<qd::HostSeg*>(p);
+}
+
+// Bootstrap.  Rank 0 removes whatever carries the name, creates the segment exclusively and acknowledges every rank that says hello IN
+// THAT SEGMENT; a rank > 0 opens the name, says hello with a token of its own and proceeds only when it reads its token back.  A leftover
+// segment of a crashed job (or the one rank 0 is about to replace) never answers: the rank closes it after half a second and opens the
+// name again.  No clocks, no modification times.
+extern "C" int qd_comm_create_host(const char* name, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out) {
+  if (!name || !out || nranks < 1 || nranks > qd::kHostMaxRanks || rank < 0 || rank >= nranks)
+    return fail(QD_ERR_INVALID, "qd_comm_create_host: bad argument (at most " + std::to_string(qd::kHostMaxRanks) + " ranks)");
+  *out = nullptr;
+  static_assert(std::atomic<unsigned long long>::is_always_lock_free, "shared-memory flags must be lock-free");
+  const std::string shm = host_shm_name(name);
+  const size_t bytes = host_seg_bytes(nranks);
+  qd::HostSeg* seg = nullptr;
+  if (timeout_s <= 0.0) timeout_s = 600.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  if (rank == 0) {
+    (void)shm_unlink(shm.c_str());
+    const int fd = shm_open(shm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fail(QD_ERR_DEVICE, "qd_comm_create_host: shm_open(" + shm + "): " + strerror(errno));
+    if (ftruncate(fd, (off_t)bytes) != 0) {
+      close(fd);
+      (void)shm_unlink(shm.c_str());
+      return fail(QD_ERR_NOMEM, "qd_comm_create_host: cannot size the shared segment");
+    }
+    seg = host_map(fd, bytes);
+    close(fd);
+    if (!seg) {
+      (void)shm_unlink(shm.c_str());
+      return fail(QD_ERR_NOMEM, "qd_comm_create_host: mmap failed");
+    }
+    seg->token = random_token();
+    seg->nranks = nranks;
+    seg->magic.store(kHostMagic, std::memory_order_release);
+    std::vector<char> acked(nranks, 0);
+    acked[0] = 1;
+    const bool ok = spin_until([&] {
+      bool all = true;
+      for (int r = 1; r < nranks; r++) {
+        const unsigned long long h = seg->hello[r].v.load(std::memory_order_acquire);
+        if (h) {
+          seg->ack[r].v.store(h, std::memory_order_release);
+          acked[r] = 1;
+        }
+        all = all && acked[r];
+      }
+      return all;
+    }, timeout_s);
+    if (!ok) {
+      munmap(seg, bytes);
+      (void)shm_unlink(shm.c_str());
+      return fail(QD_ERR_STATE, "qd_comm_create_host: timed out waiting for the other ranks");
+    }
+  } else {
+    const unsigned long long mine = random_token();
+    for (;;) {
+      if (elapsed() > timeout_s) return fail(QD_ERR_STATE, "qd_comm_create_host: timed out waiting for rank 0's segment " + shm);
+      const int fd = shm_open(shm.c_str(), O_RDWR, 0600);
+      if (fd < 0) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        continue;
+      }
+      struct stat sb;
+      if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {  // not (yet) sized for this job
+        close(fd);
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        continue;
+      }
+      seg = host_map(fd, bytes);
+      close(fd);
+      if (!seg) return fail(QD_ERR_NOMEM, "qd_comm_create_host: mmap failed");
+      bool good = spin_until([&] { return seg->magic.load(std::memory_order_acquire) == kHostMagic; }, 0.5) && seg->nranks == nranks;
+      if (good) {
+        seg->hello[rank].v.store(mine, std::memory_order_release);
+        good = spin_until([&] { return seg->ack[rank].v.load(std::memory_order_acquire) == mine; }, 0.5);
+      }
+      if (good) break;
+      munmap(seg, bytes);  // a leftover, or rank 0 has not replaced it yet: look the name up again
+      seg = nullptr;
+    }
+  }
+  qd_comm* c = new qd_comm();
+  c->rank = rank;
+  c->nranks = nranks;
+  c->device = device_ordinal;
+  c->backend = 1;
+  c->host = new qd::HostRing();
+  c->host->seg = seg;
+  c->host->bytes = bytes;
+  c->host->name = shm;
+  c->host->rank = rank;
+  c->host->nranks = nranks;
+  c->host->timeout_s = timeout_s;
+  if (qd::use_device(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    c->stream = nullptr;  // (a host-only caller: the in-stream reductions will fail loudly, the host ones work)
+  }
+  *out = c;
+  return QD_OK;
+}
+
+// in-place all-reduce of a host buffer; every rank adds the slots up in rank order, so all ranks hold bit-identical results
+static int host_allreduce(qd::HostRing* g, double* buf, size_t n, int op) {
+  qd::HostSeg* s = g->seg;
+  for (size_t off = 0; off < n; off += qd::kHostSlot) {
+    const size_t m = std::min(qd::kHostSlot, n - off);
+    const unsigned long long seq = ++g->seq;
+    // my slot is free once every rank has finished reading the previous round
+    if (!spin_until([&] {
+          for (int r = 0; r < g->nranks; r++)
+            if (s->done[r].v.load(std::memory_order_acquire) < seq - 1) return false;
+          return true;
+        }, g->timeout_s))
+      return fail(QD_ERR_STATE, "qd_comm (host): timed out waiting for the previous round to drain");
+    std::memcpy(s->slot(g->rank), buf + off, sizeof(double) * m);
+    s->arrive[g->rank].v.store(seq, std::memory_order_release);
+    if (!spin_until([&] {
+          for (int r = 0; r < g->nranks; r++)
+            if (s->arrive[r].v.load(std::memory_order_acquire) < seq) return false;
+          return true;
+        }, g->timeout_s))
+      return fail(QD_ERR_STATE, "qd_comm (host): timed out waiting for the other ranks in an all-reduce (a rank died or called a different collective)");
+    const double* s0 = s->slot(0);
+    if (op == 1) {
+      for (size_t i = 0; i < m; i++) {
+        double a = s0[i];
+        for (int r = 1; r < g->nranks; r++) a = std::max(a, s->slot(r)[i]);
+        buf[off + i] = a;
+      }
+    } else {
+      for (size_t i = 0; i < m; i++) {
+        double a = s0[i];
+        for (int r = 1; r < g->nranks; r++) a += s->slot(r)[i];
+        buf[off + i] = a;
+      }
+    }
+    s->done[g->rank].v.store(seq, std::memory_order_release);
+  }
+  return QD_OK;
+}
+
+static void host_destroy(qd_comm* c) {
+  if (!c->host) return;
+  if (c->host->seg) munmap(c->host->seg, c->host->bytes);
+  if (c->rank == 0) (void)shm_unlink(c->host->name.c_str());  // (mappings of the other ranks stay valid until they unmap)
+  delete c->host;
+  c->host = nullptr;
+}
+
 static_assert(QD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "QD_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
 
 extern "C" int qd_comm_unique_id(unsigned char* id) {
@@ -126,11 +357,18 @@ extern "C" int qd_comm_create(const unsigned char* id, int rank, int nranks, int
   return QD_OK;
 }
 
-// Rank 0 writes the id to `path` (atomically: temporary name + rename), the others wait for the file.  The file carries a header
-// {magic, job nonce}: a leftover of a crashed run or the file of another job must not be mistaken for this job's id (ranks > 0 would
-// then block in ncclCommInitRank forever - the timeout only covers the wait for the file).  The nonce is a hash of the environment
-// variable QD_JOB_ID when the launcher sets one (the same for all ranks of a job); without it, files last modified more than two
-// minutes before this rank entered the call are treated as leftovers.  Rank 0 removes whatever is there before it publishes.
+// MPI-free bootstrap through a path every rank can see.
+//
+// Backend: QD_COMM_BACKEND = rccl | host, default: host when there are more ranks than visible GPUs (the ranks then share devices, which
+// RCCL refuses; they must be on one node), RCCL otherwise.  Host: the path only names the shared-memory segment (qd_comm_create_host).
+//
+// RCCL: rank 0 writes the ncclUniqueId to `path` (atomically: temporary name + rename); the file carries {magic, job nonce, token}.  A
+// leftover of a crashed run or the file of another job must not be mistaken for this job's id - a rank that calls ncclCommInitRank with
+// a dead id blocks forever - so the id is CONFIRMED before anyone uses it: every rank > 0 echoes the token it read into `path.ack<rank>`,
+// rank 0 waits for all echoes of ITS token and then publishes `path.go` with the token; a rank proceeds only on a go that carries the token
+// it holds and keeps re-reading the id file meanwhile (rank 0 removes leftovers of all three kinds before it publishes, so a rank that
+// picked up a stale id sees the new one and echoes again).  No modification times, no clock comparison between hosts.  The job nonce (hash
+// of QD_JOB_ID when the launcher sets one) additionally rejects files of other jobs outright.
 static unsigned long long job_nonce() {
   const char* j = getenv("QD_JOB_ID");
   if (!j) return 0ull;
@@ -139,46 +377,120 @@ static unsigned long long job_nonce() {
   return h ? h : 1ull;
 }
 
-extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out) {
-  if (!path || !out) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: null argument");
-  static const char magic[8] = {'Q', 'D', 'C', 'O', 'M', 'M', '0', '2'};
-  const unsigned long long nonce = job_nonce();
-  const time_t entered = time(nullptr);
+namespace {
+struct IdFile {
+  char magic[8];
+  unsigned long long nonce, token;
   unsigned char id[QD_COMM_ID_BYTES];
-  if (rank == 0) {
-    (void)remove(path);  // a leftover of an earlier run
-    int r = qd_comm_unique_id(id);
-    if (r) return r;
-    const std::string tmp = std::string(path) + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(magic, 1, sizeof magic, f) != sizeof magic || fwrite(&nonce, 1, sizeof nonce, f) != sizeof nonce ||
-        fwrite(id, 1, sizeof id, f) != sizeof id) {
-      if (f) fclose(f);
-      return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot write the id file");
+};
+const char kIdMagic[8] = {'Q', 'D', 'C', 'O', 'M', 'M', '0', '3'};
+
+bool write_atomically(const std::string& path, const void* data, size_t n) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = fwrite(data, 1, n, f) == n;
+  fclose(f);
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+    (void)remove(tmp.c_str());
+    return false;
+  }
+  return true;
+}
+bool read_whole(const std::string& path, void* data, size_t n) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const bool ok = fread(data, 1, n, f) == n;
+  fclose(f);
+  return ok;
+}
+}  // namespace
+
+extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out) {
+  if (!path || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: bad argument");
+  if (timeout_s <= 0.0) timeout_s = 600.0;
+  // backend
+  bool host = false;
+  if (const char* b = getenv("QD_COMM_BACKEND")) {
+    if (std::strcmp(b, "host") == 0) host = true;
+    else if (std::strcmp(b, "rccl") != 0 && std::strcmp(b, "auto") != 0)
+      return fail(QD_ERR_INVALID, std::string("QD_COMM_BACKEND: unknown backend ") + b + " (rccl | host | auto)");
+  }
+  if (!host && !(getenv("QD_COMM_BACKEND") && std::strcmp(getenv("QD_COMM_BACKEND"), "rccl") == 0)) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+      (void)hipGetLastError();
+      ndev = 0;
     }
-    fclose(f);
-    if (rename(tmp.c_str(), path) != 0) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish the id file");
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      FILE* f = fopen(path, "rb");
-      if (f) {
-        char m[8];
-        unsigned long long n2 = 0;
-        const bool ok = fread(m, 1, sizeof m, f) == sizeof m && fread(&n2, 1, sizeof n2, f) == sizeof n2 && fread(id, 1, sizeof id, f) == sizeof id;
-        struct stat sb;
-        const bool have_stat = fstat(fileno(f), &sb) == 0;
-        fclose(f);
-        const bool fresh = nonce ? n2 == nonce : (have_stat && difftime(entered, sb.st_mtime) <= 120.0);
-        if (ok && std::memcmp(m, magic, sizeof m) == 0 && fresh) break;
+    host = nranks > ndev;
+  }
+  if (host) {
+    // the segment is named after the path (all ranks of a job pass the same one) and the job id
+    std::string name = path;
+    if (const char* j = getenv("QD_JOB_ID")) name += std::string("_") + j;
+    unsigned long long h = 1469598103934665603ull;
+    for (char ch : name) h = (h ^ (unsigned char)ch) * 1099511628211ull;
+    return qd_comm_create_host(("f" + std::to_string(h)).c_str(), rank, nranks, device_ordinal, timeout_s, out);
+  }
+  const std::string idp = path, gop = idp + ".go";
+  const unsigned long long nonce = job_nonce();
+  const auto t0 = std::chrono::steady_clock::now();
+  auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+  IdFile f;
+  if (rank == 0) {
+    // leftovers of an earlier run
+    (void)remove(idp.c_str());
+    (void)remove(gop.c_str());
+    for (int r = 1; r < nranks; r++) (void)remove((idp + ".ack" + std::to_string(r)).c_str());
+    std::memcpy(f.magic, kIdMagic, sizeof f.magic);
+    f.nonce = nonce;
+    f.token = random_token();
+    int r = qd_comm_unique_id(f.id);
+    if (r) return r;
+    if (!write_atomically(idp, &f, sizeof f)) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish the id file");
+    for (int k = 1; k < nranks; k++) {
+      const std::string ap = idp + ".ack" + std::to_string(k);
+      for (;;) {
+        unsigned long long t = 0;
+        if (read_whole(ap, &t, sizeof t) && t == f.token) break;
+        if (expired()) {
+          (void)remove(idp.c_str());
+          return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank " + std::to_string(k) + " to confirm the id");
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
       }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-        return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank 0's id file (a file that is there but stale - other "
-                                  "QD_JOB_ID, or older than two minutes - does not count)");
-      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+    if (nranks > 1 && !write_atomically(gop, &f.token, sizeof f.token)) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish the go file");
+  } else {
+    const std::string ap = idp + ".ack" + std::to_string(rank);
+    unsigned long long echoed = 0;
+    for (;;) {
+      IdFile g;
+      if (read_whole(idp, &g, sizeof g) && std::memcmp(g.magic, kIdMagic, sizeof g.magic) == 0 && (!nonce || g.nonce == nonce)) {
+        if (g.token != echoed) {
+          f = g;
+          if (write_atomically(ap, &g.token, sizeof g.token)) echoed = g.token;
+        }
+      }
+      unsigned long long go = 0;
+      if (echoed && read_whole(gop, &go, sizeof go) && go == echoed) break;
+      if (expired())
+        return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank 0 (no id file of this job, or rank 0 never confirmed it)");
+      std::this_thread::sleep_for(std::chrono::milliseconds(10));
     }
   }
-  return qd_comm_create(id, rank, nranks, device_ordinal, out);
+  int r = qd_comm_create(f.id, rank, nranks, device_ordinal, out);
+  // the bootstrap files have served: every rank removes its echo, rank 0 the id (the go file stays until the next run's rank 0 removes it -
+  // a rank may still be on its way to read it)
+  if (rank > 0) (void)remove((idp + ".ack" + std::to_string(rank)).c_str());
+  else {
+    (void)remove(idp.c_str());
+    if (r == QD_OK && nranks > 1) {
+      // after ncclCommInitRank returned on rank 0 every rank has entered it, i.e. has read the go file
+      (void)remove(gop.c_str());
+    }
+  }
+  return r;
 }
 
 extern "C" void qd_comm_destroy(qd_comm* c) {
@@ -186,6 +498,8 @@ extern "C" void qd_comm_destroy(qd_comm* c) {
   (void)hipSetDevice(c->device);
   struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   c->dbuf.release();
+  c->hbuf.release();
+  host_destroy(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->comm)
     if (Rccl* R = rccl()) R->CommDestroy(c->comm);
@@ -194,14 +508,28 @@ extern "C" void qd_comm_destroy(qd_comm* c) {
 
 extern "C" int qd_comm_size(const qd_comm* c) {
   if (!c) return QD_ERR_INVALID;
+  if (c->backend == 1) return c->nranks;
   int n = 0;
   Rccl* R = rccl();
   if (!R || R->CommCount(c->comm, &n) != ncclSuccess) return QD_ERR_DEVICE;
   return n;
 }
 extern "C" int qd_comm_rank(const qd_comm* c) { return c ? c->rank : QD_ERR_INVALID; }
+extern "C" int qd_comm_backend(const qd_comm* c) { return c ? c->backend : QD_ERR_INVALID; }
 
 int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_t st) {
+  if (c->backend == 1) {
+    // host backend: the buffer makes one round trip through pinned memory; the stream waits for it (what follows on the stream sees the
+    // reduced values exactly as after ncclAllReduce)
+    int r;
+    if (n > c->hbuf.cap) QD_HIP(hipStreamSynchronize(st));  // (an upload from the old staging buffer may still be in flight)
+    if ((r = c->hbuf.ensure(n))) return r;
+    QD_HIP(hipMemcpyAsync(c->hbuf.p, dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    QD_HIP(hipStreamSynchronize(st));
+    if ((r = host_allreduce(c->host, c->hbuf.p, n, op))) return r;
+    QD_HIP(hipMemcpyAsync(dbuf, c->hbuf.p, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    return QD_OK;
+  }
   QD_RCCL_OR_FAIL(R);
   QD_NCCL(R, R->AllReduce(dbuf, dbuf, n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, st));
   return QD_OK;
@@ -211,6 +539,7 @@ int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_
 extern "C" int qd_comm_allreduce(qd_comm* c, double* buf, int n, int op) {
   if (!c || !buf || n < 0 || (op != 0 && op != 1)) return fail(QD_ERR_INVALID, "qd_comm_allreduce: bad argument");
   if (n == 0) return QD_OK;
+  if (c->backend == 1) return host_allreduce(c->host, buf, (size_t)n, op);
   QD_HIP(qd::use_device(c->device));
   int r;
   if ((r = c->dbuf.ensure(n))) return r;

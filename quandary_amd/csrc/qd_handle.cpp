@@ -350,6 +350,30 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
     std::copy(hc_re, hc_re + cr.size(), cr.begin());
     std::copy(hc_im, hc_im + ci.size(), ci.begin());
   }
+  // row sums for the Gershgorin bounds of the solver gates (row_bounds): H is Hermitian, so the row sums bound the column sums too
+  {
+    const int N = h->S.N;
+    auto rowsum_max = [&](const double* a, const double* b) {
+      double m = 0.0;
+      for (int i = 0; i < N; i++) {
+        double s = 0.0;
+        for (int j = 0; j < N; j++) s += hypot(a[(size_t)i * N + j], b[(size_t)i * N + j]);
+        m = std::max(m, s);
+      }
+      for (int j = 0; j < N; j++) {  // (and the column sums, should a caller hand over a non-Hermitian matrix)
+        double s = 0.0;
+        for (int i = 0; i < N; i++) s += hypot(a[(size_t)i * N + j], b[(size_t)i * N + j]);
+        m = std::max(m, s);
+      }
+      return m;
+    };
+    std::vector<double> zero(nn, 0.0);
+    h->dense_hsys_norm = rowsum_max(hsys_re, hsys_im);
+    h->dense_hc_norm.assign(h->S.Q, 0.0);
+    if (hc_re)
+      for (int k = 0; k < h->S.Q; k++)
+        h->dense_hc_norm[k] = rowsum_max(hc_re + (size_t)k * nn, zero.data()) + rowsum_max(hc_im + (size_t)k * nn, zero.data());
+  }
   int r;
   if ((r = h->d_g0.ensure(g0.size())) || (r = h->d_hcr.ensure(cr.size())) || (r = h->d_hci.ensure(ci.size()))) return r;
   QD_HIP(hipMemcpy(h->d_g0.p, g0.data(), sizeof(double) * g0.size(), hipMemcpyHostToDevice));
@@ -359,6 +383,7 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   h->S.hcr = h->d_hcr.p;
   h->S.hci = h->d_hci.p;
   h->S.gtab = nullptr;
+  h->sub_latch = -1;
   h->S.hasJ = 0;  // the file model replaces the standard one including the dipole-dipole terms (src/mastereq.cpp:273-284)
   h->params_dirty = true;
   h->traj_valid = false;
@@ -368,6 +393,7 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
 extern "C" int qd_set_option(qd_handle* h, const char* key, const char* value) {
   if (!h || !key || !value) return fail(QD_ERR_INVALID, "qd_set_option: null argument");
   if (h->opts.set(key, value) != 0) return fail(QD_ERR_INVALID, std::string("qd_set_option: unknown key or bad value: ") + key + " = " + value);
+  h->sub_latch = -1;
   h->traj_valid = false;  // (a stored trajectory may have another layout under the new options)
   return QD_OK;
 }
@@ -386,6 +412,7 @@ extern "C" int qd_set_precision(qd_handle* h, int precision) {
       return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps need a stepper of the IMR family");
   }
   h->precision = precision;
+  h->sub_latch = -1;
   h->traj_valid = false;
   return QD_OK;
 }
@@ -564,16 +591,59 @@ size_t qd_handle::ztraj_doubles(int nb) const {
   return n;
 }
 
-// Degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (Team::gmres_g): poly_cur (tuned from sweep to
-// sweep in forward_finish, starting at 6) where the series provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
-// sub-step, from the system constants and the CURRENT control parameters (|p_k(t)|, |q_k(t)| <= sum over carriers of
-// max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
-// by their amplitude).  The option gmres_poly overrides the degree (1 = never precondition).
+// max over time of |p_k(t)|, |q_k(t)| from the CURRENT control parameters: sum over carriers of max |alpha^1| + max |alpha^2| (the
+// quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96); pi-pulses by their amplitude
+double qd_handle::control_amplitude_bound(int k) const {
+  double amp = 0.0;
+  const DevOsc& o = oscs[k];
+  for (int b = 0; b < o.nseg; b++) {
+    const DevSeg& g = segs[o.seg_begin + b];
+    double a = 0.0;
+    for (int f = 0; f < o.ncar; f++) {
+      double m1 = 0.0, m2 = 0.0;
+      if (g.type == QD_CTRL_STEP) {
+        m1 = fabs(g.a1);
+        m2 = fabs(g.a2);
+      } else if (g.type == QD_CTRL_BSPLINEAMP) {
+        for (int l = 0; l < g.nsplines; l++) m1 = std::max(m1, fabs(params[o.offset + g.skip + f * g.npc + l]));
+        m2 = m1;
+      } else {
+        for (int l = 0; l < g.nsplines; l++) {
+          m1 = std::max(m1, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + l]));
+          m2 = std::max(m2, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + g.nsplines + l]));
+        }
+      }
+      a += m1 + m2;
+    }
+    amp = std::max(amp, a);
+  }
+  for (int i = 0; i < o.npulse; i++) amp = std::max(amp, fabs(pulses[(size_t)(o.pulse_begin + i) * 3 + 2]));
+  return amp;
+}
+
 // Gershgorin bounds of one row of M(t) over all sub-steps, from the system constants and the CURRENT control parameters:
 // diag = |Delta| + |d| (level energies, diagonal decay), off = the T1 off-diagonal entry, the control ladder entries (|p_k(t)|,
 // |q_k(t)| <= sum over carriers of max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity,
 // src/controlbasis.cpp:81-96; pi-pulses by their amplitude) and the dipole-dipole couplings.
 void qd_handle::row_bounds(double* diag, double* off) const {
+  if (S.dense) {
+    // user Hamiltonians (qd_set_hamiltonian): the standard-model constants do not describe the operator.  M = -i(I x H - H^T x I) +
+    // the standard decay terms, H(t) = Hsys + sum_k p_k Re-part + q_k Im-part of Hc_k (src/mastereq.cpp:743-830): a row of M is
+    // bounded by (2 x) the row sums of the uploaded matrices.
+    const double two = S.lindblad ? 2.0 : 1.0;
+    double dg = two * dense_hsys_norm, of = 0.0;
+    for (int k = 0; k < S.Q; k++) {
+      const double nm = S.n[k] - 1.0;
+      if (S.lindblad) {
+        dg += fabs(S.g2[k]) * nm * nm / 2.0 + fabs(S.g1[k]) * nm;
+        of += fabs(S.g1off[k]) * nm;
+      }
+      of += two * control_amplitude_bound(k) * (k < (int)dense_hc_norm.size() ? dense_hc_norm[k] : 0.0);
+    }
+    *diag = dg;
+    *off = of;
+    return;
+  }
   // max |h(I)| over the level combinations: a constant of the system (a million combinations for the reference's nlevels_32_32_32_32
   // case - 15 ms of host time per sweep when it was recomputed there)
   double hmax = hmax_cache;
@@ -601,30 +671,7 @@ void qd_handle::row_bounds(double* diag, double* off) const {
       of += fabs(S.g1off[k]) * nm;
     }
     // controls: each of the (2 or 4) ladder neighbours carries |q| + |p| times sqrt(level)
-    double amp = 0.0;
-    const DevOsc& o = oscs[k];
-    for (int b = 0; b < o.nseg; b++) {
-      const DevSeg& g = segs[o.seg_begin + b];
-      double a = 0.0;
-      for (int f = 0; f < o.ncar; f++) {
-        double m1 = 0.0, m2 = 0.0;
-        if (g.type == QD_CTRL_STEP) {
-          m1 = fabs(g.a1);
-          m2 = fabs(g.a2);
-        } else if (g.type == QD_CTRL_BSPLINEAMP) {
-          for (int l = 0; l < g.nsplines; l++) m1 = std::max(m1, fabs(params[o.offset + g.skip + f * g.npc + l]));
-          m2 = m1;
-        } else {
-          for (int l = 0; l < g.nsplines; l++) {
-            m1 = std::max(m1, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + l]));
-            m2 = std::max(m2, fabs(params[o.offset + g.skip + f * 2 * g.nsplines + g.nsplines + l]));
-          }
-        }
-        a += m1 + m2;
-      }
-      amp = std::max(amp, a);
-    }
-    for (int i = 0; i < o.npulse; i++) amp = std::max(amp, fabs(pulses[(size_t)(o.pulse_begin + i) * 3 + 2]));
+    const double amp = control_amplitude_bound(k);
     of += 2.0 * amp * (S.lindblad ? 2.0 : 1.0) * (sqrt(nm) + sqrt(std::max(nm - 1.0, 0.0)));
   }
   int pair = 0;
@@ -635,6 +682,11 @@ void qd_handle::row_bounds(double* diag, double* off) const {
   *off = of;
 }
 
+// Degree of the Neumann-polynomial right preconditioner of the global-memory GMRES (Team::gmres_g): poly_cur (tuned from sweep to
+// sweep in forward_finish, starting at 6) where the series provably contracts, else 1 (plain KSPGMRES + PCNONE).  Criterion: Gershgorin bound of ||alpha M(t)||_inf <= 0.7 for every
+// sub-step, from the system constants and the CURRENT control parameters (|p_k(t)|, |q_k(t)| <= sum over carriers of
+// max |alpha^1| + max |alpha^2|: the quadratic B-splines are a partition of unity, src/controlbasis.cpp:81-96; pi-pulses
+// by their amplitude).  The option gmres_poly overrides the degree (1 = never precondition).
 int qd_handle::gmres_poly_degree() const {
   const int want = opts.gmres_poly > 0 ? opts.gmres_poly : poly_cur;  // tuned in forward_finish
   // only where the Krylov basis traffic is the cost (dim > 1024: the column / eight-elements-per-thread kernels); below
@@ -670,7 +722,25 @@ bool qd_handle::gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const {
   double amax = 0.0;
   for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
   if (kappa2) *kappa2 = (1.0 + amax * dg) * (1.0 + amax * dg);
-  return opts.gmres_split == 1 || amax * of <= 0.3;
+  if (opts.gmres_split == 1) return true;
+  return latched_substitution(1, amax * of);
+}
+
+// The gates depend on the CURRENT control parameters, and an optimiser's line search compares objectives far below the solver
+// tolerance: a solver that changes between two evaluations shows up as a jump.  The decision is therefore latched per handle: taken at
+// the first sweep (bound <= 0.3), kept while the stationary iteration still provably contracts fast enough for the tripled iteration
+// cap (bound <= 0.6: 0.6^60 ~ 5e-14), and given up for good - Krylov kernels from then on - the first time it does not.  At most one
+// switch in the life of a handle; qd_set_option / qd_set_hamiltonian / qd_set_precision start over.
+bool qd_handle::latched_substitution(int kind, double bound) const {
+  if (sub_latch == -1) {
+    if (bound <= 0.3) sub_latch = kind;
+    else if (kind == 2) sub_latch = 0;  // (the split gate is asked first and leaves the decision to the Neumann gate)
+    return sub_latch == kind;
+  }
+  if (sub_latch != kind) return false;
+  if (bound <= 0.6) return true;
+  sub_latch = 0;
+  return false;
 }
 
 // The same for every other kernel family: where the reference's own Neumann iteration provably contracts fast - Gershgorin bound
@@ -685,7 +755,7 @@ bool qd_handle::gmres_as_neumann(const qd::LaunchCfg& cfg) const {
   row_bounds(&dg, &of);
   double amax = 0.0;
   for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
-  return amax * (dg + of) <= 0.3;
+  return latched_substitution(2, amax * (dg + of));
 }
 
 // Diagonal-split Neumann iteration (qd_col.hip): same fixed point and stopping rule, the diagonal of M on the left-hand side.  It
@@ -814,7 +884,9 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   last_var = cfg.var;
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
+  last_solver = sol.stepper == QD_STEPPER_EE ? QD_SOLVER_NONE : cfg.gmres ? QD_SOLVER_KRYLOV : QD_SOLVER_NEUMANN;
   if (gmres_as_split(cfg, &a.kappa2)) {  // GMRES request served by the diagonal-split iteration of the lean column kernels
+    last_solver = QD_SOLVER_GMRES_AS_SPLIT;
     cfg.gmres = 0;
     a.use_gmres = 0;
     a.neumann_split = 1;
@@ -824,6 +896,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     last_poly = 1;
     cfg.lds = pick_config(S, nb, opts, false).lds;
   } else if (gmres_as_neumann(cfg)) {
+    last_solver = QD_SOLVER_GMRES_AS_NEUMANN;
     cfg = pick_config(S, nb, opts, false);
     a.use_gmres = 0;
     a.gmres_poly = 1;
@@ -1014,7 +1087,9 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
   last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   a.use_gmres = cfg.gmres;
+  last_solver = sol.stepper == QD_STEPPER_EE ? QD_SOLVER_NONE : cfg.gmres ? QD_SOLVER_KRYLOV : QD_SOLVER_NEUMANN;
   if (gmres_as_split(cfg, &a.kappa2)) {
+    last_solver = QD_SOLVER_GMRES_AS_SPLIT;
     cfg.gmres = 0;
     a.use_gmres = 0;
     a.neumann_split = 1;
@@ -1023,6 +1098,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     last_poly = 1;
     cfg.lds = pick_config(S, nb, opts, false, true).lds;
   } else if (gmres_as_neumann(cfg)) {
+    last_solver = QD_SOLVER_GMRES_AS_NEUMANN;
     cfg = pick_config(S, nb, opts, false, true);
     a.use_gmres = 0;
     a.gmres_poly = 1;
@@ -1095,6 +1171,7 @@ extern "C" double qd_last_mean_applies(const qd_handle* h) { return h ? h->last_
 extern "C" double qd_last_forward_ms(const qd_handle* h) { return h ? h->last_fwd_ms : 0.0; }
 extern "C" double qd_last_adjoint_ms(const qd_handle* h) { return h ? h->last_adj_ms : 0.0; }
 extern "C" int qd_last_team(const qd_handle* h) { return h ? h->last_team : QD_ERR_INVALID; }
+extern "C" int qd_last_solver(const qd_handle* h) { return h ? h->last_solver : QD_ERR_INVALID; }
 
 // Measurement hook ("settle the MFMA question"): nrep chained applications of the forward operator
 // to nb copies... of a batch of states with the fp32 stencil kernel (mfma = 0) or with the dense Kronecker-factor

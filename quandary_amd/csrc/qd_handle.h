@@ -85,6 +85,9 @@ struct qd_handle {
   // *kappa2 = (1 + max alpha |D|)^2, the factor between the squared update norm and the bound of the squared residual
   bool gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const;
   bool gmres_as_neumann(const qd::LaunchCfg& cfg) const;  // ... by the plain Neumann iteration of any other kernel family
+  // the decision of the two gates, latched per handle: -1 undecided, 0 Krylov kernels, 1 diagonal-split iteration, 2 Neumann iteration
+  mutable int sub_latch = -1;
+  bool latched_substitution(int kind, double bound) const;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // forward / adjoint kernel brackets
   qd::DevSys S{};
@@ -101,6 +104,7 @@ struct qd_handle {
   double *d_carriers = nullptr, *d_pulses = nullptr;
   int ndesign = 0, dim_ess = 1;
   int last_team = 1;  // workgroups per initial condition of the last sweep (qd_big.h)
+  int last_solver = 0;  // QD_SOLVER_* of the last sweep (qd_last_solver)
   bool has_pipulse = false;
   bool has_ampbasis = false;  // a spline_amplitude segment: forward only (src/oscillator.cpp:350-356)
   std::vector<double> params;
@@ -129,6 +133,9 @@ struct qd_handle {
   qd::DBuf d_ecoef, d_edig, d_work;  // large states (qd_big.h): element table, work vectors
   int ensure_big(int nb);            // no-op unless the launch configuration is the large-state variant
   qd::DBuf d_g0, d_hcr, d_hci, d_gtab, d_gone;  // dense user-Hamiltonian path (qd_set_hamiltonian)
+  // infinity norms of the uploaded Hamiltonians (row_bounds: the standard-model constants say nothing about a user Hamiltonian)
+  double dense_hsys_norm = 0.0;
+  std::vector<double> dense_hc_norm;  // per oscillator: ||Re Hc_k||_inf + ||Im Hc_k||_inf
   // d_res = [pen nb | dpdm nb | out4 4nb | napply]: one contiguous block, one download per sweep
   double *d_pen = nullptr, *d_dpdm = nullptr, *d_out4 = nullptr;
   unsigned long long* d_napply = nullptr;
@@ -140,6 +147,7 @@ struct qd_handle {
   // ---- internal device-pointer API used by the objective level (qd_optim.cpp) -------------------
   int refresh_tables();
   mutable double hmax_cache = -1.0;  // max |h(I)| over the level combinations (system constant, computed on first use)
+  double control_amplitude_bound(int k) const;       // max_t |p_k(t)|, |q_k(t)| for the current parameters
   void row_bounds(double* diag, double* off) const;  // Gershgorin bounds of a row of M over all sub-steps (current parameters)
   int gmres_poly_degree() const;  // > 1 where the Neumann series provably contracts for the current parameters, else 1
   // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
@@ -174,12 +182,18 @@ struct qd_handle {
   const double* res_out4() const { return h_res.p + 2 * (size_t)last_nb; }
 };
 
-// RCCL communicator (qd_comm.cpp): one per process / GPU
+// Communicator (qd_comm.cpp): one per process.  Backend RCCL (one process per GPU, ncclAllReduce over xGMI on the handle's stream) or
+// HOST (ranks on one node reducing through a POSIX shared-memory segment: the same call sites, the same buffers, the same fixed summation
+// order on every rank - for ranks that share a GPU, which RCCL refuses, and for nodes without RCCL).
+namespace qd { struct HostRing; }
 struct qd_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1, device = 0;
+  int backend = 0;                // 0 RCCL, 1 host shared memory
+  qd::HostRing* host = nullptr;   // backend 1
   hipStream_t stream = nullptr;  // for the host-staged convenience calls; the sweeps reduce on the handle's stream
   qd::DBuf dbuf;
+  qd::HBuf hbuf;                 // backend 1: pinned staging buffer of the in-stream reductions
 };
 // in-place all-reduce of a device buffer on stream `st` (op 0 = sum, 1 = max); asynchronous
 int qd_comm_allreduce_dev(qd_comm* c, double* dbuf, size_t n, int op, hipStream_t st);

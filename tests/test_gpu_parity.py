@@ -9,7 +9,7 @@ north-star figure of 1e-8 relative on the gradient norm where noted.
 import numpy as np
 import pytest
 
-from helpers import REF_ATOL, REF_RTOL, golden_grad, golden_history, golden_rows, load_case, synthetic_spec
+from helpers import GMRES_MODES, REF_ATOL, REF_RTOL, SOLVERS, check_parity, golden_grad, golden_history, golden_rows, load_case, synthetic_spec, with_gmres_mode
 from oracle.oracle import Oracle
 from quandary_amd import capi
 
@@ -30,9 +30,12 @@ SHAPES = [
 ]
 
 
-def _pair(kw, **extra):
-    sp = synthetic_spec(**{**kw, **extra})
+def _pair(kw, gmres_mode=None, **extra):
+    sp = with_gmres_mode(synthetic_spec(**{**kw, **extra}), gmres_mode)
     return sp, capi.Handle(sp), Oracle(sp)
+
+
+STAND_INS = ("gmres_as_split", "gmres_as_neumann")
 
 
 @pytest.mark.parametrize("kw", SHAPES)
@@ -186,18 +189,18 @@ def test_diagonal_split_neumann_on_the_axc_system():
 
 
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[4], SHAPES[5], SHAPES[6], SHAPES[7]])
-def test_gmres_solver_vs_oracle_gmres(kw, monkeypatch):
+def test_gmres_solver_vs_oracle_gmres(kw):
     """linearsolver_type = gmres: in-kernel GMRES against the oracle's GMRES.  Small systems keep the Krylov
     basis in LDS; the 3x20 (column kernel, 8 elements/thread) and 2^5 (4 elements/thread) systems keep it
     in global memory (option gmres_split = 0: the Krylov kernels, not the stationary iteration that serves such requests by default)."""
-    monkeypatch.setenv("QD_GMRES_SPLIT", "0")
     if kw["nlevels"] == [3, 20]:
         kw = {**kw, "init": "basis, 0"}
     if kw["nlevels"] == [2, 2, 2, 2, 2]:
         kw = {**kw, "init": "diagonal, 0, 1"}
-    sp, h, orc = _pair(kw, ntime=30, linsolve="gmres", penalties=True, dt=0.05)
+    sp, h, orc = _pair(kw, gmres_mode="0", ntime=30, linsolve="gmres", penalties=True, dt=0.05)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == "krylov"
     oval, og = orc.evalGradF(sp.params0)
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
@@ -219,8 +222,7 @@ def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
     stopping rule on the same true residual, so objective and gradient agree with the oracle either way."""
     from quandary_amd.workloads import workload_spec
     monkeypatch.setenv("QD_GMRES_POLY", poly)
-    monkeypatch.setenv("QD_GMRES_SPLIT", "0")
-    sp = workload_spec("c4", "gradient", {"ntime": 20, "linearsolver_type": "gmres", "initialcondition": "basis, 0"})
+    sp = with_gmres_mode(workload_spec("c4", "gradient", {"ntime": 20, "linearsolver_type": "gmres", "initialcondition": "basis, 0"}), "0")
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
@@ -249,6 +251,7 @@ def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == "gmres_as_split"
     oval, og = orc.evalGradF(sp.params0)
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
@@ -329,6 +332,8 @@ def test_gmres_request_served_by_the_neumann_iteration(kw):
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
+    # (the 10x10 state runs on the global-memory kernels, whose stand-in is the diagonal-split iteration with the exact residual norm)
+    assert h.last_solver == ("gmres_as_split" if kw["nlevels"] == [10, 10] else "gmres_as_neumann")
     oval, og = orc.evalGradF(sp.params0)
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
@@ -340,6 +345,7 @@ def test_gmres_request_served_by_the_neumann_iteration(kw):
     # the Krylov kernels on the same problem give the same answer
     h.set_option("gmres_split", 0)
     val2, g2 = opt.evalGradF(sp.params0)
+    assert h.last_solver == "krylov"
     assert val2["objective"] == pytest.approx(val["objective"], rel=1e-9)
     assert np.linalg.norm(g2 - g) <= 1e-8 * np.linalg.norm(g) + SOLVER_NOISE_ABS
     opt.close(); h.close(); orc.close()
@@ -373,13 +379,15 @@ def test_other_steppers_column_layout(stepper, monkeypatch):
 
 
 @pytest.mark.parametrize("levels", [5, 6])
-@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
-def test_large_schroedinger_state(linsolve, levels):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_large_schroedinger_state(solver, levels):
     """Schroedinger beyond 256 elements: 5^4 = 625 (four elements per thread, V2, hoisted ladder coefficients) and
     6^4 = 1296 (eight elements per thread, V4, explicit staging); Neumann and GMRES with the Krylov basis in
     global memory."""
+    linsolve, mode = solver
     sp, h, orc = _pair(dict(nlevels=[levels] * 4, lindblad=False, nessential=[2, 2, 2, 2], jkl=0.002, detuned=True,
-                            init="pure, 1, 0, 1, 0", target="pure", objective="Jmeasure"), ntime=8, nspline=6, linsolve=linsolve, penalties=True)
+                            init="pure, 1, 0, 1, 0", target="pure", objective="Jmeasure"), gmres_mode=mode, ntime=8, nspline=6, linsolve=linsolve,
+                       penalties=True)
     assert h.dim == levels ** 4
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
@@ -426,11 +434,12 @@ DENSE_SHAPES += [
 
 
 @pytest.mark.parametrize("kw", DENSE_SHAPES)
-@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
-def test_user_hamiltonian_operator_vs_oracle(kw, linsolve):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_user_hamiltonian_operator_vs_oracle(kw, solver):
     """qd_set_hamiltonian (dense Hsys / Hc_k instead of the standard model): operator, transpose, objective
     and gradient against the oracle's restatement of the reference's sparse-matrix formulas."""
-    sp = synthetic_spec(**{**kw, "ntime": 12, "penalties": True, "linsolve": linsolve, "dt": 0.004})
+    linsolve, mode = solver
+    sp = with_gmres_mode(synthetic_spec(**{**kw, "ntime": 12, "penalties": True, "linsolve": linsolve, "dt": 0.004}), mode)
     n = int(np.prod(kw["nlevels"]))
     sp.hamiltonian = _random_hamiltonians(n, len(kw["nlevels"]), 11)
     h, orc = capi.Handle(sp), Oracle(sp)
@@ -450,6 +459,53 @@ def test_user_hamiltonian_operator_vs_oracle(kw, linsolve):
     for k in OBJ_KEYS:
         assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
     assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw,scale,dt,want", [
+    pytest.param(dict(nlevels=[2, 2], lindblad=False), 40.0, 0.05, "krylov", id="2x2-schroedinger-alpha|H|~3"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=True), 6.0, 0.02, "krylov", id="2x2-lindblad-alpha|M|~0.7"),
+    pytest.param(dict(nlevels=[3, 4], lindblad=True, nessential=[2, 3], target="pure", objective="Jfrobenius"), 8.0, 0.01, "krylov", id="3x4-lindblad-alpha|M|~0.6"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=True), 1.0, 0.004, "gmres_as_neumann", id="2x2-lindblad-small-norm"),
+])
+def test_gmres_gate_uses_the_norm_of_the_user_hamiltonian(kw, scale, dt, want):
+    """linearsolver_type = gmres with the DEFAULT options on a qd_set_hamiltonian system: the gate that hands such requests to the
+    Neumann iteration must bound the uploaded Hsys / Hc_k (the standard-model constants of the config say nothing about them).  With
+    alpha ||M|| near or above 1 the Neumann series stalls or diverges where GMRES converges: the request must reach the Krylov kernels
+    and agree with the oracle's GMRES; with a small norm it is served by the Neumann iteration as on the standard model."""
+    sp = synthetic_spec(**{**kw, "ntime": 10, "penalties": True, "linsolve": "gmres", "dt": dt, "maxiter": 40})
+    n = int(np.prod(kw["nlevels"]))
+    hsys, hc = _random_hamiltonians(n, len(kw["nlevels"]), 17)
+    sp.hamiltonian = (scale * hsys, hc)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == want
+    oval, og = orc.evalGradF(sp.params0)
+    check_parity(sp, val, g, oval, og)
+    opt.close(); h.close(); orc.close()
+
+
+def test_solver_substitution_is_latched_per_handle():
+    """The gates look at the current control parameters; an optimiser must not see the solver change between two evaluations of a line
+    search.  The decision is taken at the first sweep and kept while the iteration still contracts (bound <= 0.6); beyond that the
+    handle goes to the Krylov kernels for good; qd_set_option starts over."""
+    sp, h, orc = _pair(dict(nlevels=[2, 2, 2], lindblad=True), ntime=10, linsolve="gmres", penalties=True)
+    opt = capi.Optim(h, sp)
+    opt.evalF(sp.params0)
+    assert h.last_solver == "gmres_as_neumann"
+    opt.evalF(8.0 * sp.params0)  # bound between 0.3 and 0.6: a fresh handle would say Krylov, this one keeps its iteration
+    kept = h.last_solver
+    opt.evalF(400.0 * sp.params0)  # far beyond: Krylov kernels, and they stay
+    assert h.last_solver == "krylov"
+    opt.evalF(sp.params0)
+    assert h.last_solver == "krylov"
+    h.set_option("gmres_split", "auto")
+    val = opt.evalF(sp.params0)
+    assert h.last_solver == "gmres_as_neumann"
+    assert kept in ("gmres_as_neumann", "krylov")
+    oval = orc.evalF(sp.params0)[0]
+    assert val["objective"] == pytest.approx(oval["objective"], rel=REF_RTOL)
     opt.close(); h.close(); orc.close()
 
 
@@ -493,12 +549,69 @@ def _random_case(seed):
                 penalties=bool(rng.integers(0, 2)), dt=float(rng.choice([0.01, 0.02])))
 
 
-@pytest.mark.parametrize("seed", range(96))
-def test_random_configurations_vs_oracle(seed):
+def _seeds_with_modes(seeds, case=None):
+    """(seed, gmres_split) pairs: a case that asks for gmres runs under the default and on the Krylov kernels, any other case once."""
+    out = []
+    for sd in seeds:
+        kw = (case or _random_case)(sd)
+        modes = GMRES_MODES if kw["linsolve"] == "gmres" and kw["stepper"] != "EE" else [None]
+        out += [pytest.param(sd, m, id=f"{sd}" + ("" if m is None else "-gmres-default" if m == "auto" else "-gmres-krylov")) for m in modes]
+    return out
+
+
+# Evaluations whose deviation from the oracle exceeds the plain tolerance of the sweep below (gradient 1e-8 of its norm + 1e-13, objective
+# 1e-7): all gmres requests.  profiles/seed_sweep.py over seeds 1000..1399 under both gmres_split settings found 21 (default) + 6 (Krylov
+# kernels) of 2 x 133 gmres cases (profiles/r4_seed_sweep_tight_oracle.jsonl); three of the suite's own 96 seeds (60, 68, 81 under the default)
+# are of the same kind.  They are NOT exempted: test_deviations_beyond_the_tolerance_are_the_oracles_own_stopping_error holds each of them
+# against a TIGHT oracle - the same restatement with every linear system solved to abstol 1e-14 - and requires the HIP path to be at least
+# as close to it as the reference-tolerance oracle is.
+STOPPING_ERROR_CASES = [(60, "auto"), (68, "auto"), (81, "auto"),
+                        (1004, "auto"), (1007, "0"), (1007, "auto"), (1020, "auto"), (1038, "auto"), (1040, "auto"), (1045, "0"), (1045, "auto"),
+                        (1056, "auto"), (1060, "auto"), (1065, "0"), (1065, "auto"), (1068, "0"), (1068, "auto"), (1071, "0"), (1071, "auto"),
+                        (1094, "auto"), (1114, "auto"), (1139, "auto"), (1145, "auto"), (1211, "auto"), (1255, "auto"), (1290, "auto"),
+                        (1308, "0"), (1308, "auto"), (1350, "auto"), (1353, "auto")]
+
+
+def _tight_spec(kw):
+    """The same problem with the linear systems solved to round-off: GMRES, abstol 1e-14, no iteration cap that matters."""
+    sp = synthetic_spec(**kw)
+    sp.solver.abstol = 1e-14
+    sp.solver.maxiter = 200
+    sp.solver.linsolve = capi.LINSOLVE["gmres"]
+    return sp
+
+
+@pytest.mark.parametrize("seed,mode", [pytest.param(sd, m, id=f"{sd}-gmres-" + ("default" if m == "auto" else "krylov")) for sd, m in STOPPING_ERROR_CASES])
+def test_deviations_beyond_the_tolerance_are_the_oracles_own_stopping_error(seed, mode):
+    """Both solvers stop at residual <= abstol = 1e-10 (src/timestepper.cpp:535-550); where the gradient norm is small, or the time grid
+    long, that stopping error alone exceeds 1e-8 of the gradient norm.  Against the exact solution of the discrete problem (tight oracle) the
+    HIP path must be no farther away than the reference-tolerance oracle (the restated reference) is: factor 1.25 for the Krylov kernels,
+    whose classical Gram-Schmidt and the oracle's modified one stop at slightly different points of the same method, plus 1 % of abstol.
+    Measured (profiles/r4_seed_sweep_tight_oracle.jsonl): the stationary stand-ins are 4x ... 1000x CLOSER to the exact solution than the
+    oracle's GMRES, the Krylov kernels within 2 % of it."""
+    kw = _random_case(seed)
+    assert kw["linsolve"] == "gmres"
+    sp = with_gmres_mode(synthetic_spec(**kw), mode)
+    h, orc, tight = capi.Handle(sp), Oracle(sp), Oracle(_tight_spec(kw))
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    tval, tg = tight.evalGradF(sp.params0)
+    assert (h.last_solver in STAND_INS) or mode == "0" or seed == 1308  # (1308: the gate keeps the Krylov kernels - same numbers under both settings)
+    for k in OBJ_KEYS:
+        assert abs(val[k] - tval[k]) <= 1.25 * abs(oval[k] - tval[k]) + 1e-12 * max(1.0, abs(tval[k])), (k, kw)
+    assert np.linalg.norm(g - tg) <= 1.25 * np.linalg.norm(og - tg) + 1e-12, kw
+    # ... and the deviation from the oracle is itself at solver-tolerance level
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 5.0 * 1e-10, kw
+    opt.close(); h.close(); orc.close(); tight.close()
+
+
+@pytest.mark.parametrize("seed,mode", [p for p in _seeds_with_modes(range(96)) if (p.values[0], p.values[1]) not in STOPPING_ERROR_CASES])
+def test_random_configurations_vs_oracle(seed, mode):
     """Seeded sweep over system shapes (1-3 oscillators, 2-5 levels, guard levels, coupling), objectives, initial
     conditions, steppers, solvers and penalties: objective parts and gradient of the HIP path against the oracle."""
     kw = _random_case(seed)
-    sp = synthetic_spec(**kw)
+    sp = with_gmres_mode(synthetic_spec(**kw), mode)
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
@@ -521,10 +634,10 @@ SOLVER_NOISE_ABS = 3e-11  # 0.3 x abstol of the linear solves
 
 
 @pytest.mark.parametrize("seed", NOISE_FLOOR_SEEDS)
-def test_random_configurations_at_the_solver_noise_floor(seed):
+def test_random_configurations_at_the_solver_noise_floor(seed, gmres_mode):
     kw = _random_case(seed)
     assert kw["linsolve"] == "gmres" and not kw["lindblad"]
-    sp = synthetic_spec(**kw)
+    sp = with_gmres_mode(synthetic_spec(**kw), gmres_mode)
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
@@ -582,11 +695,12 @@ FAMILY_CASES = [
 
 
 @pytest.mark.parametrize("kw", FAMILY_CASES)
-@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
-def test_initial_condition_and_gate_families(kw, linsolve):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_initial_condition_and_gate_families(kw, solver):
     """The initial-condition families (3states, Nplus1, ensemble, performance) and gates (swap, swap0q, cqnot, hadamard,
     ygate, zgate) that the random sweep does not draw: objective parts and gradient against the oracle."""
-    sp, h, orc = _pair(kw, ntime=14, penalties=True, linsolve=linsolve, dt=0.02)
+    linsolve, mode = solver
+    sp, h, orc = _pair(kw, gmres_mode=mode, ntime=14, penalties=True, linsolve=linsolve, dt=0.02)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     oval, og = orc.evalGradF(sp.params0)
@@ -618,10 +732,8 @@ def test_explicit_euler_schroedinger_gradient(kw):
     opt.close(); h.close(); orc.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_random_user_hamiltonians_vs_oracle(seed):
-    """Seeded sweep of the dense-operator path: random level structures (every third one a 16 x 16 density
-    matrix = the matrix-core kernel), random Hermitian Hsys / Hc_k, objectives, solvers, penalties."""
+def _random_dense_case(seed):
+    """Random level structure (every third one a 16 x 16 density matrix = the matrix-core kernel), objective, solver, penalties."""
     rng = np.random.default_rng(5000 + seed)
     lind = bool(rng.integers(0, 2)) or seed % 3 == 0
     if seed % 3 == 0:
@@ -633,18 +745,23 @@ def test_random_user_hamiltonians_vs_oracle(seed):
             if int(np.prod(nl)) <= (30 if lind else 200):
                 break
     objective = ["Jtrace", "Jfrobenius", "Jmeasure"][int(rng.integers(0, 3))]
-    kw = dict(nlevels=nl, lindblad=lind, target="pure", objective=objective, init="diagonal" if int(np.prod(nl)) <= 64 else "pure, " + ", ".join(["0"] * len(nl)),
-              ntime=int(rng.integers(6, 14)), nspline=int(rng.integers(4, 8)), linsolve=str(rng.choice(["neumann", "gmres"])),
-              stepper=str(rng.choice(["IMR", "IMR", "IMR4"])), penalties=bool(rng.integers(0, 2)), dt=0.004)
-    sp = synthetic_spec(**kw)
+    return dict(nlevels=nl, lindblad=lind, target="pure", objective=objective, init="diagonal" if int(np.prod(nl)) <= 64 else "pure, " + ", ".join(["0"] * len(nl)),
+                ntime=int(rng.integers(6, 14)), nspline=int(rng.integers(4, 8)), linsolve=str(rng.choice(["neumann", "gmres"])),
+                stepper=str(rng.choice(["IMR", "IMR", "IMR4"])), penalties=bool(rng.integers(0, 2)), dt=0.004)
+
+
+@pytest.mark.parametrize("seed,mode", _seeds_with_modes(range(24), _random_dense_case))
+def test_random_user_hamiltonians_vs_oracle(seed, mode):
+    """Seeded sweep of the dense-operator path: random level structures, random Hermitian Hsys / Hc_k, objectives, solvers, penalties."""
+    kw = _random_dense_case(seed)
+    nl = kw["nlevels"]
+    sp = with_gmres_mode(synthetic_spec(**kw), mode)
     sp.hamiltonian = _random_hamiltonians(int(np.prod(nl)), len(nl), 100 + seed)
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     oval, og = orc.evalGradF(sp.params0)
-    for k in OBJ_KEYS:
-        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-11), (k, kw)
-    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13, kw
+    assert check_parity(sp, val, g, oval, og, obj_abs=1e-11, msg=kw) == "plain" or h.last_solver in STAND_INS
     opt.close(); h.close(); orc.close()
 
 
@@ -663,8 +780,8 @@ def test_forward_states_and_trajectory():
 
 # ---- the reference's own golden regression outputs, through the C ABI --------------------------------
 @pytest.mark.parametrize("case", ["AxC", "AxC_initDiag0", "AxC_initEnsemble", "AxC_initFile", "pipulse"])
-def test_golden_forward(case):
-    sp = load_case(case)
+def test_golden_forward(case, gmres_mode):
+    sp = with_gmres_mode(load_case(case), gmres_mode)
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     val = opt.evalF(sp.params0)
@@ -674,9 +791,9 @@ def test_golden_forward(case):
     opt.close(); h.close()
 
 
-def test_golden_axc_trajectory():
+def test_golden_axc_trajectory(gmres_mode):
     case = "AxC"
-    sp = load_case(case)
+    sp = with_gmres_mode(load_case(case), gmres_mode)
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     x0, _ = opt.initial_state(0)
@@ -695,8 +812,8 @@ def test_golden_axc_trajectory():
 # fact 10); the golden file is produced by the reference's sparse-matrix path with GMRES, the device
 # solves the same systems with the Neumann iteration.  Absolute agreement is ~1e-10.
 @pytest.mark.parametrize("case,grad_rtol", [("AxC_grad_initBasis0", 1e-8), ("AxC_grad_schroedinger", 1e-8), ("xgate_sparsemat", 1e-6)])
-def test_golden_gradient(case, grad_rtol):
-    sp = load_case(case)
+def test_golden_gradient(case, grad_rtol, gmres_mode):
+    sp = with_gmres_mode(load_case(case), gmres_mode)
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
@@ -710,8 +827,8 @@ def test_golden_gradient(case, grad_rtol):
 
 
 @pytest.mark.parametrize("case", ["cnot", "xgate", "state-to-state_spline0"])
-def test_golden_optimization_iteration0(case):
-    sp = load_case(case)
+def test_golden_optimization_iteration0(case, gmres_mode):
+    sp = with_gmres_mode(load_case(case), gmres_mode)
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     x0 = np.clip(sp.params0, -sp.bounds, sp.bounds)
@@ -796,11 +913,12 @@ BIG_SHAPES = [
 
 
 @pytest.mark.parametrize("kw", BIG_SHAPES)
-@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
-def test_states_beyond_lds_vs_oracle(kw, linsolve):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_states_beyond_lds_vs_oracle(kw, solver):
     """dim > 4096 (was QD_ERR_UNSUPPORTED in round 1): the work vectors of a step live in global memory (qd_big.h).
     Operator, transpose, objective parts and gradient against the oracle, all penalties on, both linear solvers."""
-    sp, h, orc = _pair(kw, ntime=4, nspline=5, penalties=True, linsolve=linsolve)
+    linsolve, mode = solver
+    sp, h, orc = _pair(kw, gmres_mode=mode, ntime=4, nspline=5, penalties=True, linsolve=linsolve)
     assert h.dim > 4096
     rng = np.random.default_rng(21)
     h.set_params(sp.params0)
@@ -820,19 +938,20 @@ def test_states_beyond_lds_vs_oracle(kw, linsolve):
 
 
 @pytest.mark.parametrize("kw", [SHAPES[0], SHAPES[1], SHAPES[5], SHAPES[6], SHAPES[7], SHAPES[8], COL_SHAPES[3]])
-@pytest.mark.parametrize("stepper,linsolve", [("IMR", "neumann"), ("IMR4", "neumann"), ("IMR", "gmres")])
-def test_global_memory_variant_forced_onto_small_systems(kw, stepper, linsolve, monkeypatch):
+@pytest.mark.parametrize("stepper,linsolve,mode", [("IMR", "neumann", None), ("IMR4", "neumann", None), ("IMR", "gmres", "auto"), ("IMR", "gmres", "0")])
+def test_global_memory_variant_forced_onto_small_systems(kw, stepper, linsolve, mode, monkeypatch):
     """The same kernels (QD_VAR=16) on the small shapes of the LDS kernels: guard levels, dipole-dipole coupling, gates,
     every penalty (leakage, weighted-J incl. the Schroedinger Jtrace reduction, dpdm), several initial conditions."""
     monkeypatch.setenv("QD_VAR", "16")
-    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
+    sp, h, orc = _pair(kw, gmres_mode=mode, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     oval, og = orc.evalGradF(sp.params0)
-    for k in OBJ_KEYS:
-        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
-    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
-    if linsolve == "gmres":  # KSPGMRES + PCNONE iteration for iteration
+    # (dt = 0.05: stiff in the level energies, not in the couplings - under the default options the diagonal-split iteration serves the
+    # request on most of these shapes; where the oracle's GMRES stopping error exceeds 1e-8 of the gradient norm the exact discrete
+    # solution decides, helpers.check_parity)
+    assert check_parity(sp, val, g, oval, og, grad_abs=0.0) == "plain" or h.last_solver in STAND_INS
+    if h.last_solver == "krylov":  # KSPGMRES + PCNONE iteration for iteration
         orc.reset_stats()
         orc.evalF(sp.params0)
         opt.evalF(sp.params0)
@@ -1074,10 +1193,11 @@ CTRL_CASES = [
 
 
 @pytest.mark.parametrize("kw", CTRL_CASES)
-@pytest.mark.parametrize("linsolve", ["neumann", "gmres"])
-def test_step_control_basis_vs_oracle(kw, linsolve):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_step_control_basis_vs_oracle(kw, solver):
     """Step parameterisation (src/controlbasis.cpp:186-216): controls, objective and the gradient with respect to the step width."""
-    sp, h, orc = _pair(kw, ntime=40, penalties=True, linsolve=linsolve)
+    linsolve, mode = solver
+    sp, h, orc = _pair(kw, gmres_mode=mode, ntime=40, penalties=True, linsolve=linsolve)
     a = sp.params0.copy()
     h.set_params(a)
     orc.set_params(a)
@@ -1126,8 +1246,8 @@ TEAM_CASES = [
 
 @pytest.mark.parametrize("kw", TEAM_CASES)
 @pytest.mark.parametrize("team,spread,blocked", [(2, 0, 1), (8, 0, 0), (32, 0, 1), (4, 1, 2), (64, 1, 2), (64, 1, 0), (16, 1, 1)])
-@pytest.mark.parametrize("stepper,linsolve", [("IMR", "neumann"), ("IMR4", "gmres")])
-def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, blocked, stepper, linsolve, monkeypatch):
+@pytest.mark.parametrize("stepper,linsolve,mode", [("IMR", "neumann", None), ("IMR4", "gmres", "auto"), ("IMR4", "gmres", "0")])
+def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, blocked, stepper, linsolve, mode, monkeypatch):
     """Several workgroups per initial condition (qd_big.h: team barriers and team reductions through global memory, members on one
     XCD or dealt over all of them), forced onto small systems so that every penalty, guard levels, couplings and both solvers run
     through the team path, with the three element-to-member maps (big_blocked); compared with the oracle like every other kernel."""
@@ -1135,7 +1255,7 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, blocked,
     monkeypatch.setenv("QD_BIG_TEAM", str(team))
     monkeypatch.setenv("QD_BIG_SPREAD", str(spread))
     monkeypatch.setenv("QD_BIG_BLOCKED", str(blocked))
-    sp, h, orc = _pair(kw, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
+    sp, h, orc = _pair(kw, gmres_mode=mode, ntime=12, penalties=True, stepper=stepper, linsolve=linsolve, dt=0.05 if linsolve == "gmres" else 0.01)
     opt = capi.Optim(h, sp)
     nb = opt.ninit
     if (nb if spread else (nb + 7) // 8 * 8) * team > 256:
@@ -1144,10 +1264,8 @@ def test_teams_of_workgroups_on_one_initial_condition(kw, team, spread, blocked,
     val, g = opt.evalGradF(sp.params0)
     assert h.last_team == team
     oval, og = orc.evalGradF(sp.params0)
-    for k in OBJ_KEYS:
-        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
-    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
-    if linsolve == "gmres":
+    assert check_parity(sp, val, g, oval, og, grad_abs=0.0) == "plain" or h.last_solver in STAND_INS
+    if h.last_solver == "krylov":
         orc.reset_stats()
         orc.evalF(sp.params0)
         opt.evalF(sp.params0)
@@ -1191,12 +1309,12 @@ def test_diagonal_split_iteration_of_the_global_memory_kernels(kw, stepper, lins
 
 
 @pytest.mark.parametrize("name,ntime,team", [("n4444", 25, 1), ("n32", 2, 256)])
-def test_reference_performance_workloads_vs_oracle(name, ntime, team):
+def test_reference_performance_workloads_vs_oracle(name, ntime, team, gmres_mode):
     """The reference's own performance cases (tests/performance/test_cases.json): nlevels_4_4_4_4 and nlevels_32_32_32_32 - Schroedinger,
     four oscillators, dipole-dipole coupling on all six pairs, one pure state, GMRES; the second has a state of dimension 2^20 (a team
     of 256 workgroups through L2, qd_big.h).  Objective parts and gradient against the oracle at a small number of steps."""
     from quandary_amd.workloads import workload_spec
-    sp = workload_spec(name, "gradient", {"ntime": ntime})
+    sp = with_gmres_mode(workload_spec(name, "gradient", {"ntime": ntime}), gmres_mode)
     h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
