@@ -20,9 +20,11 @@ Lindblad time-steps x initial-conditions per second, whole job.
                                    contiguously over the GPUs (iinit_global = rank*nlocal + i, src/optimproblem.cpp:248),
                                    the seven objective sums are all-reduced with RCCL (src/optimproblem.cpp:292-298) - so
                                    value(N) / value(1) of the default lines is the speed-up of one workload.  The same run
-                                   also times the gradient evaluation (ntime 500 so that the stored stages fit one GPU;
+                                   also times the gradient evaluation at the same full size (stored stages beyond HBM are
+                                   handled by propagating and reversing the shard in chunks of initial conditions, one pass;
                                    sums and gradient all-reduced with RCCL, src/optimproblem.cpp:454-460, :527) and reports
                                    it under "gradient" with its own one-GPU point; `--mode grad` makes it the timed step.
+                                   One GPU: the same gradient evaluation is reported under "gradient" as well.
   --shard-of N                     one GPU: time shard 0 of N of the workload (ninit / N initial conditions) - the strong-scaling
                                    curve minus the two all-reduces, measurable without an N-GPU node.
   --scaling weak                   every GPU propagates one full set of the workload's initial conditions (the
@@ -46,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3  # same guide: FP32 vector = FP32 matrix peak (spec)
+FP64_PEAK_TFLOPS = 78.6   # AMD's public FP64 vector spec (the guide lists none); the device's sustained v_fma_f64 rate is MEASURED next to it
 
 
 # ------------------------------------------------------------------------------------------------
@@ -313,25 +316,36 @@ class Runner:
             f_step = 2.0 * f_step + f_apply
         valu_peak = FP32_PEAK_TFLOPS if self.dtype == "f32mixed" else fp64_peak
         valu_achieved = f_step * units_per_launch / kern_s / 1e12
+        vk = "fp32_valu" if self.dtype == "f32mixed" else "fp64_valu"
+        spec_peak = FP32_PEAK_TFLOPS if self.dtype == "f32mixed" else FP64_PEAK_TFLOPS
+        traffic = pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_gmres" if spec.solver.linsolve == 0 else ""),
+                              self.mode, units_per_launch)
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_unit": alg_bytes}
+        valu = {"achieved": valu_achieved, "peak": spec_peak, "unit": "TFLOP/s", "frac": valu_achieved / spec_peak,
+                "peak_measured": valu_peak, "frac_of_measured": valu_achieved / valu_peak if valu_peak > 0 else None, "flops_per_unit": f_step,
+                "peak_kind": ("FP32 vector peak, MI355X_MICROARCH.md" if self.dtype == "f32mixed" else
+                              "78.6 TFLOP/s = AMD's FP64 vector spec; peak_measured = v_fma_f64 micro-benchmark on this device (qd_measure_fp64_peak)"),
+                "active_cu_frac": min(1.0, ninit_local / 256.0)}
+        # Which roof binds: the fused step keeps the state on the chip, so the sweep kernels move FEWER HBM bytes than the algorithmic
+        # 32 dim B per unit (PMC traffic below that figure) and run against the vector-issue roof; a kernel that streams its vectors
+        # through HBM (traffic at or above the algorithmic bytes: stored trajectories, Krylov bases, states beyond LDS) is HBM-bound.
+        hbm_bound = traffic is not None and traffic >= alg_bytes * units_per_launch and hbm["frac"] >= valu["frac"]
+        primary = hbm if hbm_bound else valu
         roof = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_gmres" if spec.solver.linsolve == 0 else ""),
-                                   self.mode, units_per_launch),
+            "bound": "hbm" if hbm_bound else vk, "achieved": primary["achieved"], "peak": primary["peak"], "unit": primary["unit"],
+            "frac": primary["frac"], "traffic": traffic,
             "kernel": "k_forward" if self.mode == "fwd" else "k_forward+k_adjoint",
-            "kernel_ms_per_launch": kern_s * 1e3,
-            "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": units_per_launch,
-            ("fp32_valu" if self.dtype == "f32mixed" else "fp64_valu"): {
-                "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
-                "frac": valu_achieved / valu_peak if valu_peak > 0 else None, "flops_per_unit": f_step,
-                "peak_kind": ("FP32 vector peak, MI355X_MICROARCH.md" if self.dtype == "f32mixed"
-                              else "measured v_fma_f64 micro-benchmark (qd_measure_fp64_peak)"),
-                "active_cu_frac": min(1.0, ninit_local / 256.0)},
+            "kernel_ms_per_launch": kern_s * 1e3, "units_per_launch": units_per_launch,
+            "algorithmic_bytes_per_unit": alg_bytes,
+            "hbm": hbm, vk: valu,
         }
         cfg = {
             "workload": spec.description, "name": self.name,
             "mode": "forward sweep (evalF)" if self.mode == "fwd" else "forward + adjoint gradient (evalGradF)",
             "system_dim": dim, "ninit": ninit_global, "ninit_per_gpu": ninit_local, "ntime": ntime, "dt": spec.time.dt,
             "timestepper": "IMR", "linearsolver": ("gmres" if spec.solver.linsolve == 0 else "neumann") + " (in-kernel)",
+            "solver_path": self.handle.last_solver,
             "options": dict(getattr(spec, "options", {}) or {}),
             "parallelism": (f"{world} GPU(s): one full set of {ninit} initial conditions per GPU (weak)" if self.weak else
                             f"{ninit} initial conditions split over {world} GPU(s)"),
@@ -355,7 +369,7 @@ EXTRA = [
     ("c4", "fwd", "neumann", "f64", {"ntime": 250}, 2, {"neumann_split": 0}),  # the reference's Neumann iteration on the same kernels
     ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 2, {}),  # gmres request served by the diagonal-split iteration under GMRES's stopping rule
     ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1, {"gmres_split": 0}),  # the Krylov kernel (polynomial preconditioner, basis in L2 / HBM)
-    ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1, {}),  # = the 1-GPU point of the `--gpus N` strong-scaling series
+    ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1, {}),  # stored stages fit (104 GB): no chunking; the full grid is the "gradient" block
     ("c2", "fwd", "neumann", "f64", {}, 20, {}),  # BASELINE configs[1] (the round-1/2 headline): 64 single-wave workgroups
     ("q4", "fwd", "neumann", "f64", {}, 20, {}),  # (3-8 ms per step: enough steps that one host hiccup does not halve the rate)
     ("q4", "fwd", "gmres", "f64", {}, 10, {}),  # served by the Neumann iteration (contraction bound <= 0.3)
@@ -385,7 +399,7 @@ EXTRA = [
 LEGEND = ("n workload, m mode, s linear solver, d dtype, o options (qd_set_option), v timesteps*initconds/s, ms per evaluation (host clock), "
           "kms sweep-kernel ms per evaluation (hipEvents on the handle's stream), A RHS applications per step, nt time steps, ni initial "
           "conditions, dim state dimension, hbm algorithmic bytes / kernel time / 8 TB/s, valu canonical flops / kernel time / measured fp64 "
-          "FMA rate (fp32-mixed: 157.3 TF), chk max error of the seven partial sums against the CPU oracle on a small sample, wg workgroups "
+          "FMA rate (fp32-mixed: 157.3 TF), sol the iteration that solved the linear systems (qd_last_solver), chk max error of the seven partial sums against the CPU oracle on a small sample, wg workgroups "
           "per initial condition, x gpu_over_cpu")
 
 
@@ -410,10 +424,11 @@ def extra_entry(wn, wm, ws, wd, wo, wsteps, wopt, local_rank, sync, fp64_peak, w
         v, rf, cf = r.report(el, km, apl, wsteps, fp64_peak)
         vk = "fp32_valu" if wd == "f32mixed" else "fp64_valu"
         ent.update({"v": _sig(v), "ms": _sig(el / wsteps * 1e3, 4), "kms": _sig(rf["kernel_ms_per_launch"], 4), "A": _sig(apl, 4),
-                    "nt": cf["ntime"], "ni": cf["ninit"], "dim": cf["system_dim"], "hbm": _sig(rf["frac"], 3), "valu": _sig(rf[vk]["frac"], 3)})
+                    "nt": cf["ntime"], "ni": cf["ninit"], "dim": cf["system_dim"], "hbm": _sig(rf["hbm"]["frac"], 3),
+                    "valu": _sig(rf[vk]["frac_of_measured"], 3), "sol": r.handle.last_solver})
         if r.handle.dim > 4096:
             ent["wg"] = r.handle.last_team
-        if wm == "fwd" and not (ws == "gmres" and wn in ("c4", "c5", "q4", "l20")):  # one oracle check per (workload, dtype): small sample
+        if wm == "fwd":  # the timed solver path of every entry against the oracle on a small sample
             kk = 8 if r.spec.ninit % 8 == 0 else 1
             nn = 2 if r.spec.dim > 100000 else 20 if r.spec.dim > 256 else 100
             ent["chk"] = _sig(check_against_oracle(r.spec, local_rank, kk, nn, oracle_sample(r.spec, kk, nn), CHECK_TOL[wd]), 2)
@@ -448,12 +463,14 @@ def main():
                     help="one GPU: time shard 0 of N (ninit / N initial conditions) next to the whole batch: predicted_speedup = T(1) / T(N), "
                          "the strong-scaling curve minus the two all-reduces")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gradient", action="store_true", help="one GPU: skip the gradient evaluation of the same workload (reported under \"gradient\")")
     ap.add_argument("--no-workloads", action="store_true", help="one GPU: skip the additional workloads array")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N > 1: strong = split the initial conditions over the GPUs (default); weak = one full set per GPU")
-    ap.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "gloo", "auto-fallback"],
-                    help="auto: nccl (RCCL over xGMI, called from the library) when every rank has its own GPU, otherwise gloo (several "
-                         "ranks share one GPU: test mode).  A failing RCCL bootstrap is an ERROR unless auto-fallback is given.")
+    ap.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "host", "gloo", "auto-fallback"],
+                    help="auto: nccl (RCCL over xGMI, called from the library) when every rank has its own GPU, otherwise host (the library's "
+                         "shared-memory backend: several ranks share one GPU, same C++ call sites).  gloo: reductions through torch.distributed "
+                         "on host buffers (Python-level orchestration).  A failing RCCL bootstrap is an ERROR unless auto-fallback is given.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -490,8 +507,8 @@ def main():
     backend = args.dist_backend
     fallback_ok = backend == "auto-fallback"
     if backend in ("auto", "auto-fallback"):
-        backend = "nccl" if ndev >= world else "gloo"
-    if multi and backend == "gloo":
+        backend = "nccl" if ndev >= world else "host"
+    if multi and backend in ("gloo", "host"):
         local_rank = local_rank % max(ndev, 1)  # ranks may share a GPU in this mode
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
@@ -509,8 +526,8 @@ def main():
         over["linearsolver_type"] = args.linsolve
     if args.ntime:
         over["ntime"] = args.ntime
-    elif name == "c4" and mode == "grad":
-        over["ntime"] = 500  # trajectory + stored stages of 3600 initial conditions: 104 + 104 GB
+    # (C4 gradient: the stored stages of 3600 initial conditions x 2500 steps exceed one GPU's HBM; the shard is then propagated and reversed
+    #  in chunks of initial conditions in one pass, qd_optim.cpp: gradient_one_pass - the full time grid on any number of GPUs)
     for kv in args.set:
         k, _, v = kv.partition("=")
         over[k.strip()] = v.strip()
@@ -540,7 +557,7 @@ def main():
             "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if (weak or world == 1) else "strong",
+            "scaling": "weak" if weak else "strong",  # (the series key: the same on any number of GPUs)
             "vs_baseline": None,
             "dtype": DTYPE_NAME[args.dtype],
             "data": "synthetic",
@@ -553,17 +570,15 @@ def main():
             out["grad_wall_ms"] = elapsed / steps * 1e3
         if multi:
             out["ranks_seen"] = comm.world_size()
-            out["rccl"] = isinstance(comm, RcclComm)
+            out["rccl"] = type(comm) is RcclComm
             out["dist_backend"] = comm.describe()
             out["allreduce_ms_per_step"] = {"objective_sums": ar_ms[0] / steps, "gradient": ar_ms[1] / steps}
     run.close()
 
     if also_grad:
-        # the gradient evaluation of the same workload (ntime 500 for C4: the stored stages of 3600 initial conditions are 104 GB on one
-        # GPU), every rank takes part; then rank 0 alone on the whole batch as the one-GPU point of THIS series
+        # the gradient evaluation of the same workload at the same size, every rank takes part; then rank 0 alone on the whole batch as the one-GPU point of THIS series
         gover = dict(over)
-        if name == "c4" and not args.ntime:
-            gover["ntime"] = 500
+        gover["ntime"] = run.spec.time.ntime
         rg = Runner(name, "grad", gover, args.dtype, rank, world, local_rank, weak, comm, options)
         gel, gkm, gap = rg.time(steps, warmup, sync)
         gar = rg.obj.allreduce_ms()
@@ -615,6 +630,32 @@ def main():
         except (Exception, SystemExit) as e:  # noqa: BLE001
             sh["error"] = f"{type(e).__name__}: {e}"
         out["shard"] = sh
+
+    if rank == 0 and not multi and mode == "fwd" and not args.shard_of and not args.no_gradient:
+        # ---- BASELINE.json's metric names the gradient wall time: the gradient evaluation of the SAME workload at the SAME full size
+        # (C4: 3600 initial conditions x 2500 steps).  Its stored stages (3600 x 2500 x 57.6 KB = 518 GB) exceed HBM - the storage problem of
+        # src/timestepper.cpp:38-48 - so the shard is propagated and reversed in chunks of initial conditions, in one pass (qd_optim.cpp:
+        # gradient_one_pass): no sweep is repeated, the price is the tail of every chunk's last round of workgroups.
+        try:
+            gover = dict(over)
+            gover["ntime"] = run.spec.time.ntime  # (the workload table's gradient default for C4 is the 500-step grid whose stages fit)
+            rg = Runner(name, "grad", gover, args.dtype, 0, 1, local_rank, False, None, options)
+            gsteps = max(1, min(steps, 2))
+            gel, gkm, gap = rg.time(gsteps, 1, sync)
+            gval, groof, gcfg = rg.report(gel, gkm, gap, gsteps, fp64_peak)
+            fwd_ms, adj_ms = rg.handle.forward_ms, rg.handle.adjoint_ms
+            out["gradient"] = {
+                "mode": gcfg["mode"], "workload": gcfg["workload"], "ntime": gcfg["ntime"], "ninit": gcfg["ninit"], "steps": gsteps,
+                "grad_wall_ms": gel / gsteps * 1e3, "value": gval, "unit": "timesteps*initconds/s",
+                "kernel_ms_per_evaluation": groof["kernel_ms_per_launch"], "forward_kernel_ms": fwd_ms, "adjoint_kernel_ms": adj_ms,
+                "chunks": rg.optim.last_chunks,
+                "repropagation": ("none: forward + adjoint per chunk in one pass" if rg.optim.last_chunks > 1 else "none: the stored stages fit"),
+                "forward_sweep_alone_ms": elapsed / steps * 1e3,
+                "rhs_applications_per_step": gap, "objective": rg.val["objective"], "roofline": groof,
+            }
+            rg.close()
+        except (Exception, SystemExit) as e:  # noqa: BLE001
+            out["gradient"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0 and not multi:
         # ---- oracle check of the timed workload + CPU baseline on the same sample -------------------------------

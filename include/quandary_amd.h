@@ -326,6 +326,10 @@ int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const double* globa
 /* Single-rank convenience wrappers (nranks must be 1). */
 int qd_optim_evalF(qd_optim* o, const double* alpha, qd_objective_value* val);
 int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective_value* val, double* grad);
+/* Chunks of the last gradient evaluation: 1 when the shard's stored trajectory fitted in HBM; otherwise the shard was propagated and
+ * reversed in this many batches of initial conditions (the storage problem of src/timestepper.cpp:38-48 at 288 GB) - in one pass
+ * (forward + adjoint per chunk) wherever the adjoint seeds do not depend on the reduced cost, i.e. everywhere but Schroedinger + Jtrace. */
+int qd_optim_last_chunks(const qd_optim* o);
 
 /* ---------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, initial conditions sharded over the ranks.

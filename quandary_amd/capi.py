@@ -178,7 +178,7 @@ EXPORTS = [
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
     "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_create_host", "qd_comm_backend", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
-    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables", "qd_set_option",
+    "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_optim_last_chunks", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables", "qd_set_option",
 ]
 COMM_ID_BYTES = 128
 PRECISION = {"f64": 0, "f32mixed": 1}
@@ -234,6 +234,7 @@ def load_library(path=None):
     lib.qd_optim_destroy.restype = None
     lib.qd_optim_ninit.argtypes = [vp]
     lib.qd_optim_ninit_local.argtypes = [vp]
+    lib.qd_optim_last_chunks.argtypes = [vp]
     lib.qd_optim_initial_state.argtypes = [vp, C.c_int, c_dp, C.POINTER(C.c_int)]
     lib.qd_optim_target_state.argtypes = [vp, C.c_int, c_dp]
     lib.qd_optim_forward_local.argtypes = [vp, c_dp, C.c_int, c_dp]
@@ -514,6 +515,11 @@ class Optim:
         g = np.zeros(max(self.h.ndesign, 1))
         _check(self.lib, self.lib.qd_optim_evalGradF(self._o, dptr(alpha), C.byref(val), dptr(g)), "qd_optim_evalGradF")
         return val.as_dict(), g[: self.h.ndesign]
+
+    @property
+    def last_chunks(self):
+        """Chunks of the last gradient evaluation (1 = the shard's stored trajectory fitted in HBM)."""
+        return self.lib.qd_optim_last_chunks(self._o)
 
     # multi-GPU: every rank calls with the RCCL communicator (qd_comm*) created for the same rank / nranks
     def evalF_dist(self, comm, alpha):

@@ -420,6 +420,7 @@ extern "C" int qd_set_precision(qd_handle* h, int precision) {
 extern "C" int qd_set_params(qd_handle* h, const double* alpha, int ndesign) {
   if (!h || (!alpha && ndesign > 0)) return fail(QD_ERR_INVALID, "qd_set_params: null argument");
   if (ndesign != h->ndesign) return fail(QD_ERR_INVALID, "qd_set_params: ndesign mismatch");
+  h->params_set = true;
   QD_HIP(qd::use_device(h->device));
   if (ndesign > 0) {
     std::memcpy(h->params.data(), alpha, sizeof(double) * ndesign);
@@ -732,6 +733,7 @@ bool qd_handle::gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const {
 // cap (bound <= 0.6: 0.6^60 ~ 5e-14), and given up for good - Krylov kernels from then on - the first time it does not.  At most one
 // switch in the life of a handle; qd_set_option / qd_set_hamiltonian / qd_set_precision start over.
 bool qd_handle::latched_substitution(int kind, double bound) const {
+  if (!params_set) return bound <= 0.3;  // (a query before the first qd_set_params sees no controls: answer, but decide nothing)
   if (sub_latch == -1) {
     if (bound <= 0.3) sub_latch = kind;
     else if (kind == 2) sub_latch = 0;  // (the split gate is asked first and leaves the decision to the Neumann gate)

@@ -87,6 +87,7 @@ struct qd_handle {
   bool gmres_as_neumann(const qd::LaunchCfg& cfg) const;  // ... by the plain Neumann iteration of any other kernel family
   // the decision of the two gates, latched per handle: -1 undecided, 0 Krylov kernels, 1 diagonal-split iteration, 2 Neumann iteration
   mutable int sub_latch = -1;
+  bool params_set = false;  // qd_set_params has been called (the gates look at the control amplitudes)
   bool latched_substitution(int kind, double bound) const;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // forward / adjoint kernel brackets

@@ -38,6 +38,7 @@ struct qd_optim {
   // state between forward_local and adjoint_local
   std::vector<double> last_alpha;
   bool stored = false, forward_done = false;
+  int last_chunks = 1;  // chunks of the last gradient evaluation (1 = the shard's trajectory fitted)
   int dist_fits = -1;  // qd_optim_evalGradF_dist: -1 undecided, 1 fused device path, 0 host-staged fallback (decided collectively)
 };
 
@@ -547,6 +548,41 @@ static DevTarget shifted_target(const qd_optim* o, int offset) {
   return t;
 }
 
+// the seven sums of the last forward sweep, which propagated the local initial conditions [off, off + nc): src/optimproblem.cpp:258-279
+static void add_partial_sums(const qd_optim* o, int off, int nc, double energy, double* partial) {
+  const qd_handle* h = o->h;
+  const double *pen = h->res_pen(), *dpdm = h->res_dpdm(), *o4 = h->res_out4();  // pinned, downloaded with the sweep
+  for (int i = 0; i < nc; i++) {
+    const double w = o->weights[o->first + off + i];
+    partial[QD_SUM_PENALTY] += w * o->pen.gamma_penalty * (o->pen.gamma_penalty > 1e-13 ? pen[i] : 0.0);
+    partial[QD_SUM_DPDM] += w * o->pen.gamma_penalty_dpdm * (o->pen.gamma_penalty_dpdm > 1e-13 ? dpdm[i] : 0.0);
+    partial[QD_SUM_ENERGY] += w * o->pen.gamma_penalty_energy * (o->pen.gamma_penalty_energy > 1e-13 ? energy : 0.0);
+    partial[QD_SUM_COST_RE] += w * o4[4 * i];
+    partial[QD_SUM_COST_IM] += w * o4[4 * i + 1];
+    partial[QD_SUM_FID_RE] += 1. / o->ninit * o4[4 * i + 2];
+    partial[QD_SUM_FID_IM] += 1. / o->ninit * o4[4 * i + 3];
+  }
+}
+
+// How a shard whose trajectory does not fit is cut: the fewest chunks that fit, of equal size (halving until it fits left 3600 initial
+// conditions in four chunks of 900 where three of 1200 fit), rounded up to whole rounds of workgroups over the CUs where that still fits.
+static int plan_chunk(qd_handle* h, int nl, const DevTarget* tg) {
+  if (trajectory_fits(h, nl, tg)) return nl;
+  int lo = 0, hi = nl;  // largest batch that fits: lo fits (0 = none), hi does not
+  while (hi - lo > 1) {
+    const int mid = lo + (hi - lo) / 2;
+    if (trajectory_fits(h, mid, tg)) lo = mid;
+    else hi = mid;
+  }
+  if (lo < 1) return 0;
+  const int nchunks = (nl + lo - 1) / lo;
+  int chunk = (nl + nchunks - 1) / nchunks;
+  const int round = 256;  // CUs of the device: one workgroup per initial condition and CU on the large systems that get here
+  const int up = (chunk + round - 1) / round * round;
+  if (up <= lo) chunk = up;
+  return chunk;
+}
+
 extern "C" int qd_optim_forward_local(qd_optim* o, const double* alpha, int store_trajectory, double* partial) {
   if (!o || !partial || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_forward_local: null argument");
   qd_handle* h = o->h;
@@ -564,18 +600,8 @@ extern "C" int qd_optim_forward_local(qd_optim* o, const double* alpha, int stor
   }
   o->stored = store;
   o->forward_done = true;
-  const double *pen = h->res_pen(), *dpdm = h->res_dpdm(), *o4 = h->res_out4();  // pinned, downloaded with the sweep
   for (int i = 0; i < QD_NSUMS; i++) partial[i] = 0.0;
-  for (int i = 0; i < nl; i++) {  // src/optimproblem.cpp:258-279
-    const double w = o->weights[o->first + i];
-    partial[QD_SUM_PENALTY] += w * o->pen.gamma_penalty * (o->pen.gamma_penalty > 1e-13 ? pen[i] : 0.0);
-    partial[QD_SUM_DPDM] += w * o->pen.gamma_penalty_dpdm * (o->pen.gamma_penalty_dpdm > 1e-13 ? dpdm[i] : 0.0);
-    partial[QD_SUM_ENERGY] += w * o->pen.gamma_penalty_energy * (o->pen.gamma_penalty_energy > 1e-13 ? energy : 0.0);
-    partial[QD_SUM_COST_RE] += w * o4[4 * i];
-    partial[QD_SUM_COST_IM] += w * o4[4 * i + 1];
-    partial[QD_SUM_FID_RE] += 1. / o->ninit * o4[4 * i + 2];
-    partial[QD_SUM_FID_IM] += 1. / o->ninit * o4[4 * i + 3];
-  }
+  add_partial_sums(o, 0, nl, energy, partial);
   return QD_OK;
 }
 
@@ -633,10 +659,10 @@ extern "C" int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const do
     // The trajectory of the whole shard does not fit in HBM: redo the forward sweep chunk by chunk
     // with storage and reverse each chunk at once (the seeds only need the global sums).
     StagesScope ss(h);
-    int chunk = nl;
-    while (chunk > 1 && !trajectory_fits(h, chunk, &o->tg)) chunk = (chunk + 1) / 2;
-    if (!trajectory_fits(h, chunk, &o->tg)) return fail(QD_ERR_NOMEM, "qd_optim_adjoint_local: one trajectory does not fit in device memory");
+    const int chunk = plan_chunk(h, nl, &o->tg);
+    if (chunk < 1) return fail(QD_ERR_NOMEM, "qd_optim_adjoint_local: one trajectory does not fit in device memory");
     bool first = true;
+    o->last_chunks = (nl + chunk - 1) / chunk;
     for (int off = 0; off < nl; off += chunk) {
       const int nc = std::min(chunk, nl - off);
       DevTarget t = shifted_target(o, off);
@@ -666,12 +692,92 @@ extern "C" int qd_optim_evalF(qd_optim* o, const double* alpha, qd_objective_val
   return qd_optim_finalize(o, alpha, sums, val);
 }
 
+// Gradient of a shard whose trajectory does not fit in HBM, in ONE pass over the initial conditions: chunk by chunk a storing forward sweep,
+// its partial sums, its seeds and its adjoint sweep.  Possible wherever the adjoint seeds do not depend on the reduced cost - every
+// objective but Schroedinger + Jtrace (finalizeJ_diff is constant, src/optimtarget.cpp:889-895; the reference propagates every initial
+// condition forward and backward in turn anyway, src/optimproblem.cpp:384-452).  The two-pass form (qd_optim_forward_local without storage,
+// then the chunked re-propagation of qd_optim_adjoint_local) costs one more forward sweep of the whole shard: 0.77 s of 2.5 s on the 3x20
+// workload at its full time grid.  sums[7] = this shard's partial sums, grad[ndesign] = this shard's gradient WITHOUT regularisation terms.
+static int gradient_one_pass(qd_optim* o, const double* alpha, double* sums, double* grad) {
+  qd_handle* h = o->h;
+  const int nl = o->nlocal;
+  const size_t n2 = (size_t)2 * h->S.dim;
+  int r;
+  if ((r = qd_set_params(h, alpha, h->ndesign))) return r;
+  o->last_alpha.assign(alpha, alpha + h->ndesign);
+  PenaltyScope ps(h, o->pen);
+  StagesScope ss(h);
+  const int chunk = plan_chunk(h, nl, &o->tg);
+  if (chunk < 1) return fail(QD_ERR_NOMEM, "qd_optim_evalGradF: one trajectory does not fit in device memory");
+  double rb, ib;
+  finalize_J_diff(o, 0.0, 0.0, &rb, &ib);  // (constant for the objectives that get here)
+  std::vector<double> rbib((size_t)2 * nl), jbar((size_t)3 * nl);
+  double ebar = 0.0;
+  for (int i = 0; i < nl; i++) {
+    const double w = o->weights[o->first + i];
+    rbib[2 * i] = w * rb;
+    rbib[2 * i + 1] = w * ib;
+    jbar[3 * i] = w * o->pen.gamma_penalty;
+    jbar[3 * i + 1] = w * o->pen.gamma_penalty_dpdm;
+    jbar[3 * i + 2] = w * o->pen.gamma_penalty_energy;
+    if (o->pen.gamma_penalty_energy > 1e-13) ebar += jbar[3 * i + 2];
+  }
+  QD_HIP(hipMemcpyAsync(o->d_rbib.p, rbib.data(), sizeof(double) * rbib.size(), hipMemcpyHostToDevice, h->stream));
+  QD_HIP(hipMemcpyAsync(o->d_jbar.p, jbar.data(), sizeof(double) * jbar.size(), hipMemcpyHostToDevice, h->stream));
+  QD_HIP(hipStreamSynchronize(h->stream));  // (rbib / jbar are locals)
+  for (int i = 0; i < QD_NSUMS; i++) sums[i] = 0.0;
+  double fwd_ms = 0.0, applies = 0.0;
+  bool first = true;
+  for (int off = 0; off < nl; off += chunk) {
+    const int nc = std::min(chunk, nl - off);
+    DevTarget t = shifted_target(o, off);
+    double energy = 0.0;
+    if ((r = h->forward_dev(o->d_x0.p + (size_t)off * n2, nc, true, &t, &energy))) return r;
+    add_partial_sums(o, off, nc, energy, sums);
+    fwd_ms += h->last_fwd_ms;
+    applies += h->last_mean_applies * nc;
+    QD_HIP(launch_seed(h->S, t, h->d_xT.p, o->d_rbib.p + (size_t)2 * off, nc, o->d_xbar.p, h->stream));
+    if ((r = h->adjoint_dev(o->d_xbar.p, o->d_jbar.p + (size_t)3 * off, nc, &t, !first))) return r;  // (accumulates last_adj_ms too)
+    first = false;
+  }
+  h->last_fwd_ms = fwd_ms;  // the whole evaluation, as the one-sweep path reports it
+  h->last_mean_applies = applies / nl;
+  o->stored = false;
+  o->forward_done = false;  // (no sweep of the WHOLE shard is pending: qd_optim_adjoint_local needs its own forward_local)
+  o->last_chunks = (nl + chunk - 1) / chunk;
+  return h->gradient_from_coeffs(ebar, grad);
+}
+
+static bool seeds_need_global_cost(const qd_optim* o) { return !o->h->S.lindblad && o->objective_type == QD_OBJ_JTRACE; }
+
+extern "C" int qd_optim_last_chunks(const qd_optim* o) { return o ? o->last_chunks : QD_ERR_INVALID; }
+
 extern "C" int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective_value* val, double* grad) {
   if (!o || !val || !grad) return fail(QD_ERR_INVALID, "qd_optim_evalGradF: null argument");
   if (o->nranks != 1) return fail(QD_ERR_STATE, "qd_optim_evalGradF: single-rank wrapper; use the *_local entry points");
   double sums[QD_NSUMS];
   int r;
   StagesScope ss(o->h);
+  o->last_chunks = 1;
+  if (!seeds_need_global_cost(o)) {
+    bool fits;
+    // (the parameters first: whether the adjoint sweep reads states or stages only - and with it the size of the stored trajectory - follows
+    //  the solver path, whose gates look at the current control amplitudes)
+    if ((r = qd_set_params(o->h, alpha, o->h->ndesign))) return r;
+    {
+      PenaltyScope ps(o->h, o->pen);
+      fits = trajectory_fits(o->h, o->nlocal, &o->tg);
+    }
+    if (!fits) {
+      QD_HIP(qd::use_device(o->h->device));
+      if ((r = gradient_one_pass(o, alpha, sums, grad))) return r;
+      if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
+      const int nd = o->h->ndesign;
+      for (int i = 0; i < nd; i++) grad[i] += o->gamma_tik * (alpha[i] - (o->alpha0.empty() ? 0.0 : o->alpha0[i]));
+      control_variation(o->h, alpha, grad, 0.5 * o->gamma_var);
+      return QD_OK;
+    }
+  }
   if ((r = qd_optim_forward_local(o, alpha, 1, sums))) return r;
   if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
   return qd_optim_adjoint_local(o, alpha, sums, grad);
@@ -751,6 +857,7 @@ extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* al
   // Fused device path or host-staged fallback: the two issue DIFFERENT collectives, and trajectory_fits() looks at this rank's own free
   // memory - so the choice is made collectively (any rank that does not fit sends every rank down the fallback), once per objective.
   if (o->dist_fits < 0) {
+    if ((r = qd_set_params(h, alpha, h->ndesign))) return r;  // (the solver gates behind trajectory_fits look at the current controls)
     double nofit = trajectory_fits(h, nl, &o->tg) ? 0.0 : 1.0;
     if (c->nranks > 1 && (r = qd_comm_allreduce(c, &nofit, 1, 1))) return r;
     o->dist_fits = nofit > 0.5 ? 0 : 1;
@@ -758,6 +865,17 @@ extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* al
   if (!o->dist_fits) {
     // the shard's trajectory exceeds HBM: host-staged path (chunked re-propagation), collectives through the same communicator
     double sums[QD_NSUMS];
+    if (!seeds_need_global_cost(o)) {
+      // one pass over the shard (the seeds are constants), then both reductions
+      if ((r = gradient_one_pass(o, alpha, sums, grad))) return r;
+      if ((r = qd_comm_allreduce(c, sums, QD_NSUMS, 0))) return r;
+      if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
+      if ((r = qd_comm_allreduce(c, grad, nd, 0))) return r;
+      for (int i = 0; i < nd; i++) grad[i] += o->gamma_tik * (alpha[i] - (o->alpha0.empty() ? 0.0 : o->alpha0[i]));
+      control_variation(h, alpha, grad, 0.5 * o->gamma_var);
+      if (allreduce_ms) allreduce_ms[0] = allreduce_ms[1] = 0.0;
+      return QD_OK;
+    }
     if ((r = qd_optim_forward_local(o, alpha, 0, sums))) return r;
     if ((r = qd_comm_allreduce(c, sums, QD_NSUMS, 0))) return r;
     if ((r = qd_optim_finalize(o, alpha, sums, val))) return r;
@@ -773,7 +891,7 @@ extern "C" int qd_optim_evalGradF_dist(qd_optim* o, qd_comm* c, const double* al
     return QD_OK;
   }
   if ((r = dist_forward(o, c, alpha, true))) return r;
-  const bool two = !h->S.lindblad && o->objective_type == QD_OBJ_JTRACE;  // seeds need the GLOBAL cost
+  const bool two = seeds_need_global_cost(o);  // seeds need the GLOBAL cost
   QD_HIP(hipEventRecord(o->evr[0], h->stream));
   if (two && (r = qd_comm_allreduce_dev(c, o->d_red.p, QD_NSUMS, 0, h->stream))) return r;
   QD_HIP(hipEventRecord(o->evr[1], h->stream));

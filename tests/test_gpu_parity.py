@@ -990,20 +990,38 @@ def test_explicit_euler_beyond_lds(kw, team, linsolve):
     opt.close(); h.close(); orc.close()
 
 
-def test_chunked_adjoint_when_trajectory_does_not_fit(monkeypatch):
-    """A shard whose stored trajectory exceeds HBM is re-propagated and reversed in chunks
-    (qd_optim_adjoint_local); the budget is faked through the option traj_budget_mb."""
-    sp = synthetic_spec([2, 2], lindblad=True, ntime=20, penalties=True)
+@pytest.mark.parametrize("kw,one_pass", [
+    pytest.param(dict(nlevels=[2, 2], lindblad=True), True, id="lindblad-one-pass"),
+    pytest.param(dict(nlevels=[3, 4], lindblad=True, target="pure", objective="Jmeasure", init="diagonal", nspline=6), True, id="3x4-lindblad-jmeasure-one-pass"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=False, objective="Jfrobenius"), True, id="schroedinger-jfrobenius-one-pass"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=False, objective="Jtrace"), False, id="schroedinger-jtrace-two-passes"),
+])
+def test_chunked_gradient_when_the_trajectory_does_not_fit(kw, one_pass):
+    """A shard whose stored trajectory exceeds HBM (the storage problem of src/timestepper.cpp:38-48; faked through the option
+    traj_budget_mb) is propagated and reversed in chunks of initial conditions: in ONE pass - forward + adjoint per chunk, no sweep of the
+    whole shard first - wherever the adjoint seeds do not depend on the reduced cost; Schroedinger + Jtrace needs the global cost before
+    any seed (src/optimproblem.cpp:495-511) and pays a forward sweep without storage first.  Same numbers as the unchunked evaluation."""
+    sp = synthetic_spec(**{**kw, "ntime": 20, "penalties": True})
     h = capi.Handle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
-    # one trajectory = 21 states x 16 initial conditions x 32 doubles = 86 kB; allow ~5 initial conditions
-    h.set_option("traj_budget_mb", 21 * 5 * 32 * 8 / 1048576.0)
-    val2, g2 = opt.evalGradF(sp.params0)
+    assert opt.last_chunks == 1
+    nl = opt.ninit
+    per_ic = (21 + 20) * 2 * h.dim * 8  # states + primal stages of one initial condition (an upper bound: stages only where that suffices)
+    fwd_whole = h.forward_ms
+    for fit, want in ((nl // 2 + 1, 2), (max(1, nl // 3), 3 if nl % 3 == 0 else None)):
+        h.set_option("traj_budget_mb", per_ic * fit / 1048576.0)
+        val2, g2 = opt.evalGradF(sp.params0)
+        assert opt.last_chunks >= 2 and (want is None or opt.last_chunks <= want + 1)
+        for k in OBJ_KEYS:
+            assert val2[k] == pytest.approx(val[k], rel=1e-13, abs=1e-15), k
+        np.testing.assert_allclose(g2, g, rtol=1e-11, atol=1e-15 + 1e-12 * np.linalg.norm(g))
+        # evalF afterwards still works on the whole shard, and a second chunked evaluation reproduces the first bit for bit
+        assert opt.evalF(sp.params0)["objective"] == pytest.approx(val["objective"], rel=1e-13)
+        val3, g3 = opt.evalGradF(sp.params0)
+        assert np.array_equal(g3, g2) and val3["objective"] == val2["objective"]
     h.set_option("traj_budget_mb", 0)
-    for k in OBJ_KEYS:
-        assert val2[k] == pytest.approx(val[k], rel=1e-13, abs=1e-15), k
-    np.testing.assert_allclose(g2, g, rtol=1e-11, atol=1e-15)
+    assert fwd_whole > 0
     opt.close(); h.close()
 
 
