@@ -212,6 +212,9 @@ class DistributedObjective:
         return self.b.finalize(alpha, sums)
 
     def evalGradF(self, alpha):
+        if self.comm is None and self.scale == 1.0 and hasattr(self.b, "evalGradF"):
+            # one rank: the library's own evaluation (stages-only storage, one-pass chunking when the stored stages exceed HBM)
+            return self.b.evalGradF(alpha)
         if self.native:
             val, grad, ms = self.b.evalGradF_dist(self.comm.comm, alpha)
             self._t[0] += ms[0] * 1e-3
