@@ -405,6 +405,50 @@ struct ColTeam {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Time-sliced scheduling of the sweeps.  One workgroup owns one CU (two exchange buffers of N KiB), so a batch of nb initial conditions
+// runs in nb / #CUs rounds of whole sweeps and the last round is as long as any other however few workgroups it holds: 3600 initial
+// conditions on 256 CUs are 14.06 rounds - 6 % of the sweep with 240 CUs idle; the 450 of an eight-GPU shard 1.76 rounds - 12 %.  With
+// A.sched set the sweep is cut into A.nslice slices of whole time steps and a resident grid draws (slice, initial condition) tasks from
+// a counter, slice-major: the tail shrinks to one SLICE.  Slice k of an initial condition waits for slice k - 1 (a flag per initial
+// condition, released at agent scope after the state has been written back; the predecessor was drawn earlier, hence is running or
+// done: no deadlock whatever the dispatch order) and picks the state up from the carry buffer.  A wait that exceeds ~4 s raises the
+// error word instead of hanging the device.
+//   sched[0] task counter | sched[1] error word | sched[2 + ic] slices of ic completed
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sched_next(unsigned* sched, unsigned* slot) {
+  __syncthreads();  // (the previous task's last reads of *slot)
+  if (threadIdx.x == 0) *slot = atomicAdd(sched, 1u);
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane((int)*slot);
+}
+// wait until `want` slices of initial condition ic are complete; false after the time limit
+__device__ __forceinline__ bool sched_wait(unsigned* sched, int ic, unsigned want) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while (__hip_atomic_load(sched + 2 + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 400000000ull) {
+        atomicExch(sched + 1, 1u);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  return __hip_atomic_load(sched + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+// the state of ic has been written: publish the completion of its slice
+__device__ __forceinline__ void sched_done(unsigned* sched, int ic, unsigned done) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(sched + 2 + ic, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// first sub-step of slice sl (whole time steps)
+__device__ __forceinline__ int slice_start(const SweepArgs& A, int sl) {
+  return (int)((long long)A.ntime * sl / A.nslice) * A.nstages;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
 template <int Q, int EPT, bool SPLIT>
@@ -414,16 +458,22 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
-  const int ic = blockIdx.x, dim = S.dim;
-  double2 x[EPT];
-  {
-    const double* x0 = A.x0 + (size_t)ic * 2 * dim;
-#pragma unroll
-    for (int j = 0; j < EPT; j++) x[j] = tm.st.ok(j) ? make_double2(x0[tm.st.elem(j)], x0[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
-  }
+  __shared__ unsigned task_slot;
+  const int dim = S.dim, ntask = A.nb * A.nslice;
   const bool pen_on = A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   const bool leak = pen_on && A.leak_on && tm.st.row_is_guard(S);
+  for (int task = A.sched ? sched_next(A.sched, &task_slot) : (int)blockIdx.x; task < ntask; task = A.sched ? sched_next(A.sched, &task_slot) : ntask) {
+  const int ic = task % A.nb, sl = task / A.nb;
+  const int s_lo = slice_start(A, sl), s_hi = slice_start(A, sl + 1);
+  if (sl > 0 && !sched_wait(A.sched, ic, (unsigned)sl)) return;
+  double2 x[EPT];
+  {
+    // slice 0 starts from the initial condition, every other one from where its predecessor left the state (the carry = xT)
+    const double* x0 = (sl > 0 ? A.xT : A.x0) + (size_t)ic * 2 * dim;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = tm.st.ok(j) ? make_double2(x0[tm.st.elem(j)], x0[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
+  }
   double pen_local = 0.0, pen_uniform = 0.0;
   unsigned long long napply = 0;
   double* xpark = A.xT + (size_t)ic * 2 * dim;
@@ -445,7 +495,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     }
   };
 
-  for (int s = 0; s < A.nsub; s++) {
+  for (int s = s_lo; s < s_hi; s++) {
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
     scalarize<Q>(c, false);
@@ -524,13 +574,15 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     }
   }
   store_state(A.xT + (size_t)ic * 2 * dim, x, false);
-  if (A.traj) store_state(A.traj + ((size_t)A.nsub * A.nb + ic) * 2 * dim, x, false);
+  if (A.traj && sl == A.nslice - 1) store_state(A.traj + ((size_t)A.nsub * A.nb + ic) * 2 * dim, x, false);
   double v[1] = {pen_local};
   tm.template sum<1>(v);
   if (threadIdx.x == 0) {
-    A.pen_out[ic] = v[0] + pen_uniform;
+    A.pen_out[ic] = (sl > 0 ? A.pen_out[ic] : 0.0) + v[0] + pen_uniform;  // (slices of one initial condition run one after the other)
     A.dpdm_out[ic] = 0.0;  // the dpdm penalty is Schroedinger only (timestepper.cpp:143-146)
     atomicAdd(A.napply, napply);
+  }
+  if (A.sched) sched_done(A.sched, ic, (unsigned)(sl + 1));
   }
 }
 
@@ -544,17 +596,23 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
-  const int ic = blockIdx.x, dim = S.dim;
+  __shared__ unsigned task_slot;
+  const int dim = S.dim, ntask = A.nb * A.nslice;
+  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool wj_on = pen_on && A.penalty_param > 1e-13;
+  const bool leak = pen_on && A.leak_on && tm.st.row_is_guard(S);
+  for (int task = A.sched ? sched_next(A.sched, &task_slot) : (int)blockIdx.x; task < ntask; task = A.sched ? sched_next(A.sched, &task_slot) : ntask) {
+  // backwards in time: task slice sl covers the time slice nslice - 1 - sl
+  const int ic = task % A.nb, sl = task / A.nb;
+  const int s_lo = slice_start(A, A.nslice - 1 - sl), s_hi = slice_start(A, A.nslice - sl);
+  if (sl > 0 && !sched_wait(A.sched, ic, (unsigned)sl)) return;
   double2 xb[EPT];
   {
-    const double* xbT = A.xbarT + (size_t)ic * 2 * dim;
+    const double* xbT = (sl > 0 ? A.stash : A.xbarT) + (size_t)ic * 2 * dim;  // (the carry of the adjoint state: SweepArgs::stash)
 #pragma unroll
     for (int j = 0; j < EPT; j++) xb[j] = tm.st.ok(j) ? make_double2(xbT[tm.st.elem(j)], xbT[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
   }
   const double jbar_pen = A.jbar[ic * 3 + 0];
-  const bool pen_on = A.gamma_penalty > 1e-13;
-  const bool wj_on = pen_on && A.penalty_param > 1e-13;
-  const bool leak = pen_on && A.leak_on && tm.st.row_is_guard(S);
   auto load_state = [&](const double* base, int s, double2(&dst)[EPT]) {
     const double* src = base + ((size_t)s * A.nb + ic) * 2 * dim;
 #pragma unroll
@@ -563,7 +621,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
                            : make_double2(0.0, 0.0);
   };
 
-  for (int s = A.nsub - 1; s >= 0; s--) {
+  for (int s = s_hi - 1; s >= s_lo; s--) {
     // penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227, :300-339)
     if (pen_on && (s + 1) % A.nstages == 0 && (wj_on || leak)) {
       const int n = (s + 1) / A.nstages;
@@ -657,14 +715,17 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
       xb[j].y += t[j].y;
     }
   }
-  if (A.xbar0) {
-    double* d0 = A.xbar0 + (size_t)ic * 2 * dim;
+  double* d0 = sl == A.nslice - 1 ? A.xbar0 : A.stash;
+  if (d0) {
+    d0 += (size_t)ic * 2 * dim;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (tm.st.ok(j)) {
         d0[tm.st.elem(j)] = xb[j].x;
         d0[dim + tm.st.elem(j)] = xb[j].y;
       }
+  }
+  if (A.sched) sched_done(A.sched, ic, (unsigned)(sl + 1));
   }
 }
 
@@ -699,6 +760,38 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_apply_col(const DevSys
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+int col_cu_count() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  return ncu;
+}
+
+// Slices of a sweep of nb initial conditions over ntime steps (1 = one workgroup per initial condition, no scheduler): the smallest power
+// of two that brings the idle tail - (ceil(r) - r) / ceil(r) for r = nb k / #CUs rounds - below 1 %, keeping at least 32 steps per slice.
+int col_slices(int nb, int ntime, const TuneOpts& o) {
+  if (o.col_slices == 1) return 1;
+  if (o.col_slices > 1) return std::min(o.col_slices, std::max(ntime, 1));
+  const int ncu = col_cu_count();
+  if (nb <= ncu) return 1;
+  int best = 1;
+  double best_waste = 1.0;
+  for (int k = 1; k <= 64 && ntime / k >= 32; k *= 2) {
+    const double r = (double)nb * k / ncu;
+    const double waste = (ceil(r) - r) / ceil(r);
+    if (waste < best_waste - 1e-12) {
+      best_waste = waste;
+      best = k;
+    }
+    if (waste < 0.01) break;
+  }
+  return best_waste < 0.01 || best > 1 ? best : 1;
+}
+
 template <typename K>
 static hipError_t set_lds_col(K kern, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -714,6 +807,19 @@ bool collean_available(const DevSys& S, const TuneOpts& o) {
   return !qubit && S.post[S.Q - 1] == 1;
 }
 
+// grid of a sweep: one workgroup per initial condition, or - time-sliced scheduling - as many workgroups as are resident at once
+template <typename K>
+static int col_grid(K kern, const SweepArgs& a, int threads, size_t lds) {
+  if (!a.sched) return a.nb;
+  int per_cu = 1, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  int ncu = col_cu_count();
+  (void)dev;
+  (void)prop;
+  return std::min(a.nb * a.nslice, per_cu * ncu);
+}
+
 template <int Q, int EPT, bool SPLIT>
 static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
@@ -721,7 +827,7 @@ static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   auto kf = k_forward_col<Q, EPT, SPLIT>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3(a.nb), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
+  hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
   return hipGetLastError();
 }
 template <int Q, int EPT>
@@ -735,7 +841,7 @@ static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   auto kf = k_adjoint_col<Q, EPT, SPLIT>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kf, dim3(a.nb), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
+  hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
   return hipGetLastError();
 }
 template <int Q, int EPT>

@@ -66,13 +66,14 @@ extern "C" void qd_destroy(qd_handle* h) {
   struct Quiet { ~Quiet() { (void)hipGetLastError(); } } quiet;  // teardown never leaves a sticky error behind
   for (DBuf* b : {&h->d_params, &h->d_tbar, &h->d_tred, &h->d_sched_t, &h->d_sched_h, &h->d_etimes, &h->d_ezero, &h->d_table, &h->d_etable, &h->d_onerow,
                   &h->d_onetime, &h->d_tstates, &h->d_purity, &h->d_x0, &h->d_xT, &h->d_traj, &h->d_ztraj, &h->d_res,
-                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_stash, &h->d_kry, &h->d_ecoef, &h->d_edig, &h->d_work, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
+                  &h->d_xbar, &h->d_jbar, &h->d_coeff, &h->d_coeffsum, &h->d_grad, &h->d_y, &h->d_sched, &h->d_stash, &h->d_kry, &h->d_ecoef, &h->d_edig, &h->d_work, &h->d_g0, &h->d_hcr, &h->d_hci, &h->d_gtab, &h->d_gone})
     b->release();
   if (h->d_segs) (void)hipFree(h->d_segs);
   if (h->d_oscs) (void)hipFree(h->d_oscs);
   if (h->d_carriers) (void)hipFree(h->d_carriers);
   if (h->d_pulses) (void)hipFree(h->d_pulses);
   h->h_etable.release();
+  h->h_sched.release();
   h->h_res.release();
   h->h_params.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -828,6 +829,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.inv_abs2 = 1.0 / (a.abstol * a.abstol);
   a.rel2 = (float)(a.reltol * a.reltol);
   a.gmres_poly = h->gmres_poly_degree();
+  a.nslice = 1;
   a.neumann_split = h->neumann_split_on();
   // penalties that need target data are only active when a target has been set
   a.gamma_penalty = h->pen.gamma_penalty;
@@ -837,6 +839,28 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.leak_on = 0;
   for (int k = 0; k < h->S.Q; k++)
     if (h->S.ness[k] < h->S.n[k]) a.leak_on = 1;  // addLeakagePrevent, src/timestepper.cpp:28-32
+}
+
+// Time-sliced scheduling of a lean column sweep (qd_col.hip): scheduler words zeroed on the stream, carry buffer of the adjoint state.
+// which = 0 forward, 1 adjoint (their scheduler words are separate: both sweeps may be queued before the first has run).
+int qd_handle::arm_slices(qd::SweepArgs& a, int nb, int which) {
+  a.nslice = col_slices(nb, tg.ntime, opts);
+  a.sched = nullptr;
+  if (a.nslice <= 1) {
+    a.nslice = 1;
+    return QD_OK;
+  }
+  int r;
+  const size_t words = (size_t)nb + 2, dbl = (words + 1) / 2;
+  if ((r = d_sched.ensure(2 * dbl)) || (r = h_sched.ensure(1))) return r;
+  unsigned* p = reinterpret_cast<unsigned*>(d_sched.p + (which ? dbl : 0));
+  QD_HIP(hipMemsetAsync(p, 0, sizeof(unsigned) * words, stream));
+  a.sched = p;
+  if (which) {
+    if ((r = d_stash.ensure((size_t)nb * 2 * S.dim))) return r;
+    a.stash = d_stash.p;
+  }
+  return QD_OK;
 }
 
 int qd_handle::forward_dev(const double* dx0, int nb, bool store, const DevTarget* tgp, double* energy) {
@@ -916,9 +940,13 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, opts, stream));
-  else if (use_col(cfg)) QD_HIP(launch_forward_col(a, opts, stream));
-  else QD_HIP(launch_forward(a, cfg, stream));
+  else if (use_col(cfg)) {
+    if ((r = arm_slices(a, nb, 0))) return r;
+    QD_HIP(launch_forward_col(a, opts, stream));
+  } else QD_HIP(launch_forward(a, cfg, stream));
   QD_HIP(hipEventRecord(ev1, stream));
+  if (a.sched) QD_HIP(hipMemcpyAsync(h_sched.p, a.sched + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+  sliced_fwd = a.sched != nullptr;
   if (tgp) QD_HIP(launch_objective(S, *tgp, d_xT.p, nb, d_out4, stream));
   // every result of the sweep in one pinned buffer, one synchronisation
   if ((r = h_res.ensure((size_t)6 * nb + 1))) return r;
@@ -934,6 +962,8 @@ int qd_handle::forward_finish(double* energy) {
   const int nb = last_nb;
   const bool store = pending_store;
   QD_HIP(hipStreamSynchronize(stream));
+  if (sliced_fwd && reinterpret_cast<const unsigned*>(h_sched.p)[0] != 0u)
+    return fail(QD_ERR_DEVICE, "forward sweep: a time slice waited more than four seconds for its predecessor (time-sliced scheduling, option col_slices)");
   unsigned long long nap = 0;
   std::memcpy(&nap, h_res.p + 6 * (size_t)nb, sizeof nap);
   float ms = 0.f;
@@ -1117,15 +1147,21 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, opts, stream));
-  else if (use_col(cfg)) QD_HIP(launch_adjoint_col(a, opts, stream));
-  else QD_HIP(launch_adjoint(a, cfg, stream));
+  else if (use_col(cfg)) {
+    if ((r = arm_slices(a, nb, 1))) return r;
+    QD_HIP(launch_adjoint_col(a, opts, stream));
+  } else QD_HIP(launch_adjoint(a, cfg, stream));
   QD_HIP(hipEventRecord(ev3, stream));
+  if (a.sched) QD_HIP(hipMemcpyAsync(reinterpret_cast<unsigned*>(h_sched.p) + 1, a.sched + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+  sliced_adj = a.sched != nullptr;
   QD_HIP(launch_reduce_coeff(d_coeff.p, nb, (int)ncol, d_coeffsum.p, accumulate ? 1 : 0, stream));
   return QD_OK;
 }
 
 int qd_handle::adjoint_finish(bool accumulate) {
   QD_HIP(hipStreamSynchronize(stream));
+  if (sliced_adj && reinterpret_cast<const unsigned*>(h_sched.p)[1] != 0u)
+    return fail(QD_ERR_DEVICE, "adjoint sweep: a time slice waited more than four seconds for its predecessor (time-sliced scheduling, option col_slices)");
   float ms = 0.f;
   QD_HIP(hipEventElapsedTime(&ms, ev2, ev3));
   last_adj_ms = accumulate ? last_adj_ms + ms : ms;

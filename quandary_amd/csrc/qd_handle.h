@@ -132,6 +132,10 @@ struct qd_handle {
   int ensure_wj_weights();
   qd::DBuf d_x0, d_xT, d_traj, d_res, d_xbar, d_jbar, d_coeff, d_coeffsum, d_grad, d_y, d_stash, d_kry;
   qd::DBuf d_ecoef, d_edig, d_work;  // large states (qd_big.h): element table, work vectors
+  qd::DBuf d_sched;                  // scheduler words of the time-sliced lean column sweeps (forward | adjoint)
+  qd::HBuf h_sched;                  // their error words, downloaded with the sweep
+  bool sliced_fwd = false, sliced_adj = false;
+  int arm_slices(qd::SweepArgs& a, int nb, int which);
   int ensure_big(int nb);            // no-op unless the launch configuration is the large-state variant
   qd::DBuf d_g0, d_hcr, d_hci, d_gtab, d_gone;  // dense user-Hamiltonian path (qd_set_hamiltonian)
   // infinity norms of the uploaded Hamiltonians (row_bounds: the standard-model constants say nothing about a user Hamiltonian)

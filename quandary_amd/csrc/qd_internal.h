@@ -107,6 +107,10 @@ struct SweepArgs {
   double* coeff;        // [nb][nsub][2Q]  (x^T dM/dp_k z, x^T dM/dq_k z)
   double* xbar0;        // [nb][2*dim] adjoint at t=0 (diagnostic) or nullptr
   double* kry;          // [nb][GMRES_MR_G+1][2*dim] Krylov basis of the GMRES variant whose basis does not fit in LDS
+  // time-sliced scheduling of the lean column kernels (qd_col.hip): nslice slices of whole time steps, tasks drawn from sched[0]
+  // (sched = nullptr: one workgroup per initial condition); the adjoint state is carried from slice to slice in `stash`
+  int nslice;
+  unsigned* sched;
   double* stash;        // [2][nb][2*dim] staging area of the several-elements-per-thread variants (adjoint state / midpoint state
                         // parked in L2/HBM while a linear solve runs, instead of compiler-chosen scratch spills)
 };
@@ -131,6 +135,7 @@ struct TuneOpts {
   int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
+  int col_slices = 0;      // "col_slices": time slices of the lean column sweeps (0 = automatic, 1 = none, k = force k)
   int col_min_n = 33;      // "col_min_n": smallest density-matrix dimension N the lean column kernels take over from the eight-elements-per-thread kernel
   int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
   int gmres_split = -1;    // "gmres_split": linearsolver_type = gmres served by the diagonal-split iteration under GMRES's stopping rule where that
@@ -184,6 +189,7 @@ hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStrea
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st);
 // lean column kernels (qd_col.hip): Lindblad Neumann sweeps of density matrices with 33..64 rows and runtime level counts
 bool collean_available(const DevSys& S, const TuneOpts& o);
+int col_slices(int nb, int ntime, const TuneOpts& o);  // time slices of a lean column sweep (1 = none)
 hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, const TuneOpts& o, hipStream_t st);

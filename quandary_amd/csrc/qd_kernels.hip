@@ -557,7 +557,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // options
 // ---------------------------------------------------------------------------------------------
 static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "big_blocked", "f32_sb", "lean64_sb", "no_lean64", "no_collean",
-                                       "col_ept", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb"};
+                                       "col_ept", "col_slices", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
   const std::string k(key), v(value);
@@ -585,6 +585,7 @@ int TuneOpts::set(const char* key, const char* value) {
   else if (k == "no_lean64") no_lean64 = iv != 0;
   else if (k == "no_collean") no_collean = iv != 0;
   else if (k == "col_ept") col_ept = (int)iv;
+  else if (k == "col_slices") col_slices = iv > 0 ? (int)iv : 0;
   else if (k == "col_min_n") col_min_n = iv > 0 ? (int)iv : 33;
   else if (k == "gmres_poly") gmres_poly = iv > 0 ? (int)iv : 0;
   else if (k == "neumann_split") neumann_split = iv < 0 ? -1 : iv != 0;

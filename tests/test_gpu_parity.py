@@ -168,6 +168,43 @@ def test_lean_column_kernels(kw, stepper, split):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("slices", [2, 5])
+@pytest.mark.parametrize("stepper,ntime", [("IMR", 13), ("IMR4", 7)])
+@pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[1], LEANCOL_SHAPES[2], LEANCOL_SHAPES[3]])
+def test_time_sliced_scheduling_of_the_column_sweeps(kw, stepper, ntime, slices):
+    """Lean column kernels with the sweep cut into time slices that a resident grid draws from a task counter (option col_slices; automatic
+    for batches beyond one workgroup per CU, where it shrinks the idle tail of the last round from one sweep to one slice): forward and
+    adjoint sweeps, slices that do not divide the number of steps, composite steps, guard levels (the adjoint reads stored states), every
+    penalty - against the oracle and against the unsliced sweep (same arithmetic per step; only the penalty sums are added slice by slice)."""
+    sp = synthetic_spec(**{**kw, "ntime": ntime, "penalties": True, "stepper": stepper, "dt": 0.002})
+    sp.options = {"col_slices": slices}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    valf = opt.evalF(sp.params0)
+    assert valf["objective"] == pytest.approx(val["objective"], rel=1e-13)
+    h.set_option("col_slices", 1)
+    val1, g1 = opt.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(val1[k], rel=1e-13, abs=1e-15), k
+    np.testing.assert_allclose(g, g1, rtol=1e-12, atol=1e-14 * np.linalg.norm(g1))
+    # stored trajectory of a sliced forward sweep: the states at the slice boundaries and at the end are where they belong
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(opt.ninit_local)])
+    h.set_params(sp.params0)
+    ref = h.forward(x0, store_trajectory=True)
+    st_ref = [h.get_state(n, x0.shape[0]) for n in (0, ntime // 2, ntime)]
+    h.set_option("col_slices", slices)
+    res = h.forward(x0, store_trajectory=True)
+    np.testing.assert_array_equal(res["final_states"], ref["final_states"])
+    for n, want in zip((0, ntime // 2, ntime), st_ref):
+        np.testing.assert_array_equal(h.get_state(n, x0.shape[0]), want)
+    opt.close(); h.close(); orc.close()
+
+
 def test_diagonal_split_neumann_on_the_axc_system():
     """BASELINE config 4 (3 x 20, AxC constants): the diagonal-split iteration needs fewer applications per step than the reference's
     Neumann iteration and gives the same objective and gradient (both stop on the update norm at abstol 1e-10)."""
