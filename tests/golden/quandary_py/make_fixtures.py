@@ -98,7 +98,60 @@ def main():
             info["Hc_im"] = [np.asarray(a).tolist() for a in q.Hc_im]
         json.dump(info, open(os.path.join(d, "case.json"), "w"), indent=1)
         print(name, info["derived"], info["launch"], info["files"])
+    known_answers(rec)
     os.remove(rec)
+
+
+def known_answers(rec):
+    """The two tests of the reference's tests/python that do not depend on PETSc TAO's iterates: test_example_spinchain.py (a forward
+    simulation with expected energies / populations at ten sample points, tolerance rtol 1e-3: tests/python/utils.py:4-5) and
+    test_evalControls.py (the time grid of runtype = evalcontrols).  The constructor arguments and the expected NUMBERS are taken from
+    the imported test modules; what is committed is the config quandary.py writes for them and those numbers."""
+    sys.path.insert(0, os.path.join(REF, "tests", "python"))
+    import test_example_spinchain as sc  # noqa: E402  (the reference's test module: data and the coefficient map)
+
+    N = 8
+    np.random.seed(9001)
+    h = np.random.uniform(-1.0, 1.0, N)
+    freq01, crosskerr, Jkl = sc.mapCoeffs_SpinChainToQuandary(N, h, np.zeros(N), np.ones(N))
+    init = "pure, " + "".join(str(int(i < N // 2)) + ", " for i in range(N))
+    q = Q.Quandary(Ne=[2] * N, Ng=[0] * N, freq01=freq01, rotfreq=np.zeros(N), crosskerr=crosskerr, Jkl=Jkl, initialcondition=init, T=10.0, dT=0.01,
+                   initctrl_MHz=0.0, carrier_frequency=[[0.0] for _ in range(N)], verbose=False)
+    d = os.path.join(HERE, "known_answer_spinchain")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    try:
+        q.simulate(maxcores=1, datadir=d, quandary_exec="quandary", mpi_exec=rec + " ")
+    except AttributeError:
+        pass
+    args = open(os.path.join(d, "launch_args.txt")).read().split()
+    os.remove(os.path.join(d, "launch_args.txt"))
+    os.remove(os.path.join(d, "launch_cwd.txt"))
+    json.dump(dict(source="tests/python/test_example_spinchain.py (expected values) + tests/python/utils.py (tolerances)", ncores=int(args[0]),
+                   n_osc=N, T=10.0, expected_length=sc.EXPECTED_LENGTH, expected_infidelity=sc.EXPECTED_INFIDELITY, sample_indices=sc.SAMPLE_INDICES,
+                   expected_pt=np.asarray(sc.EXPECTED_PT).tolist(), expected_qt=np.asarray(sc.EXPECTED_QT).tolist(),
+                   expected_energy=sc.EXPECTED_ENERGY, expected_population=sc.EXPECTED_POPULATION, rel_tol=1e-3, abs_tol=1e-10,
+                   derived=dict(nsteps=int(q.nsteps), dT=float(q.dT), ninit=int(q._ninit), lindblad=bool(q._lindblad_solver), Ne=list(q.Ne), Ng=list(q.Ng))),
+              open(os.path.join(d, "case.json"), "w"), indent=1)
+    print("known_answer_spinchain", sorted(os.listdir(d)))
+
+    # test_evalControls.py::test_evalControls_updates_timestep: T = 5, two points per ns -> nsteps = floor(T * ppns), dT = T / nsteps
+    q = Q.Quandary(Ne=[2], freq01=[4.0], T=5.0, verbose=False, rand_seed=5)
+    d = os.path.join(HERE, "known_answer_evalcontrols")
+    shutil.rmtree(d, ignore_errors=True)
+    shutil.rmtree(d + "_ppns2", ignore_errors=True)
+    try:
+        q.evalControls(points_per_ns=2, datadir=d, quandary_exec="quandary", mpi_exec=rec + " ")
+    except (AttributeError, TypeError, IndexError):
+        pass
+    os.rename(d + "_ppns2", d)
+    args = open(os.path.join(d, "launch_args.txt")).read().split()
+    os.remove(os.path.join(d, "launch_args.txt"))
+    os.remove(os.path.join(d, "launch_cwd.txt"))
+    json.dump(dict(source="tests/python/test_evalControls.py::test_evalControls_updates_timestep", ncores=int(args[0]), T=5.0, points_per_ns=2,
+                   expected_nsteps=int(np.floor(5.0 * 2)), expected_dT=5.0 / int(np.floor(5.0 * 2)), original_nsteps=int(q.nsteps), original_dT=float(q.dT)),
+              open(os.path.join(d, "case.json"), "w"), indent=1)
+    print("known_answer_evalcontrols", sorted(os.listdir(d)))
 
 
 if __name__ == "__main__":

@@ -259,3 +259,36 @@ def test_driver_large_state_runs_on_a_team_of_workgroups(tmp_path):
     assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
     assert _load(tmp_path / "data_out" / "optim_history.dat")[0][1] == pytest.approx(oval["objective"], rel=REF_RTOL)
     orc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gate,nlevels,ness,lindblad", [("swap0q", [2, 2, 2], None, False), ("cqnot", [2, 2, 2], None, False), ("qft", [2, 2], None, True),
+                                                        ("hadamard", [3], [2], True), ("ygate", [2], None, False), ("zgate", [2], None, True),
+                                                        ("swap", [3, 3], [2, 2], False), ("cqnot", [3, 2], [2, 2], True)])
+def test_driver_gate_zoo_and_initial_state_families(gate, nlevels, ness, lindblad, tmp_path):
+    """The C++ driver's own gate matrices and guard-level lifting (quandary_main.cpp; src/gate.cpp:286-571) - the Python mirror config.py is
+    pinned against independent constructions in tests/test_independent_constructions.py, the driver against the oracle fed by that mirror:
+    objective and gradient of a gate optimisation problem per gate, then the Nplus1 / performance / 3states / ensemble families."""
+    from helpers import synthetic_cfg
+    from oracle.oracle import Oracle
+    from quandary_amd import config
+
+    cases = [synthetic_cfg(nlevels, lindblad=lindblad, ntime=20, nspline=6, gate=gate, nessential=ness, penalties=True, objective="Jtrace")]
+    if lindblad and gate in ("qft", "hadamard"):
+        cases += [synthetic_cfg(nlevels, lindblad=True, ntime=20, nspline=6, gate=gate, nessential=ness, init=fam, objective="Jfrobenius")
+                  for fam in ("Nplus1", "performance", "3states", "ensemble, 0")]
+    for n, text in enumerate(cases):
+        d = tmp_path / f"c{n}"
+        d.mkdir()
+        (d / "g.cfg").write_text(text)
+        r = subprocess.run([EXE, "g.cfg", "--quiet"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        sp = config.build_spec(config.parse_config_text(text))
+        orc = Oracle(sp)
+        oval, og = orc.evalGradF(sp.params0)
+        orc.close()
+        hist = _load(d / "data_out" / "optim_history.dat")[0]
+        assert hist[1] == pytest.approx(oval["objective"], rel=REF_RTOL), text
+        assert hist[4] == pytest.approx(oval["fidelity"], rel=REF_RTOL, abs=1e-12)
+        g = _load(d / "data_out" / "grad.dat").ravel()
+        assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + 1e-13
