@@ -33,7 +33,10 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 
 // SPLIT: the kernels of the diagonal-split solver keep (1 - alpha D)^-1 per element instead of the diagonal itself; the diagonal is then
 // re-derived where the full operator is applied (once or twice per step) from a row part held by the thread and a column part in LDS
-template <int Q, int EPT, bool SPLIT = false>
+// USLOT: every column of a wave has the same level indices i'_k of the oscillators k < L (post[k] a multiple of EPT, no idle columns):
+// the byte offsets to the ket neighbour columns are then one pair per oscillator instead of one per slot, and the compiler forms each
+// neighbour address once per application instead of once per slot (12 of 300 vector instructions of a solver iteration on 3 x 20).
+template <int Q, int EPT, bool SPLIT = false, bool USLOT = false>
 struct ColLean {
   static constexpr int L = Q - 1;  // the stride-1 oscillator (post[Q-1] == 1)
   // thread invariants (functions of the row)
@@ -47,7 +50,8 @@ struct ColLean {
   int dlt;                  // byte distance from the buffer being read to the other one (+- bufbytes)
   // wave-uniform (functions of the wave's columns; scalar registers)
   double cx[EPT][Q], cy[EPT][Q];  // sqrt(i'_k + 1) (0 at the top level), sqrt(i'_k) of the column of slot j
-  int ocu[EPT][Q], ocd[EPT][Q];   // byte offset to the ket neighbour column up / down (0 where there is none)
+  int ocu[USLOT ? 1 : EPT][Q], ocd[USLOT ? 1 : EPT][Q];  // byte offset to the ket neighbour column up / down (0 where there is none)
+  static __device__ __forceinline__ constexpr int us(int j) { return USLOT ? 0 : j; }
   int N, row, col0;
   bool rowok;
   unsigned char* smem;
@@ -151,8 +155,12 @@ struct ColLean {
         const bool up = cok && ipa[k] < S.n[k] - 1, dn = cok && ipa[k] > 0;
         cx[j][k] = to_scalar(up ? sqrt((double)(ipa[k] + 1)) : 0.0);
         cy[j][k] = to_scalar(dn ? sqrt((double)ipa[k]) : 0.0);
-        ocu[j][k] = uniform_i(up ? S.post[k] * (int)COLB : 0);
-        ocd[j][k] = uniform_i(dn ? -S.post[k] * (int)COLB : 0);
+        if (!USLOT || j == 0 || k == L) {
+          // (USLOT: the offsets of the stride-1 oscillator are only used at the two edge slots, whose neighbours are not in registers:
+          //  the up offset of the last slot, the down offset of the first)
+          if (!USLOT || k != L || j == 0) ocd[us(j)][k] = uniform_i(dn ? -S.post[k] * (int)COLB : 0);
+          if (!USLOT || k != L || j == EPT - 1 || EPT == 1) ocu[us(j)][k] = uniform_i(up ? S.post[k] * (int)COLB : 0);
+        }
       }
       const bool live = rowok && cok;
       if (!SPLIT) {
@@ -197,13 +205,13 @@ struct ColLean {
     if (k == L) {
       xu = lane_shift<true>(own);
       xd = lane_shift<false>(own);
-      xup = j < EPT - 1 ? next : ld(tb + (unsigned)ocu[j][k] + (unsigned)j * COLB);
-      xdp = j > 0 ? prev : ld(tb + (unsigned)ocd[j][k] + (unsigned)j * COLB);
+      xup = j < EPT - 1 ? next : ld(tb + (unsigned)ocu[us(j)][k] + (unsigned)j * COLB);
+      xdp = j > 0 ? prev : ld(tb + (unsigned)ocd[us(j)][k] + (unsigned)j * COLB);
     } else {
       xu = ld(aru[k] + (unsigned)j * COLB);
       xd = ld(ard[k] + (unsigned)j * COLB);
-      xup = ld(tb + (unsigned)ocu[j][k] + (unsigned)j * COLB);
-      xdp = ld(tb + (unsigned)ocd[j][k] + (unsigned)j * COLB);
+      xup = ld(tb + (unsigned)ocu[us(j)][k] + (unsigned)j * COLB);
+      xdp = ld(tb + (unsigned)ocd[us(j)][k] + (unsigned)j * COLB);
     }
   }
 
@@ -231,10 +239,10 @@ struct ColLean {
       // T1 off-diagonal term: forward couples to (row + s, column + s), transposed to (row - s, column - s)
       double2 xl;
       if (k == L) {
-        if (TRANS) xl = j > 0 ? lane_shift<false>(prev) : ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB);
-        else xl = j < EPT - 1 ? lane_shift<true>(next) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+        if (TRANS) xl = j > 0 ? lane_shift<false>(prev) : ld(ard[k] + (unsigned)ocd[us(j)][k] + (unsigned)j * COLB);
+        else xl = j < EPT - 1 ? lane_shift<true>(next) : ld(aru[k] + (unsigned)ocu[us(j)][k] + (unsigned)j * COLB);
       } else {
-        xl = TRANS ? ld(ard[k] + (unsigned)ocd[j][k] + (unsigned)j * COLB) : ld(aru[k] + (unsigned)ocu[j][k] + (unsigned)j * COLB);
+        xl = TRANS ? ld(ard[k] + (unsigned)ocd[us(j)][k] + (unsigned)j * COLB) : ld(aru[k] + (unsigned)ocu[us(j)][k] + (unsigned)j * COLB);
       }
       const double l1 = TRANS ? g1d[k] * cy[j][k] : g1u[k] * cx[j][k];
       ar = fma(l1, xl.x, ar);
@@ -268,9 +276,9 @@ struct ColLean {
 };
 
 // per-workgroup machinery: buffers, reductions, the Neumann solver
-template <int Q, int EPT, bool SPLIT = false>
+template <int Q, int EPT, bool SPLIT = false, bool USLOT = false>
 struct ColTeam {
-  typedef ColLean<Q, EPT, SPLIT> ST;
+  typedef ColLean<Q, EPT, SPLIT, USLOT> ST;
   ST st;
   double* red;
   float4* fred;  // two slots of 16 partial sums of the solver's fp32 norm reduction
@@ -451,10 +459,10 @@ __device__ __forceinline__ int slice_start(const SweepArgs& A, int sl) {
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, bool SPLIT>
+template <int Q, int EPT, bool SPLIT, bool USLOT = false>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT, SPLIT> TM;
+  typedef ColTeam<Q, EPT, SPLIT, USLOT> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -589,10 +597,10 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, bool SPLIT>
+template <int Q, int EPT, bool SPLIT, bool USLOT = false>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT, SPLIT> TM;
+  typedef ColTeam<Q, EPT, SPLIT, USLOT> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -807,6 +815,15 @@ bool collean_available(const DevSys& S, const TuneOpts& o) {
   return !qubit && S.post[S.Q - 1] == 1;
 }
 
+// the columns of a wave share the level indices of every oscillator but the stride-1 one (ColLean's USLOT)
+template <int EPT>
+static bool col_uslot(const DevSys& S) {
+  if (S.N % EPT != 0) return false;
+  for (int k = 0; k < S.Q - 1; k++)
+    if (S.post[k] % EPT != 0) return false;
+  return true;
+}
+
 // grid of a sweep: one workgroup per initial condition, or - time-sliced scheduling - as many workgroups as are resident at once
 template <typename K>
 static int col_grid(K kern, const SweepArgs& a, int threads, size_t lds) {
@@ -824,7 +841,7 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  auto kf = k_forward_col<Q, EPT, SPLIT>;
+  auto kf = col_uslot<EPT>(a.S) ? k_forward_col<Q, EPT, SPLIT, true> : k_forward_col<Q, EPT, SPLIT, false>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
@@ -838,7 +855,7 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  auto kf = k_adjoint_col<Q, EPT, SPLIT>;
+  auto kf = col_uslot<EPT>(a.S) ? k_adjoint_col<Q, EPT, SPLIT, true> : k_adjoint_col<Q, EPT, SPLIT, false>;
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
