@@ -318,7 +318,8 @@ class Runner:
         valu_achieved = f_step * units_per_launch / kern_s / 1e12
         vk = "fp32_valu" if self.dtype == "f32mixed" else "fp64_valu"
         spec_peak = FP32_PEAK_TFLOPS if self.dtype == "f32mixed" else FP64_PEAK_TFLOPS
-        traffic = pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_gmres" if spec.solver.linsolve == 0 else ""),
+        # (a gmres request served by a stationary iteration runs the Neumann kernels: only the Krylov kernels have a profile of their own)
+        traffic = pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_krylov" if self.handle.last_solver == "krylov" else ""),
                               self.mode, units_per_launch)
         hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "algorithmic_bytes_per_unit": alg_bytes}

@@ -58,7 +58,7 @@ def main():
     for l in lines[start + 1:]:
         if re.match(r"^[0-9a-f]+ <.*>:$", l):
             break
-        m = re.match(r"\s+(\S.*?)\s+//\s*([0-9A-F]+):", l)
+        m = re.match(r"\s+(\S.*?)\s*//\s*([0-9A-F]+):", l)
         if m:
             ins.append((int(m.group(2), 16), m.group(1)))
     index = {a: i for i, (a, _) in enumerate(ins)}

@@ -48,6 +48,7 @@ def main():
         full = [t for t in full if t >= 0.5 * max(full)]  # (a one-state workload: the check launch has the full grid but few steps)
         d["avg_ms_full_grid"] = sum(full) / len(full)
         d["n_full_grid"] = len(full)
+        d["total_ms_full_grid"] = sum(full)  # (a chunked gradient evaluation launches each sweep once per chunk: divide by the evaluations)
     res["sweep_launches"] = launches
     pmc = {}
     for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
@@ -71,6 +72,7 @@ def main():
         wm = sum(w) / len(w) if w else None
         summary[k] = {
             "launches": max(len(f), len(w)),
+            "hbm_bytes_all_launches_fetch_x2": (2 * sum(f) + sum(w)) * 1024.0,
             "FETCH_SIZE_mean": fm, "WRITE_SIZE_mean": wm,
             "hbm_bytes_per_launch_raw": ((fm or 0) + (wm or 0)) * 1024.0,
             "hbm_bytes_per_launch_fetch_x2": (2 * (fm or 0) + (wm or 0)) * 1024.0,
@@ -84,16 +86,19 @@ def main():
     if len(parts) >= 3:
         key = "_".join(parts[1:])  # r2_c5_f32_fwd -> c5_f32_fwd
         tot, names = 0.0, []
-        for k, v in summary.items():
-            if ("k_forward" in k or "k_adjoint" in k) and "hbm_bytes_per_launch_fetch_x2" in v:
-                tot += v["hbm_bytes_per_launch_fetch_x2"]
-                names.append(k[:60])
-        units = None  # units (time steps x initial conditions) per launch of the profiled command
+        units = evals = None  # units (time steps x initial conditions) per evaluation of the profiled command, evaluations run
         try:
-            line = [l for l in open(os.path.join(out, "bench_pmc_fetch.log")) if l.startswith("{")][-1]
-            units = json.loads(line)["roofline"]["units_per_launch"]
+            line = json.loads([l for l in open(os.path.join(out, "bench_pmc_fetch.log")) if l.startswith("{")][-1])
+            units = line["roofline"]["units_per_launch"]
+            evals = line["steps"] + line["warmup"]
         except Exception:
             pass
+        for k, v in summary.items():
+            if ("k_forward" in k or "k_adjoint" in k) and "hbm_bytes_per_launch_fetch_x2" in v:
+                # bytes per EVALUATION: all launches of the run (a chunked gradient launches each sweep once per chunk; the one small launch
+                # of bench.py's oracle check is in the sum as well) over the evaluations of the run
+                tot += v["hbm_bytes_all_launches_fetch_x2"] / evals if evals else v["hbm_bytes_per_launch_fetch_x2"]
+                names.append(k[:60])
         if names:
             latest_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json")
             latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}

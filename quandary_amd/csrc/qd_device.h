@@ -2498,7 +2498,12 @@ struct Team {
 // ---------------------------------------------------------------------------------------------
 // forward sweep: TimeStepper::solveODE for every initial condition of the batch
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int VAR, bool QUBIT, bool GM>
+// PLAIN: the sweep has no in-loop penalty (leakage, weighted J), no dpdm penalty and an implicit-midpoint stepper - known at launch
+// (plain_sweep(), qd_internal.h).  The small-system kernels (one wave per initial condition) are bound by the NUMBER of instructions a
+// single wave issues per step; with those branches, their registers (dpdm history, guard flags, penalty sums) and the scalar registers
+// they pin compiled out, the 2^4 Schroedinger adjoint step drops from ~1900 static instructions (81 spilt scalar registers, reloaded by
+// ~300 v_readlane per step) to the solve, the gradient contraction and one transposed application.
+template <int Q, bool LIND, int VAR, bool QUBIT, bool GM, bool PLAIN = false>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team<Q, LIND, VAR, QUBIT, GM> TM;
@@ -2516,12 +2521,13 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   team_sync<TM::V::ONEWAVE>();  // coefficient tables written by init()
   tm.publish(x);
   // penalty bookkeeping
-  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool ee = PLAIN ? false : A.stepper_ee != 0;
+  const bool pen_on = PLAIN ? false : A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   // Schroedinger Jtrace is the only objective whose finalizeJ is nonlinear in the per-state sums:
   // it needs a block reduction per step; everything else accumulates thread-locally.
   const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
-  const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
+  const bool dpdm_on = PLAIN ? false : (A.gamma_dpdm > 1e-13 && !LIND);
   const bool jpairs = S.npairs > 0;
   bool guard[EPT];
 #pragma unroll
@@ -2565,7 +2571,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
     double2 rhs[EPT];
     tm.template apply_all<false>(S, c, x, rhs);
     napply++;
-    if (XSTASH && !A.stepper_ee) {  // x is not needed during the linear solve: park it in the output buffer
+    if (XSTASH && !ee) {  // x is not needed during the linear solve: park it in the output buffer
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (tm.ok(j)) {
@@ -2575,7 +2581,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
           xs[dim + e] = x[j].y;
         }
     }
-    if (A.stepper_ee) {
+    if (ee) {
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         x[j].x = fma(c.h, rhs[j].x, x[j].x);
@@ -2708,7 +2714,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
 // the reference's backward recomputation of the Schroedinger primal unnecessary - except for explicit
 // Euler, where the recomputed chain differs from the forward states and defines the reference's gradient)
 // ---------------------------------------------------------------------------------------------
-template <int Q, bool LIND, int VAR, bool QUBIT, bool GM>
+template <int Q, bool LIND, int VAR, bool QUBIT, bool GM, bool PLAIN = false>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team<Q, LIND, VAR, QUBIT, GM> TM;
@@ -2733,7 +2739,8 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     xb[j] = make_double2(xbT[tm.st.it[j]], xbT[dim + tm.st.it[j]]);
   }
   const bool jpairs = S.npairs > 0;
-  if (A.stepper_ee && !LIND) {
+  const bool ee = PLAIN ? false : A.stepper_ee != 0;
+  if (ee && !LIND) {
     // Schroedinger runs of the reference do not store the forward states: the adjoint loop re-computes the primal
     // backwards with the FORWARD stepper and a negative step, xprimal <- xprimal + (tstart - tstop) M(tstop) xprimal
     // (src/timestepper.cpp:229-231 with ExplEuler::evolveFWD :496-507), and so do the dpdm states (:207-211, :236-243).
@@ -2771,7 +2778,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   }
   // Latency-bound variants (few elements per thread) carry x_{n+1} in registers and prefetch x_{n-1} one
   // step ahead; the throughput variants re-read them (L2 / HBM) to keep the register footprint small.
-  constexpr bool CARRY = !TM::V::LEAN;
+  constexpr bool CARRY = !TM::V::LEAN && !PLAIN;  // (PLAIN: nothing in the sweep reads the primal states)
   if (CARRY) load_state(A.nsub, xn);
   double jbar_pen[ICPB], jbar_dpdm[ICPB];
 #pragma unroll
@@ -2780,10 +2787,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     jbar_pen[q] = A.jbar[bq * 3 + 0];
     jbar_dpdm[q] = A.jbar[bq * 3 + 1];
   }
-  const bool pen_on = A.gamma_penalty > 1e-13;
+  const bool pen_on = PLAIN ? false : A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
   const bool wj_reduce = wj_on && !LIND && A.tg.objective_type == QD_OBJ_JTRACE;
-  const bool dpdm_on = A.gamma_dpdm > 1e-13 && !LIND;
+  const bool dpdm_on = PLAIN ? false : (A.gamma_dpdm > 1e-13 && !LIND);
   bool guard[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; j++) guard[j] = A.leak_on && tm.ok(j) && tm.st.is_guard(S, j);
@@ -2791,13 +2798,30 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   const int ntime = A.ntime;
   double2 x[EPT], xnext[CARRY ? EPT : 1];
   if (CARRY) load_state(A.nsub - 1, reinterpret_cast<double2(&)[EPT]>(xnext));  // primal at the start of the last sub-step
+  // Latency-bound variants: the primal stage z and the control row of sub-step s - 1 are fetched while sub-step s is being reversed.
+  // Loaded where they are used, each costs a full global / scalar memory round trip on the critical path of EVERY step of a sweep
+  // that is nothing but one dependent chain per initial condition.
+  constexpr bool ZAHEAD = !TM::V::LEAN;
+  double2 znext[ZAHEAD ? EPT : 1];
+  StepC<Q> cn;
+  auto load_stage = [&](int ss, double2(&dst)[ZAHEAD ? EPT : 1]) {
+#pragma unroll
+    for (int j = 0; j < (ZAHEAD ? EPT : 0); j++) {
+      const double* src = A.ztraj + ((size_t)ss * A.nb + tm.ic(j)) * 2 * dim;
+      dst[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
+    }
+  };
+  if (ZAHEAD && !ee && A.nsub > 0) {
+    load_stage(A.nsub - 1, znext);
+    load_step<Q>(A.ctl + (size_t)(A.nsub - 1) * A.cs, cn, jpairs);
+  }
 
   for (int s = A.nsub - 1; s >= 0; s--) {
     if (CARRY) {
 #pragma unroll
       for (int j = 0; j < EPT; j++) x[j] = xnext[CARRY ? j : 0];
       if (s > 0) load_state(s - 1, reinterpret_cast<double2(&)[EPT]>(xnext));
-    } else if (A.stepper_ee) {
+    } else if (ee) {
       load_state(s, x);
     }
     // ---- penalty adjoints at the end of a full step, using the primal x_n (timestepper.cpp:220-227)
@@ -2876,8 +2900,19 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       }
     }
     StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
-    if (!CARRY) scalarize<Q>(c, jpairs);
+    double2 znow[ZAHEAD ? EPT : 1];
+    if (ZAHEAD && !ee) {
+      c = cn;
+#pragma unroll
+      for (int j = 0; j < (ZAHEAD ? EPT : 0); j++) znow[j] = znext[j];
+      if (s > 0) {
+        load_stage(s - 1, znext);
+        load_step<Q>(A.ctl + (size_t)(s - 1) * A.cs, cn, jpairs);
+      }
+    } else {
+      load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    }
+    if (TM::V::LEAN) scalarize<Q>(c, jpairs);
     c.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     tm.st.prep(S, tm.L, c);
     double cf[2 * Q * ICPB];
@@ -2894,7 +2929,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
             if (threadIdx.x == i) co[i] = cf[q * 2 * Q + i];
         }
     };
-    if (A.stepper_ee) {
+    if (ee) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt * x_adj against x_{n-1}, then
       // x_adj += dt M(tstop)^T x_adj.  The table row of sub-step s holds M(tstart); M(tstop) is row s+1
       // (the last row is followed by one extra row for t = T).
@@ -2938,8 +2973,12 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       double2 z[EPT];
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const double* src = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-        z[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
+        if (ZAHEAD) {
+          z[j] = znow[ZAHEAD ? j : 0];
+        } else {
+          const double* src = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
+          z[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
+        }
       }
       tm.publish(z);
       // gradient coefficients: x^T dM/dp_k z and x^T dM/dq_k z with x := kbar

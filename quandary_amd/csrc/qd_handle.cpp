@@ -395,6 +395,14 @@ extern "C" int qd_set_option(qd_handle* h, const char* key, const char* value) {
   if (!h || !key || !value) return fail(QD_ERR_INVALID, "qd_set_option: null argument");
   if (h->opts.set(key, value) != 0) return fail(QD_ERR_INVALID, std::string("qd_set_option: unknown key or bad value: ") + key + " = " + value);
   h->sub_latch = -1;
+  if (std::string(key) == "gmres_poly") {  // (any setting of the degree starts the tuner over: `auto` re-tunes at the current parameters)
+    h->poly_frozen = false;
+    h->poly_cur = 6;
+    h->poly_lo = 1;
+    h->poly_hi = 0;
+    h->poly_steps = 0;
+    h->poly_slow = 0;
+  }
   h->traj_valid = false;  // (a stored trajectory may have another layout under the new options)
   return QD_OK;
 }
@@ -977,6 +985,21 @@ int qd_handle::forward_finish(double* energy) {
   // Once the bracket has closed (or after eight tuning sweeps) the degree is FROZEN for the life of the handle: from then on two
   // evaluations at the same parameters take the same GMRES path and are bit-identical (a line search compares objectives far below
   // the solver tolerance).  The option gmres_poly fixes the degree from the first sweep on.
+  // A frozen degree is tuned at the parameters of the first sweeps; as an optimisation drives the amplitudes up it can become too low
+  // (k > 1 Krylov vectors per solve, each costing a round of orthogonalisation and basis traffic).  Three consecutive sweeps with
+  // k > 1.5 reopen the tuning - upwards only, so that the evaluations in between stay comparable; qd_set_option(gmres_poly, auto)
+  // starts it over.
+  if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && opts.gmres_poly == 0 && poly_frozen) {
+    const double k = ((double)nap / ((double)nb * (double)nsub) - 1.0) / last_poly;
+    poly_slow = k > 1.5 ? poly_slow + 1 : 0;
+    if (poly_slow >= 3) {
+      poly_frozen = false;
+      poly_slow = 0;
+      poly_steps = 4;  // (at most four more tuning sweeps)
+      poly_lo = last_poly;
+      poly_hi = 0;
+    }
+  }
   if (sol.linsolve == QD_LINSOLVE_GMRES && last_poly > 1 && sol.stepper != QD_STEPPER_EE && opts.gmres_poly == 0 && !poly_frozen) {
     const double per_solve = (double)nap / ((double)nb * (double)nsub);
     const double k = (per_solve - 1.0) / last_poly;

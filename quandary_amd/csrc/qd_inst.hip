@@ -70,6 +70,9 @@ static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream
     return launch_big(reinterpret_cast<const void*>(k_forward_big<QD_Q, kLind, kDense, kGmPart>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart>;
+    if constexpr ((VAR == 0 || VAR == 1) && !kGmPart) {
+      if (plain_sweep(a, cfg)) kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart, true>;
+    }
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3((a.nb + Variant<VAR>::ICPB - 1) / Variant<VAR>::ICPB), dim3(cfg.block), cfg.lds, st, a);
@@ -110,6 +113,9 @@ static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream
     return launch_big(reinterpret_cast<const void*>(k_adjoint_big<QD_Q, kLind, kDense, kGmPart, false>), a, cfg, st);
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;
+    if constexpr ((VAR == 0 || VAR == 1) && !kGmPart) {
+      if (plain_sweep(a, cfg)) kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart, true>;
+    }
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kf, dim3((a.nb + Variant<VAR>::ICPB - 1) / Variant<VAR>::ICPB), dim3(cfg.block), cfg.lds, st, a);

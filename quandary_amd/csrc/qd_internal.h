@@ -157,6 +157,12 @@ struct LaunchCfg {
   size_t lds;
 };
 
+// the sweep runs on the PLAIN instantiation of the small-system kernels (qd_device.h): variants 0 / 1, Neumann kernels, an
+// implicit-midpoint stepper, no in-loop penalty, no dpdm penalty
+inline bool plain_sweep(const SweepArgs& a, const LaunchCfg& cfg) {
+  return (cfg.var == 0 || cfg.var == 1) && !cfg.gmres && !a.stepper_ee && !(a.gamma_penalty > 1e-13) && !(a.gamma_dpdm > 1e-13 && !a.S.lindblad);
+}
+
 // kernel launch wrappers implemented in qd_kernels.hip; all return hipError_t
 hipError_t launch_controls(const DevCtlDesc& d, const double* params, const double* times, const double* hs, int nrows,
                            double* table, int cs, hipStream_t st);

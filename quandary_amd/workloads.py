@@ -109,8 +109,10 @@ WORKLOADS = {
            lambda mode: _qubits(4, False, 1000, 0.01, 30, runtype=mode)),
     "q4": ("4-qubit open system (2^4 Lindblad, dim 256), 256 basis initial conditions, ntime 1000",
            lambda mode: _qubits(4, True, 1000, 0.01, 30, runtype=mode)),
-    "c4": ("C4 3x20 Lindblad (AxC constants), 3600 basis initial conditions, ntime 2500 (500 for gradients)",
-           lambda mode: _axc(2500 if mode == "simulation" else 500, runtype=mode)),
+    # (the AxC time grid for both modes: a gradient evaluation whose stored stages exceed HBM - 3600 x 2500 x 57.6 KB = 518 GB - is propagated
+    #  and reversed in chunks of initial conditions, one pass, qd_optim.cpp: gradient_one_pass)
+    "c4": ("C4 3x20 Lindblad (AxC constants), 3600 basis initial conditions, ntime 2500 (the AxC grid)",
+           lambda mode: _axc(2500, runtype=mode)),
     "c5": ("C5 2^5 Lindblad (dim 1024), 1024 basis initial conditions, ntime 1000, fp64 stencil path",
            lambda mode: _qubits(5, True, 1000, 0.01, 30, runtype=mode)),
     # one pure initial state of the 20 x 20 Lindblad system (dim 160 000): a team of workgroups per state (qd_big.h)

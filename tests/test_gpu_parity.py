@@ -702,6 +702,15 @@ def test_options_and_reproducible_gmres_evaluations():
     vals = [opt.evalF(sp.params0)["objective"] for _ in range(12)]
     assert vals[-1] == vals[-2] == vals[-3]  # frozen: bit-identical
     assert vals[-1] == pytest.approx(vals[0], rel=1e-9)  # the tuning sweeps differ at solver-tolerance level only
+    # the frozen degree was tuned at these parameters; far larger amplitudes need more Krylov vectors per solve at that degree: after three
+    # such sweeps the tuner reopens (upwards), settles again, and evaluations are bit-identical once more; `gmres_poly = auto` starts it over
+    big = 30.0 * sp.params0
+    vb = [opt.evalF(big)["objective"] for _ in range(12)]
+    assert vb[-1] == vb[-2] == vb[-3]
+    assert vb[-1] == pytest.approx(vb[0], rel=1e-8)
+    h.set_option("gmres_poly", "auto")
+    va = [opt.evalF(sp.params0)["objective"] for _ in range(12)]
+    assert va[-1] == va[-2] and va[-1] == pytest.approx(vals[-1], rel=1e-9)
     opt.close(); h.close()
     sp.options = {"gmres_poly": 9, "gmres_split": 0}
     h = capi.Handle(sp)
@@ -1190,6 +1199,13 @@ def test_full_batch_properties_at_baseline_size(name, ninit):
     np.testing.assert_allclose(np.trace(v, axis1=1, axis2=2), 0.0, rtol=0, atol=1e-10)
     assert np.abs(u - u.transpose(0, 2, 1)).max() < 1e-10
     assert np.abs(v + v.transpose(0, 2, 1)).max() < 1e-10
+    if name == "c4":
+        # the full batch through the time-sliced scheduler (automatic from 32 steps per slice on; forced here): 3600 x 4 tasks drawn by 256
+        # resident workgroups, every slice waiting for its predecessor - the same states, bit for bit
+        h.set_option("col_slices", 4)
+        fin4 = h.forward(x0)["final_states"].reshape(ninit, 2, N, N)
+        h.set_option("col_slices", 0)
+        assert np.array_equal(fin4, fin)
     opt.close()
     orc = Oracle(sp)
     rng = np.random.default_rng(99)
