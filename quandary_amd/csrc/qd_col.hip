@@ -410,6 +410,58 @@ struct ColTeam {
     }
     return iter;
   }
+
+  // Forward sub-step in STAGE form.  The reference solves (I - alpha M) k = M x and sets x += h k (ImplMidpoint::evolveFWD,
+  // timestepper.cpp:594-629, alpha = h / 2).  The iterates of its Neumann solver, y_0 = b = M x, y_{m+1} = b + alpha M y_m (SPLIT:
+  // y_0 = P b, y_{m+1} = P (b + alpha C y_m), P = (1 - alpha D)^-1, C = M - D), map one to one onto iterates of the stage
+  // z = x + alpha k:   z_m = x + alpha y_m   satisfies   z_{-1} = x,  z_m = x + alpha M z_{m-1}   (SPLIT: z_m = P (x + alpha C z_{m-1})),
+  // (SPLIT: P x - x = alpha P D x, hence z_0 = P (x + alpha C x) = x + alpha P (D + C) x = x + alpha y_0.)  So the application that
+  // forms b IS the first pass of the same loop, x itself is the right-hand side - it stays in registers and is never parked - and no
+  // separate operator application, no b, no y_0 = P b is needed.  The update norms agree up to the factor alpha:
+  // ||y_m - y_{m-1}|| = ||z_m - z_{m-1}|| / alpha, tested from the second pass on against the same thresholds.  On exit z = x + alpha k
+  // (the primal stage the adjoint sweep reads) and x_{n+1} = 2 z - x.  Returns the RHS applications (passes).
+  // In place of GMRES (A.stop_residual): threshold max(rtol^2 ||b||^2, abstol^2) / kappa^2 with ||b||^2 >= ||y_0||^2 (|1 - alpha D| >= 1:
+  // the diagonal of M has a non-positive real part) taken from the first pass - never looser than the rule it stands for.
+  __device__ __forceinline__ int stage(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&x)[EPT], double2 (&z)[EPT]) {
+    const double sc = A.inv_abs2 / (alpha * alpha);
+    float rel2 = A.rel2, thr = 1.f, d0 = 1.f;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) z[j] = x[j];
+    int iter;
+    for (iter = -1; iter < A.maxiter; iter++) {
+      const unsigned wa = st.tb + (unsigned)st.dlt;
+      double dl = 0.0;
+      double2 prev = z[0];
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 own = z[j];
+        const double2 t = st.template apply<false, SPLIT>(c, j, own, prev, z[j + 1 < EPT ? j + 1 : j]);
+        double2 w;
+        w.x = fma(alpha, t.x, x[j].x);
+        w.y = fma(alpha, t.y, x[j].y);
+        if (SPLIT) w = make_double2(fma(pr[SPLIT ? j : 0], w.x, -pi[SPLIT ? j : 0] * w.y), fma(pr[SPLIT ? j : 0], w.y, pi[SPLIT ? j : 0] * w.x));
+        const double dx = own.x - w.x, dy = own.y - w.y;
+        dl = fma(dx, dx, fma(dy, dy, dl));
+        prev = own;
+        z[j] = w;
+        st.st(wa + (unsigned)j * COLB, w);
+        slot_fence<EPT>();
+      }
+      const float d = sum_f32((float)fmin(dl * sc, 1e30));  // contains the barrier that makes the new iterate readable
+      st.flip();
+      if (iter < 0) {  // first pass: d = ||y_0||^2 / abstol^2
+        if (A.stop_residual) {
+          thr = (float)fmin(fmax(A.reltol * A.reltol * (double)d, 1.0) / A.kappa2, 1e30);  // (d is capped at 1e30: conservative)
+          rel2 = 0.f;
+        }
+        continue;
+      }
+      if (iter == 0) d0 = d;
+      if (d < thr) { iter++; break; }
+      if (d < rel2 * d0) { iter++; break; }
+    }
+    return iter + 1;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -484,7 +536,6 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
   }
   double pen_local = 0.0, pen_uniform = 0.0;
   unsigned long long napply = 0;
-  double* xpark = A.xT + (size_t)ic * 2 * dim;
   // global accesses of the thread's elements: one divergent region per call (rows), uniform branches inside (columns)
   auto store_state = [&](double* dst, const double2(&v)[EPT], bool nt) {
     if (tm.st.rowok) {
@@ -509,37 +560,15 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     scalarize<Q>(c, false);
     if (SPLIT) tm.template set_alpha<false>(0.5 * c.h);
     if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
-    // x is not needed during the linear solve: parked in the output buffer (L2 resident) BEFORE the right-hand side is formed, so that
-    // no control flow separates the operator application from the solver that consumes it
-#ifndef QD_COL_NOSTASH
-    store_state(xpark, x, false);
-#endif
+    // the sub-step in stage form (ColTeam::stage): x is the right-hand side of the solve and stays in registers
     tm.publish(x);
-    double2 rhs[EPT], k[EPT];
-    tm.template apply_all<false>(c, x, rhs);  // rhs = M x (ImplMidpoint::evolveFWD, timestepper.cpp:594)
-    napply += 1 + tm.template neumann<false>(A, c, 0.5 * c.h, rhs, k);
-#ifndef QD_COL_NOSTASH
+    double2 z[EPT];
+    napply += tm.stage(A, c, 0.5 * c.h, x, z);
+    if (A.ztraj) store_state(A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim, z, true);  // read back by the adjoint sweep instead of repeating this solve
 #pragma unroll
-    for (int j = 0; j < EPT; j++) x[j] = make_double2(0.0, 0.0);
-    if (tm.st.rowok) {
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (tm.st.colok(j)) {
-          const int e = tm.st.elem_now(j);
-          x[j] = make_double2(xpark[e], xpark[dim + e]);
-        }
-    }
-#endif
-    if (A.ztraj) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
-      double2 z[EPT];
-#pragma unroll
-      for (int j = 0; j < EPT; j++) z[j] = make_double2(fma(0.5 * c.h, k[j].x, x[j].x), fma(0.5 * c.h, k[j].y, x[j].y));
-      store_state(A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim, z, true);
-    }
-#pragma unroll
-    for (int j = 0; j < EPT; j++) {
-      x[j].x = fma(c.h, k[j].x, x[j].x);
-      x[j].y = fma(c.h, k[j].y, x[j].y);
+    for (int j = 0; j < EPT; j++) {  // x_{n+1} = x + h k = 2 z - x
+      x[j].x = fma(2.0, z[j].x, -x[j].x);
+      x[j].y = fma(2.0, z[j].y, -x[j].y);
     }
     // in-loop penalties at the end of a FULL time step (timestepper.cpp:141-154, :256-298)
     if (pen_on && (s + 1) % A.nstages == 0) {
