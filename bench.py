@@ -678,6 +678,12 @@ def main():
             out["workloads_legend"] = LEGEND
             out["workloads"] = [extra_entry(wn, wm, ws, wd, wo, wsteps, wopt, local_rank, sync, fp64_peak, not args.no_cpu_baseline)
                                 for (wn, wm, ws, wd, wo, wsteps, wopt) in EXTRA]
+            if "cpu_baseline" in out and name == "c4" and mode == "fwd":
+                # the CPU baseline runs the REFERENCE's Neumann iteration (~13 applications per step on this system), the headline the
+                # diagonal-split one (~8): gpu_over_cpu folds that algorithmic change in.  The same iteration on both sides:
+                same = [w for w in out["workloads"] if w.get("n") == "c4" and w.get("m") == "fwd" and w.get("o") == {"neumann_split": 0} and "v" in w]
+                if same:
+                    out["gpu_over_cpu_reference_iteration"] = same[0]["v"] / out["cpu_baseline"]["value"]
     if rank == 0 and multi and not weak:
         # The same workload on ONE GPU (rank 0 alone, after the timed region): the one-GPU point of this strong-scaling series in
         # the same line.

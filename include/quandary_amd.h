@@ -149,6 +149,12 @@ typedef struct qd_solver {
   int32_t maxiter;                     /* linearsolver_maxiter               */
   double abstol;                       /* reference: 1e-10 (timestepper.cpp:536) */
   double reltol;                       /* reference: 1e-20 (timestepper.cpp:535) */
+  /* Stopping tests.  Neumann (timestepper.cpp:716-717): the update norm ||y_{m+1} - y_m|| against abstol, and against reltol times the
+   * first update.  The sweep kernels accumulate the squared update per thread in fp64, scale it by 1 / abstol^2 and reduce it over the
+   * workgroup in FP32 (one DPP / LDS round instead of two fp64 ones): the value is only compared with 1, so the fp32 reduction moves the
+   * stopping point by at most one part in 1e7 of the tolerance - the iteration counts equal the oracle's on every tested shape
+   * (tests assert |applications per step - oracle| < 0.25).  GMRES (Krylov kernels): Hessenberg problem, projections and the
+   * recurrence residual in fp64, stop at max(reltol ||b||, abstol) as KSPGMRES (timestepper.cpp:541-550). */
 } qd_solver;
 
 /* What the forward sweep needs to evaluate objective-dependent terms inside

@@ -273,7 +273,7 @@ struct BigTeam {
     // y_0 = b is read in place (the caller has put a team barrier behind the last write to Bv); the iterates alternate Ya / Yb
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
     float rel2 = (float)(A.reltol * A.reltol), thr = 1.f;
-    float d0 = 1.f;
+    float d0 = 1.f, dprev = 1.f;
     int iter, wb = 0;
     double2* const bufs[2] = {Ya, Yb};
     const double2* cur = Bv;
@@ -334,9 +334,10 @@ struct BigTeam {
       const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the (team) barrier and its fences
       cur = nxt;
       wb ^= 1;
-      if (iter == 0) d0 = d;
-      if (d < thr) { iter++; break; }
+      if (iter == 0) d0 = dprev = d;
+      if (d < thr && standin_ok(A.standin_tau2, d, dprev, thr)) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
+      dprev = d;
     }
     *iters = iter;
     return const_cast<double2*>(cur);

@@ -317,6 +317,29 @@ struct ColTeam {
     block_sum<NV, false>(v, red + redslot * NRED * nw);
     redslot ^= 1;
   }
+  // Workgroup sum in two halves, for values only a few threads need (the 2Q gradient coefficients of a step, written by threads 0 .. 2Q - 1):
+  // every wave leaves its partial sums in LDS; AFTER a later barrier of the caller (the one that publishes the next vector) thread i adds
+  // the partial sums of value i in wave order - the same order, hence the same bits, as block_sum.  Saves the reduction's own barrier and
+  // the nw x NV broadcast reads of every thread.
+  double* pend;
+  template <int NV>
+  __device__ __forceinline__ void sum_post(double (&v)[NV]) {
+    pend = red + redslot * NRED * nw;
+    redslot ^= 1;
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
+    if ((threadIdx.x & 63) == 0) {
+      const int wave = (int)(threadIdx.x >> 6);
+#pragma unroll
+      for (int i = 0; i < NV; i++) pend[i * nw + wave] = v[i];
+    }
+  }
+  // (call after a __syncthreads() that follows sum_post; thread i < NV returns the sum of value i)
+  __device__ __forceinline__ double sum_collect(int i) const {
+    double t = 0.0;
+    for (int w = 0; w < nw; w++) t += pend[i * nw + w];
+    return t;
+  }
   // workgroup sum of the solver's squared update norm (fp32; only compared with a threshold).  One barrier - the one that makes the
   // new iterate readable - and ONE round of LDS latency: the <= 16 partial sums are fetched by four broadcast reads and added as a tree
   // (a loop over the waves would chain 15 dependent LDS round trips in front of every stopping test).
@@ -381,7 +404,7 @@ struct ColTeam {
       rel2 = 0.f;
     }
     publish(y);
-    float d0 = 1.f;
+    float d0 = 1.f, dprev = 1.f;
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
       const unsigned wa = st.tb + (unsigned)st.dlt;
@@ -404,9 +427,10 @@ struct ColTeam {
       }
       const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
       st.flip();
-      if (iter == 0) d0 = d;
-      if (d < thr) { iter++; break; }
+      if (iter == 0) d0 = dprev = d;
+      if (d < thr && standin_ok(A.standin_tau2, d, dprev, thr)) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
+      dprev = d;
     }
     return iter;
   }
@@ -424,7 +448,7 @@ struct ColTeam {
   // the diagonal of M has a non-positive real part) taken from the first pass - never looser than the rule it stands for.
   __device__ __forceinline__ int stage(const SweepArgs& A, const StepC<Q>& c, double alpha, const double2 (&x)[EPT], double2 (&z)[EPT]) {
     const double sc = A.inv_abs2 / (alpha * alpha);
-    float rel2 = A.rel2, thr = 1.f, d0 = 1.f;
+    float rel2 = A.rel2, thr = 1.f, d0 = 1.f, dprev = 1.f;
 #pragma unroll
     for (int j = 0; j < EPT; j++) z[j] = x[j];
     int iter;
@@ -456,9 +480,10 @@ struct ColTeam {
         }
         continue;
       }
-      if (iter == 0) d0 = d;
-      if (d < thr) { iter++; break; }
+      if (iter == 0) d0 = dprev = d;
+      if (d < thr && standin_ok(A.standin_tau2, d, dprev, thr)) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
+      dprev = d;
     }
     return iter + 1;
   }
@@ -735,15 +760,10 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
         slot_fence<EPT>();
       }
     }
-    tm.template sum<2 * Q>(cf);
-    {
-      double* co = A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q;
-#pragma unroll
-      for (int i = 0; i < 2 * Q; i++)
-        if (threadIdx.x == i) co[i] = cf[i];
-    }
+    tm.template sum_post<2 * Q>(cf);
     // xbar += M^T kbar
-    tm.publish(kb);
+    tm.publish(kb);  // (its barrier also completes the coefficient sums)
+    if (threadIdx.x < 2 * Q) A.coeff[((size_t)ic * A.nsub + s) * 2 * Q + threadIdx.x] = tm.sum_collect((int)threadIdx.x);
     double2 t[EPT];
     tm.template apply_all<true>(c, kb, t);
 #pragma unroll

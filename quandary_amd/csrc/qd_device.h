@@ -2023,7 +2023,7 @@ struct Team {
     // 1/abstol^2 keeps the fp32 value away from the subnormal range.
     const double inv_abs2 = 1.0 / (A.abstol * A.abstol);
     const float rel2 = (float)(A.reltol * A.reltol);
-    float d0 = 1.f;
+    float d0 = 1.f, dprev = 1.f;
     int iter;
     if constexpr (V::ONEWAVE && !V::DBUF && EPT == 1 && ICPB == 1 && has_split_fetch<ST>::value) {
       // Single wave, one element per lane (the latency-bound small systems): software-pipelined iteration.  The
@@ -2047,9 +2047,10 @@ struct Team {
           continue;
         }
         const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));
-        if (iter == 0) d0 = d;
-        if (d < 1.f) { iter++; break; }
+        if (iter == 0) d0 = dprev = d;
+        if (d < 1.f && standin_ok(A.standin_tau2, d, dprev, 1.f)) { iter++; break; }
         if (d < rel2 * d0) { iter++; break; }
+        dprev = d;
       }
       return iter;
     }
@@ -2093,9 +2094,10 @@ struct Team {
           if (ok(j)) bufp(cur)[lidx(j)] = y[j];
         team_sync<V::ONEWAVE>();
       }
-      if (iter == 0) d0 = d;
-      if (d < 1.f) { iter++; break; }
+      if (iter == 0) d0 = dprev = d;
+      if (d < 1.f && standin_ok(A.standin_tau2, d, dprev, 1.f)) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
+      dprev = d;
     }
     return iter;
   }

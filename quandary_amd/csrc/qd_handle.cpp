@@ -921,6 +921,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   last_solver = sol.stepper == QD_STEPPER_EE ? QD_SOLVER_NONE : cfg.gmres ? QD_SOLVER_KRYLOV : QD_SOLVER_NEUMANN;
   if (gmres_as_split(cfg, &a.kappa2)) {  // GMRES request served by the diagonal-split iteration of the lean column kernels
     last_solver = QD_SOLVER_GMRES_AS_SPLIT;
+    a.standin_tau2 = (float)(opts.standin_tau * opts.standin_tau);
     cfg.gmres = 0;
     a.use_gmres = 0;
     a.neumann_split = 1;
@@ -931,6 +932,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     cfg.lds = pick_config(S, nb, opts, false).lds;
   } else if (gmres_as_neumann(cfg)) {
     last_solver = QD_SOLVER_GMRES_AS_NEUMANN;
+    a.standin_tau2 = (float)(opts.standin_tau * opts.standin_tau);
     cfg = pick_config(S, nb, opts, false);
     a.use_gmres = 0;
     a.gmres_poly = 1;
@@ -1145,6 +1147,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   last_solver = sol.stepper == QD_STEPPER_EE ? QD_SOLVER_NONE : cfg.gmres ? QD_SOLVER_KRYLOV : QD_SOLVER_NEUMANN;
   if (gmres_as_split(cfg, &a.kappa2)) {
     last_solver = QD_SOLVER_GMRES_AS_SPLIT;
+    a.standin_tau2 = (float)(opts.standin_tau * opts.standin_tau);
     cfg.gmres = 0;
     a.use_gmres = 0;
     a.neumann_split = 1;
@@ -1154,6 +1157,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     cfg.lds = pick_config(S, nb, opts, false, true).lds;
   } else if (gmres_as_neumann(cfg)) {
     last_solver = QD_SOLVER_GMRES_AS_NEUMANN;
+    a.standin_tau2 = (float)(opts.standin_tau * opts.standin_tau);
     cfg = pick_config(S, nb, opts, false, true);
     a.use_gmres = 0;
     a.gmres_poly = 1;

@@ -81,6 +81,14 @@ struct SweepArgs {
   // kappa >= |1 - alpha D_ii| bounds the true residual ||b - (I - alpha M) y_m|| = ||(1 - alpha D)(y_{m+1} - y_m)|| from above
   int stop_residual;
   double kappa2;
+  // A stationary iteration that SERVES A GMRES REQUEST (qd_handle::gmres_as_split / gmres_as_neumann) stops on the update norm like
+  // the reference's Neumann solver, i.e. with an error of ~rho x abstol, rho = its contraction.  KSPGMRES typically ends far below its
+  // tolerance (the last Krylov vector takes the residual down by orders of magnitude): on the reference's xgate_sparsemat case its
+  // gradient sits 8.6e-9 (of the gradient norm) from the exact one, the plain update-norm rule - the reference's own Neumann solver - 1.2e-7;
+  // with tau = 1e-3 (the default) the stand-in lands at 3e-9, one application more per step (profiles/xgate_probe.py).  With standin_tau2 > 0 the stand-ins additionally require the
+  // error ESTIMATE below tau x tolerance: rho^2 d <= tau^2 thr with rho^2 = d / d_previous (squared update norms) - no extra iteration
+  // where the contraction is strong, one more where it is not.  0 for neumann requests (the reference's rule, iteration for iteration).
+  float standin_tau2;
   // Gaussian weights of the weighted-J penalty, one per time step: wjw[n] = exp(-((n + 1) dt - T)^2 / param^2) / param
   // (timestepper.cpp:262-270, :304-315); tabulated once per handle so that the sweep kernels of qd_col.hip need no exp() per step
   const double* wjw;
@@ -135,6 +143,7 @@ struct TuneOpts {
   int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
+  double standin_tau = 1e-3;  // "standin_tau": error-estimate factor of the stationary iterations that serve gmres requests (0 = plain update-norm rule)
   int col_slices = 0;      // "col_slices": time slices of the lean column sweeps (0 = automatic, 1 = none, k = force k)
   int col_min_n = 33;      // "col_min_n": smallest density-matrix dimension N the lean column kernels take over from the eight-elements-per-thread kernel
   int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
@@ -156,6 +165,10 @@ struct LaunchCfg {
   int blocked; // team members own contiguous blocks of the state
   size_t lds;
 };
+
+// stopping rule of a stand-in for GMRES (SweepArgs::standin_tau2): d, dprev = squared update norms of this and the previous iteration
+// (dprev = d in the first one: no contraction estimate yet), thr = the threshold d has already passed
+__device__ __forceinline__ bool standin_ok(float tau2, float d, float dprev, float thr) { return tau2 == 0.f || d * d <= tau2 * thr * dprev; }
 
 // the sweep runs on the PLAIN instantiation of the small-system kernels (qd_device.h): variants 0 / 1, Neumann kernels, an
 // implicit-midpoint stepper, no in-loop penalty, no dpdm penalty

@@ -289,7 +289,7 @@ struct Team32 {
     const R scale = F32 ? (R)1 : (R)(1.0 / (A.abstol * A.abstol));
     const float abs2 = F32 ? (float)(A.abstol * A.abstol) : 1.f;
     const float rel2 = (float)(A.reltol * A.reltol);
-    float d0 = 1.f, tol2 = abs2;
+    float d0 = 1.f, tol2 = abs2, dprev = 1.f;
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
       const f2* src = vec();
@@ -315,8 +315,10 @@ struct Team32 {
         d0 = d;
         if (F32) tol2 = fmaxf(abs2, F32_SOLVER_TOL * F32_SOLVER_TOL * n2);
       }
-      if (F32 ? d <= tol2 : d < 1.f) { iter++; break; }
+      // (fp32-mixed: the iterates cannot get below their fp32 floor - no error-estimate rule there)
+      if (F32 ? d <= tol2 : (d < 1.f && standin_ok(A.standin_tau2, d, iter == 0 ? d : dprev, 1.f))) { iter++; break; }
       if (d < rel2 * d0) { iter++; break; }
+      dprev = d;
     }
     return iter;
   }

@@ -95,7 +95,7 @@ def test_simulation_cases(case, patterns, tmp_path, gmres_mode):
 @pytest.mark.parametrize("case,patterns,grad_rtol", [
     ("AxC_grad_initBasis0", ["expected*.dat"], 1e-8),
     ("AxC_grad_schroedinger", ["rho*.dat"], 1e-8),
-    ("xgate_sparsemat", ["rho*.dat", "population*.dat"], 1e-6),
+    ("xgate_sparsemat", ["rho*.dat", "population*.dat"], 1.2e-8),  # (the golden gradient is 8.6e-9 from the exact one: test_gpu_parity)
 ])
 def test_gradient_cases(case, patterns, grad_rtol, tmp_path, gmres_mode):
     out = _run(case, str(tmp_path), env={"QD_GMRES_SPLIT": gmres_mode})

@@ -65,7 +65,7 @@ def test_axc_observables():
 @pytest.mark.parametrize("case,grad_rtol", [
     ("AxC_grad_initBasis0", 1e-8),     # Lindblad adjoint, matfree <3,20>, 9 initial conditions
     ("AxC_grad_schroedinger", 1e-8),   # Schroedinger adjoint, Jkl != 0, eta != 0, dpdm/energy/weighted-J penalties
-    ("xgate_sparsemat", 1e-7),         # sparse-matrix path of the reference: same math, other rounding
+    ("xgate_sparsemat", 1e-9),         # sparse-matrix path of the reference: same math, other rounding (measured 3.7e-10)
 ])
 def test_gradient_cases(case, grad_rtol):
     sp = load_case(case)
