@@ -707,7 +707,7 @@ static int gradient_one_pass(qd_optim* o, const double* alpha, double* sums, dou
   o->last_alpha.assign(alpha, alpha + h->ndesign);
   PenaltyScope ps(h, o->pen);
   StagesScope ss(h);
-  const int chunk = plan_chunk(h, nl, &o->tg);
+  int chunk = plan_chunk(h, nl, &o->tg);
   if (chunk < 1) return fail(QD_ERR_NOMEM, "qd_optim_evalGradF: one trajectory does not fit in device memory");
   double rb, ib;
   finalize_J_diff(o, 0.0, 0.0, &rb, &ib);  // (constant for the objectives that get here)
@@ -729,10 +729,17 @@ static int gradient_one_pass(qd_optim* o, const double* alpha, double* sums, dou
   double fwd_ms = 0.0, applies = 0.0;
   bool first = true;
   for (int off = 0; off < nl; off += chunk) {
-    const int nc = std::min(chunk, nl - off);
+    int nc = std::min(chunk, nl - off);
     DevTarget t = shifted_target(o, off);
     double energy = 0.0;
-    if ((r = h->forward_dev(o->d_x0.p + (size_t)off * n2, nc, true, &t, &energy))) return r;
+    // plan_chunk looked at the FREE memory; another process on the same device (ranks sharing a GPU) may have taken it since: an
+    // allocation that fails for the first chunk halves the chunk instead of failing the evaluation
+    while ((r = h->forward_dev(o->d_x0.p + (size_t)off * n2, nc, true, &t, &energy)) == QD_ERR_NOMEM && off == 0 && chunk > 1) {
+      (void)hipGetLastError();
+      chunk = (chunk + 1) / 2;
+      nc = std::min(chunk, nl);
+    }
+    if (r) return r;
     add_partial_sums(o, off, nc, energy, sums);
     fwd_ms += h->last_fwd_ms;
     applies += h->last_mean_applies * nc;

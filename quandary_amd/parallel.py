@@ -19,6 +19,7 @@ Communicators (`make_comm`):
 `backend_obj` is anything with forward_local / finalize / adjoint_local (quandary_amd.capi.Optim on a GPU,
 the oracle's sharded API in the CPU tests)."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -36,7 +37,18 @@ class TorchComm:
         self._own = False
         if init and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."), at the first collective: keep stdout for the
+            # one JSON line of bench.py - file descriptor 1 points at stderr until the group has talked once
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self._own = True
         self._bufs = {}
 
