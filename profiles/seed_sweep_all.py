@@ -1,0 +1,41 @@
+"""Wide random sweep of the parity criterion of tests/test_gpu_parity.py (run on the GPU box): every seed in [LO, HI), every solver
+setting.  A case passes if it meets the plain tolerance (objective parts 1e-7 relative, gradient 1e-8 of its norm + 1e-13) or - gmres
+requests only - the stopping-error criterion of helpers.check_parity (no farther from the exact discrete solution than the
+reference-tolerance oracle, factor 1.25 + 1 % of abstol).  Prints every case that passes neither, and a summary.
+
+usage: python profiles/seed_sweep_all.py LO HI"""
+import json
+import os
+import sys
+
+import numpy as np
+
+_r = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_r, "tests"))
+sys.path.insert(0, _r)
+from helpers import check_parity, synthetic_spec, with_gmres_mode  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+from quandary_amd import capi  # noqa: E402
+from test_gpu_parity import _random_case  # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+n = {"plain": 0, "stopping-error": 0, "FAILED": 0}
+for seed in range(lo, hi):
+    kw = _random_case(seed)
+    modes = ["auto", "0"] if kw["linsolve"] == "gmres" and kw["stepper"] != "EE" else [None]
+    orc = Oracle(synthetic_spec(**kw))
+    oval, og = orc.evalGradF(synthetic_spec(**kw).params0)
+    orc.close()
+    for mode in modes:
+        sp = with_gmres_mode(synthetic_spec(**kw), mode)
+        h = capi.Handle(sp)
+        opt = capi.Optim(h, sp)
+        val, g = opt.evalGradF(sp.params0)
+        try:
+            n[check_parity(sp, val, g, oval, og, obj_abs=1e-11, msg=kw)] += 1
+        except AssertionError as e:
+            n["FAILED"] += 1
+            print(json.dumps(dict(seed=seed, mode=mode, solver=h.last_solver, kw=kw, dev=float(np.linalg.norm(g - og)), gnorm=float(np.linalg.norm(og)),
+                                  error=str(e)[:300])), flush=True)
+        opt.close(); h.close()
+print(json.dumps(dict(range=[lo, hi], result=n)))

@@ -786,9 +786,10 @@ int qd_handle::neumann_split_on() const {
 // and every kernel family whose adjoint kernel has not been written to do without (general / global-memory kernels).
 bool qd_handle::adjoint_reads_states(int nb, const qd::DevTarget* tgp) const {
   if (sol.stepper == QD_STEPPER_EE || pen.gamma_penalty_dpdm > 1e-13) return true;
-  LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES);
+  // (the same selection as adjoint_launch makes: the adjoint flag passed through)
+  LaunchCfg cfg = pick_config(S, nb, opts, sol.linsolve == QD_LINSOLVE_GMRES, /*adjoint=*/true);
   if (gmres_as_split(cfg, nullptr)) cfg.gmres = 0;
-  else if (gmres_as_neumann(cfg)) cfg = pick_config(S, nb, opts, false);
+  else if (gmres_as_neumann(cfg)) cfg = pick_config(S, nb, opts, false, true);
   const bool pen_on = pen.gamma_penalty > 1e-13;
   const bool wj = pen_on && tgp && pen.penalty_param > 1e-13;
   bool leak = false;
