@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   double pen_local = 0.0, dpdm_local = 0.0, pen_uniform = 0.0;
   unsigned long long napply = 0;
   const double dtinv4 = 1.0 / (A.dt * A.dt * A.dt * A.dt);
+  vm_drain();
   for (int s = 0; s < A.nsub; s++) {
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
@@ -712,6 +713,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
       tm.tsync();
     }
   }
+  vm_drain();
   for (int s = A.nsub - 1; s >= 0; s--) {
     // ---- penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227)
     if ((pen_on || dpdm_on) && (s + 1) % A.nstages == 0) {

@@ -2505,6 +2505,13 @@ struct Team {
 // single wave issues per step; with those branches, their registers (dpdm history, guard flags, penalty sums) and the scalar registers
 // they pin compiled out, the 2^4 Schroedinger adjoint step drops from ~1900 static instructions (81 spilt scalar registers, reloaded by
 // ~300 v_readlane per step) to the solve, the gradient contraction and one transposed application.
+// All outstanding vector-memory operations have returned.  Placed in front of a time-step loop: the loop carries registers that were
+// filled by global loads before it (initial state, first control row) and by arithmetic inside it; the compiler's wait-count pass merges
+// the two and keeps `s_waitcnt vmcnt(0..1)` in front of the first use of the carried state in EVERY pass - directly behind the prefetch
+// of the next control row, whose L2/HBM latency (~0.25 us of a ~1 us step of the one-wave kernels) was thereby exposed on every step.
+// An explicit wait before the loop is seen by that pass and removes the in-loop one.
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), expcnt / lgkmcnt untouched
+
 template <int Q, bool LIND, int VAR, bool QUBIT, bool GM, bool PLAIN = false>
 __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2550,6 +2557,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
   StepC<Q> c, cn;
   if (PREFETCH) load_step<Q>(A.ctl, cn, jpairs);
 
+  vm_drain();
   for (int s = 0; s < A.nsub; s++) {
     if (PREFETCH) {
       c = cn;
@@ -2818,6 +2826,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     load_step<Q>(A.ctl + (size_t)(A.nsub - 1) * A.cs, cn, jpairs);
   }
 
+  vm_drain();
   for (int s = A.nsub - 1; s >= 0; s--) {
     if (CARRY) {
 #pragma unroll

@@ -71,7 +71,7 @@ static hipError_t go_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart>;
     if constexpr ((VAR == 0 || VAR == 1) && !kGmPart) {
-      if (plain_sweep(a, cfg)) kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart, true>;
+      if (plain_sweep(a, cfg, 0)) kf = k_forward<QD_Q, kLind, VAR, kQubit, kGmPart, true>;
     }
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;
@@ -114,7 +114,7 @@ static hipError_t go_adjoint(const SweepArgs& a, const LaunchCfg& cfg, hipStream
   } else if constexpr (VAR != 16 && variant_built<VAR>()) {
     auto kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart>;
     if constexpr ((VAR == 0 || VAR == 1) && !kGmPart) {
-      if (plain_sweep(a, cfg)) kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart, true>;
+      if (plain_sweep(a, cfg, 1)) kf = k_adjoint<QD_Q, kLind, VAR, kQubit, kGmPart, true>;
     }
     hipError_t e = set_lds(kf, cfg.lds);
     if (e != hipSuccess) return e;

@@ -144,6 +144,7 @@ struct TuneOpts {
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
   double standin_tau = 1e-3;  // "standin_tau": error-estimate factor of the stationary iterations that serve gmres requests (0 = plain update-norm rule)
+  int no_plain = 0;        // "no_plain": 1 / 2 / 3 = forward / adjoint / both sweeps of the small systems on the general instantiation (A/B)
   int col_slices = 0;      // "col_slices": time slices of the lean column sweeps (0 = automatic, 1 = none, k = force k)
   int col_min_n = 33;      // "col_min_n": smallest density-matrix dimension N the lean column kernels take over from the eight-elements-per-thread kernel
   int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
@@ -163,6 +164,7 @@ struct LaunchCfg {
   int team;   // workgroups per initial condition (qd_big.h; 1 everywhere else)
   int spread; // team members dealt over all XCDs instead of one
   int blocked; // team members own contiguous blocks of the state
+  int noplain; // A/B switch (option no_plain): bit 0 keeps the forward sweep, bit 1 the adjoint sweep off the PLAIN instantiation
   size_t lds;
 };
 
@@ -172,8 +174,8 @@ __device__ __forceinline__ bool standin_ok(float tau2, float d, float dprev, flo
 
 // the sweep runs on the PLAIN instantiation of the small-system kernels (qd_device.h): variants 0 / 1, Neumann kernels, an
 // implicit-midpoint stepper, no in-loop penalty, no dpdm penalty
-inline bool plain_sweep(const SweepArgs& a, const LaunchCfg& cfg) {
-  return (cfg.var == 0 || cfg.var == 1) && !cfg.gmres && !a.stepper_ee && !(a.gamma_penalty > 1e-13) && !(a.gamma_dpdm > 1e-13 && !a.S.lindblad);
+inline bool plain_sweep(const SweepArgs& a, const LaunchCfg& cfg, int adjoint) {
+  return !(cfg.noplain & (adjoint ? 2 : 1)) && (cfg.var == 0 || cfg.var == 1) && !cfg.gmres && !a.stepper_ee && !(a.gamma_penalty > 1e-13) && !(a.gamma_dpdm > 1e-13 && !a.S.lindblad);
 }
 
 // kernel launch wrappers implemented in qd_kernels.hip; all return hipError_t

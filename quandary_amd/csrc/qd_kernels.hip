@@ -451,6 +451,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmre
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
   if (S.dense) qubit = false;
   c.qubit = S.dense ? 2 : qubit ? 1 : 0;
+  c.noplain = o.no_plain;
   const bool gm = want_gmres && !o.force_neumann;
   // column layout (V8/V9): one wave per column of rho, N <= 64 lanes used
   // V14 packs floor(64 / N) columns into one wave slot
@@ -557,7 +558,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // options
 // ---------------------------------------------------------------------------------------------
 static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "big_blocked", "f32_sb", "lean64_sb", "no_lean64", "no_collean",
-                                       "col_ept", "col_slices", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb", "standin_tau"};
+                                       "col_ept", "col_slices", "no_plain", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb", "standin_tau"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
   const std::string k(key), v(value);
@@ -591,6 +592,7 @@ int TuneOpts::set(const char* key, const char* value) {
   else if (k == "no_lean64") no_lean64 = iv != 0;
   else if (k == "no_collean") no_collean = iv != 0;
   else if (k == "col_ept") col_ept = (int)iv;
+  else if (k == "no_plain") no_plain = (int)(iv & 3);
   else if (k == "col_slices") col_slices = iv > 0 ? (int)iv : 0;
   else if (k == "col_min_n") col_min_n = iv > 0 ? (int)iv : 33;
   else if (k == "gmres_poly") gmres_poly = iv > 0 ? (int)iv : 0;

@@ -589,6 +589,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
   double pen_local = 0.0, pen_uniform = 0.0;
   unsigned long long napply = 0;
 
+  vm_drain();
   for (int s = 0; s < A.nsub; s++) {
     StepC<Q> c;
     load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
@@ -682,6 +683,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
   const bool pen_on = A.gamma_penalty > 1e-13;
   const bool wj_on = pen_on && A.penalty_param > 1e-13;
 
+  vm_drain();
   for (int s = A.nsub - 1; s >= 0; s--) {
     // penaltyIntegral_diff at the end of a full step, with the primal x_n (timestepper.cpp:220-227, :300-339)
     if (wj_on && (s + 1) % A.nstages == 0) {
