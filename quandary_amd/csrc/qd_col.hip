@@ -318,20 +318,26 @@ struct ColTeam {
     redslot ^= 1;
   }
   // Workgroup sum in two halves, for values only a few threads need (the 2Q gradient coefficients of a step, written by threads 0 .. 2Q - 1):
-  // every wave leaves its partial sums in LDS; AFTER a later barrier of the caller (the one that publishes the next vector) thread i adds
-  // the partial sums of value i in wave order - the same order, hence the same bits, as block_sum.  Saves the reduction's own barrier and
-  // the nw x NV broadcast reads of every thread.
+  // every wave leaves its partial sums in LDS (wave_reduce_scatter: the total of value g ends up in one row of 16 lanes, 21 vector
+  // instructions for the four values of a two-oscillator system where four wave_sum()s are ~120); AFTER a later barrier of the caller (the
+  // one that publishes the next vector) thread i adds the partial sums of value i in wave order.  Saves the reduction's own barrier and the
+  // nw x NV broadcast reads of every thread.
   double* pend;
   template <int NV>
-  __device__ __forceinline__ void sum_post(double (&v)[NV]) {
+  __device__ __forceinline__ void sum_post(const double (&v)[NV]) {
     pend = red + redslot * NRED * nw;
     redslot ^= 1;
-#pragma unroll
-    for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
-    if ((threadIdx.x & 63) == 0) {
+    constexpr int K = ((NV + 1) / 2 + 1) / 2;
+    double o[K];
+    wave_reduce_scatter<NV>(v, o);
+    const int lane = (int)(threadIdx.x & 63);
+    if ((lane & 15) == 0) {
       const int wave = (int)(threadIdx.x >> 6);
 #pragma unroll
-      for (int i = 0; i < NV; i++) pend[i * nw + wave] = v[i];
+      for (int m = 0; m < K; m++) {
+        const int g = wave_scatter_index<NV>(lane >> 4, m);
+        if (g >= 0) pend[g * nw + wave] = o[m];
+      }
     }
   }
   // (call after a __syncthreads() that follows sum_post; thread i < NV returns the sum of value i)

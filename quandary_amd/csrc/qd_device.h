@@ -132,6 +132,47 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// Sums over the 64 lanes of a wave of NV per-lane values of which each total is needed in ONE lane only (the 2Q gradient coefficients of
+// an adjoint step are stored, not consumed): a reduce-scatter.  gfx950's row swaps make the two upper levels a butterfly without selects -
+// v_permlane32_swap(a, b) leaves a' = [a.lo, b.lo], b' = [a.hi, b.hi], so a' + b' is the total over both halves of a in the lower 32 lanes and
+// of b in the upper 32; v_permlane16_swap does the same between the even and the odd rows of 16 - and halve the number of values each
+// (3 instructions per remaining value and level); the four levels inside a row are DPP adds on the K = ceil(ceil(NV / 2) / 2) values
+// that are left.  NV = 8: 42 vector instructions where eight wave_sum()s are ~250.  Afterwards every lane of row r = lane >> 4 holds in
+// out[m] the total of v[wave_scatter_index<NV>(r, m)] (-1: padding).
+typedef unsigned int qd_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double swap_add32(double a, double b) {
+  const qd_u2 l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const qd_u2 h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+  const qd_u2 l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const qd_u2 h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+}
+template <int NV>
+__device__ __forceinline__ constexpr int wave_scatter_index(int r, int m) {
+  constexpr int H = (NV + 1) / 2, K = (H + 1) / 2;
+  const int j = (r & 1) * K + m, g = (r >> 1) * H + j;
+  return (j < H && g < NV) ? g : -1;
+}
+template <int NV>
+__device__ __forceinline__ void wave_reduce_scatter(const double (&v)[NV], double (&out)[((NV + 1) / 2 + 1) / 2]) {
+  constexpr int H = (NV + 1) / 2, K = (H + 1) / 2;
+  double h[H];
+#pragma unroll
+  for (int i = 0; i < H; i++) h[i] = swap_add32(v[i], H + i < NV ? v[H + i < NV ? H + i : 0] : 0.0);
+#pragma unroll
+  for (int m = 0; m < K; m++) {
+    double o = swap_add16(h[m], K + m < H ? h[K + m < H ? K + m : 0] : 0.0);
+    o += dpp_mov<0xB1>(o);   // quad_perm [1,0,3,2]
+    o += dpp_mov<0x4E>(o);   // quad_perm [2,3,0,1]
+    o += dpp_mov<0x124>(o);  // row_ror:4
+    o += dpp_mov<0x128>(o);  // row_ror:8
+    out[m] = o;
+  }
+}
+
 // 1 / sqrt(x), x > 0, to fp64 round-off without fp64 sqrt or division (~40 dependent instructions each): v_rsq_f64 estimate and two
 // Newton steps.  The Hessenberg scalars of the in-kernel GMRES are computed redundantly by every lane on uniform values: their
 // dependent latency is paid in full by the latency-bound small systems.
@@ -224,6 +265,42 @@ __device__ __forceinline__ void block_sum_f32v(float (&v)[NV], double* red) {
     float s = 0.f;
     for (int w = 0; w < nw; w++) s += rf[i * nw + w];
     v[i] = s;
+  }
+}
+
+// Block-wide sums of NV values that are only STORED: *dst(i) = total of v[i] (dst(i) may return null: nothing stored).  Same barrier
+// structure as block_sum (one __syncthreads() in multi-wave blocks, `red` = one of the caller's two alternating slots); the wave level is
+// wave_reduce_scatter(), the totals over the waves are formed by NV threads instead of by every thread.
+template <int NV, bool ONEWAVE, typename F>
+__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* red, F&& dst) {
+  constexpr int K = ((NV + 1) / 2 + 1) / 2;
+  double o[K];
+  wave_reduce_scatter<NV>(v, o);
+  const int lane = threadIdx.x & 63, r = lane >> 4;
+  if (ONEWAVE) {
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int m = 0; m < K; m++) {
+        const int g = wave_scatter_index<NV>(r, m);
+        if (g >= 0)
+          if (double* d = dst(g)) *d = o[m];
+      }
+    }
+    return;
+  }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int m = 0; m < K; m++) {
+      const int g = wave_scatter_index<NV>(r, m);
+      if (g >= 0) red[g * nw + wave] = o[m];
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NV) {
+    double t = 0.0;
+    for (int w = 0; w < nw; w++) t += red[threadIdx.x * nw + w];
+    if (double* d = dst((int)threadIdx.x)) *d = t;
   }
 }
 
@@ -1927,6 +2004,14 @@ struct Team {
     redslot ^= 1;
   }
 
+  // Team-wide sums of NV values that are only STORED (block_sum_store)
+  template <int NV, typename F>
+  __device__ __forceinline__ void sum_store(const double (&v)[NV], F&& dst) {
+    double* red = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
+    redslot ^= 1;
+    block_sum_store<NV, V::ONEWAVE>(v, red, dst);
+  }
+
   __device__ __forceinline__ float sum_f32(float v) {
     double* red = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
     redslot ^= 1;
@@ -2930,15 +3015,10 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
 #pragma unroll
     for (int i = 0; i < 2 * Q * ICPB; i++) cf[i] = 0.0;
     auto store_coeffs = [&]() {
-      tm.template sum<2 * Q * ICPB>(cf);
-#pragma unroll
-      for (int q = 0; q < ICPB; q++)
-        if (tm.icvalid(q)) {
-          double* co = A.coeff + ((size_t)(tm.ic0 + q) * A.nsub + s) * 2 * Q;
-#pragma unroll
-          for (int i = 0; i < 2 * Q; i++)
-            if (threadIdx.x == i) co[i] = cf[q * 2 * Q + i];
-        }
+      tm.template sum_store<2 * Q * ICPB>(cf, [&](int g) -> double* {
+        const int q = ICPB == 1 ? 0 : g / (2 * Q), i = ICPB == 1 ? g : g % (2 * Q);
+        return tm.icvalid(q) ? A.coeff + ((size_t)(tm.ic0 + q) * A.nsub + s) * 2 * Q + i : nullptr;
+      });
     };
     if (ee) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt * x_adj against x_{n-1}, then

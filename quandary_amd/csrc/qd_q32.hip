@@ -247,6 +247,13 @@ struct Team32 {
     redslot ^= 1;
   }
 
+  template <int NV, typename F>
+  __device__ __forceinline__ void sum_store(const double (&v)[NV], F&& dst) {
+    double* r = red + redslot * NRED * NW;
+    redslot ^= 1;
+    block_sum_store<NV, ONEWAVE>(v, r, dst);
+  }
+
   // block-wide sum of two floats; contains the one barrier of a solver iteration (multi-wave blocks)
   __device__ __forceinline__ void sum2_f32(float& a, float& b) {
     a = wave_sum_f32(a);
@@ -742,13 +749,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
         }
       }
     }
-    tm.template sum<2 * Q>(cf);
-    {
-      double* co = A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q;
-#pragma unroll
-      for (int i = 0; i < 2 * Q; i++)
-        if (threadIdx.x == i) co[i] = cf[i];
-    }
+    tm.template sum_store<2 * Q>(cf, [&](int g) -> double* { return A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q + g; });
     // xbar += M^T kbar
     tm.publish(kb);
     f2 t[EPT];
