@@ -616,10 +616,14 @@ def main():
             from quandary_amd.parallel import DistributedObjective
             rs.obj = DistributedObjective(rs.optim, None)
 
-            def shard_step():  # local sweeps only; the reductions of the missing ranks are replaced by this shard's own sums x N
-                sums = rs.optim.forward_local(rs.spec.params0, mode == "grad")
+            def shard_step():  # local sweeps only, no collective: the shard's own sums stand in for the reduced ones
                 if mode == "grad":
-                    rs.optim.adjoint_local(rs.spec.params0, np.asarray(sums) * n)
+                    # both sweeps of the local shard in one call (qd_optim_gradient_local) - what qd_optim_evalGradF_dist runs between its
+                    # collectives, including the one-pass chunking of a shard whose stored stages exceed HBM (C4, N = 2: 1800 x 2500 x 57.6 KB
+                    # = 259 GB next to the solver's work vectors)
+                    rs.optim.gradient_local(rs.spec.params0)
+                else:
+                    rs.optim.forward_local(rs.spec.params0, False)
             for _ in range(warmup):
                 shard_step()
             torch.cuda.synchronize()

@@ -329,6 +329,13 @@ int qd_optim_finalize(qd_optim* o, const double* alpha, const double* global_sum
  * over ranks (:527).  Rank 0 adds the Tikhonov / variation terms (:356-372). */
 int qd_optim_adjoint_local(qd_optim* o, const double* alpha, const double* global_sums, double* grad_local);
 
+/* Both sweeps of the local shard in ONE call, no collective, for a host that reduces by itself (the reference's two MPI_Allreduce,
+ * src/optimproblem.cpp:454-460 and :527): partial[QD_NSUMS] and grad_local[ndesign] are this rank's sums, WITHOUT the regularisation
+ * terms (:356-372; the caller adds them once after its reduction, then qd_optim_finalize on the reduced sums).  A shard whose stored
+ * stages exceed HBM is propagated and reversed in chunks in one pass - the two-call form above has to propagate it twice.  Available
+ * wherever the adjoint seeds do not depend on the reduced cost (src/optimtarget.cpp:889-895): QD_ERR_STATE for Schroedinger + Jtrace. */
+int qd_optim_gradient_local(qd_optim* o, const double* alpha, double* partial, double* grad_local);
+
 /* Single-rank convenience wrappers (nranks must be 1). */
 int qd_optim_evalF(qd_optim* o, const double* alpha, qd_objective_value* val);
 int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective_value* val, double* grad);

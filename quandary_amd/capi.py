@@ -176,7 +176,7 @@ EXPORTS = [
     "qd_set_target", "qd_set_penalty", "qd_forward", "qd_adjoint", "qd_last_mean_applies",
     "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_last_team", "qd_last_solver", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
-    "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_evalF", "qd_optim_evalGradF",
+    "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_gradient_local", "qd_optim_evalF", "qd_optim_evalGradF",
     "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_create_host", "qd_comm_backend", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
     "qd_comm_allreduce", "qd_comm_barrier", "qd_optim_evalF_dist", "qd_optim_evalGradF_dist", "qd_optim_last_chunks", "qd_set_precision", "qd_get_precision", "qd_bench_apply_f32", "qd_get_observables", "qd_set_option",
 ]
@@ -240,6 +240,7 @@ def load_library(path=None):
     lib.qd_optim_forward_local.argtypes = [vp, c_dp, C.c_int, c_dp]
     lib.qd_optim_finalize.argtypes = [vp, c_dp, c_dp, C.POINTER(qd_objective_value)]
     lib.qd_optim_adjoint_local.argtypes = [vp, c_dp, c_dp, c_dp]
+    lib.qd_optim_gradient_local.argtypes = [vp, c_dp, c_dp, c_dp]
     lib.qd_optim_evalF.argtypes = [vp, c_dp, C.POINTER(qd_objective_value)]
     lib.qd_optim_evalGradF.argtypes = [vp, c_dp, C.POINTER(qd_objective_value), c_dp]
     lib.qd_comm_unique_id.argtypes = [c_u8p]
@@ -502,6 +503,14 @@ class Optim:
         g = np.zeros(max(self.h.ndesign, 1))
         _check(self.lib, self.lib.qd_optim_adjoint_local(self._o, dptr(alpha), dptr(sums), dptr(g)), "qd_optim_adjoint_local")
         return g[: self.h.ndesign]
+
+    def gradient_local(self, alpha):
+        """Both sweeps of the local shard, no collective: (partial sums, local gradient without regularisation terms)."""
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        sums = np.zeros(NSUMS)
+        g = np.zeros(max(self.h.ndesign, 1))
+        _check(self.lib, self.lib.qd_optim_gradient_local(self._o, dptr(alpha), dptr(sums), dptr(g)), "qd_optim_gradient_local")
+        return sums, g[: self.h.ndesign]
 
     def evalF(self, alpha):
         alpha = np.ascontiguousarray(alpha, dtype=np.float64)

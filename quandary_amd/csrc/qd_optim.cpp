@@ -790,6 +790,38 @@ extern "C" int qd_optim_evalGradF(qd_optim* o, const double* alpha, qd_objective
   return qd_optim_adjoint_local(o, alpha, sums, grad);
 }
 
+// Both sweeps of this rank's shard in one call, NO collective: for a host that reduces by itself (the reference's MPI_Allreduce pair,
+// src/optimproblem.cpp:454-460 and :527) and wants the library's one-pass handling of a shard whose stored stages exceed HBM, which the
+// two-call form (forward_local, all-reduce, adjoint_local) cannot offer - it has to propagate the shard twice.  Possible wherever the
+// adjoint seeds do not depend on the reduced cost (finalizeJ_diff constant, src/optimtarget.cpp:889-895): everything except Schroedinger +
+// Jtrace.  partial[QD_NSUMS] and grad_local[ndesign] are this rank's sums; no regularisation term is added (the caller adds it once, after
+// its reduction: gamma_tik (alpha - alpha0) and the control-variation term, src/optimproblem.cpp:356-372).
+extern "C" int qd_optim_gradient_local(qd_optim* o, const double* alpha, double* partial, double* grad_local) {
+  if (!o || !partial || !grad_local || (!alpha && o->h->ndesign > 0)) return fail(QD_ERR_INVALID, "qd_optim_gradient_local: null argument");
+  if (seeds_need_global_cost(o))
+    return fail(QD_ERR_STATE, "qd_optim_gradient_local: the adjoint seeds of Schroedinger + Jtrace need the REDUCED cost (src/optimproblem.cpp:495-511); "
+                              "use qd_optim_forward_local, reduce, qd_optim_adjoint_local");
+  int r;
+  StagesScope ss(o->h);
+  o->last_chunks = 1;
+  if ((r = qd_set_params(o->h, alpha, o->h->ndesign))) return r;
+  bool fits;
+  {
+    PenaltyScope ps(o->h, o->pen);
+    fits = trajectory_fits(o->h, o->nlocal, &o->tg);
+  }
+  if (!fits) {
+    QD_HIP(qd::use_device(o->h->device));
+    return gradient_one_pass(o, alpha, partial, grad_local);
+  }
+  if ((r = qd_optim_forward_local(o, alpha, 1, partial))) return r;
+  const int rank_keep = o->rank;
+  o->rank = 1;  // (no regularisation here)
+  r = qd_optim_adjoint_local(o, alpha, partial, grad_local);
+  o->rank = rank_keep;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // multi-GPU evalF / evalGradF: one process per GPU, this rank's shard, RCCL reductions on the handle's stream.
 // Everything between the forward sweep and the last collective stays in HBM: the partial sums are formed by

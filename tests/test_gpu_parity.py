@@ -942,6 +942,59 @@ def test_two_rank_sharding_matches_single_rank():
     h.close()
 
 
+@pytest.mark.parametrize("kw", [
+    pytest.param(dict(nlevels=[2, 2], lindblad=True, penalties=True), id="lindblad-jtrace"),
+    pytest.param(dict(nlevels=[3, 4], lindblad=True, target="pure", objective="Jmeasure", init="diagonal", nspline=6, penalties=True), id="3x4-lindblad-jmeasure"),
+    pytest.param(dict(nlevels=[2, 2], lindblad=False, objective="Jfrobenius", penalties=True), id="schroedinger-jfrobenius"),
+])
+def test_gradient_local_of_both_shards_adds_up(kw):
+    """qd_optim_gradient_local: forward + adjoint of one rank's shard in one call, no collective (the host reduces: src/optimproblem.cpp:454-460,
+    :527).  The partial sums and local gradients of two shards add up to the single-rank evaluation once the regularisation terms (:356-372)
+    are added; the same with a trajectory budget that forces the one-pass chunking of each shard."""
+    sp = synthetic_spec(**{**kw, "ntime": 20})
+    h = capi.Handle(sp)
+    full = capi.Optim(h, sp)
+    val, g = full.evalGradF(sp.params0)
+    full.close()
+    hs = [capi.Handle(sp) for _ in range(2)]
+    shards = [capi.Optim(hs[r], sp, rank=r, nranks=2) for r in range(2)]
+    keep_reg = None
+    nl = shards[0].ninit_local
+    for budget in (0.0, (21 + 20) * 2 * h.dim * 8 * max(1, nl // 2) / 1048576.0):  # (room for half a shard, counting states AND stages)
+        for x in hs:
+            x.set_option("traj_budget_mb", budget)
+        out = [s.gradient_local(sp.params0) for s in shards]
+        if budget and nl >= 4:
+            assert all(s.last_chunks >= 2 for s in shards)
+        sums = out[0][0] + out[1][0]
+        v2 = shards[0].finalize(sp.params0, sums)
+        for k in OBJ_KEYS:
+            assert v2[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15), k
+        # the regularisation gradient = what the single-rank evaluation holds beyond the two local parts: recover it from a two-call evaluation
+        # of the same shards (adjoint_local adds it on rank 0 only)
+        parts = [s.forward_local(sp.params0, store_trajectory=True) for s in shards] if not budget else None
+        if parts is not None:
+            gl = [s.adjoint_local(sp.params0, parts[0] + parts[1]) for s in shards]
+            reg = gl[0] - out[0][1]  # rank 0: local gradient + regularisation
+            np.testing.assert_allclose(gl[1], out[1][1], rtol=1e-12, atol=1e-15 + 1e-13 * np.linalg.norm(g))
+            keep_reg = reg
+        np.testing.assert_allclose(out[0][1] + out[1][1] + keep_reg, g, rtol=1e-10, atol=1e-14 + 1e-12 * np.linalg.norm(g))
+    for s in shards:
+        s.close()
+    for x in hs:
+        x.close()
+    h.close()
+
+
+def test_gradient_local_refuses_schroedinger_jtrace():
+    sp = synthetic_spec([2, 2], lindblad=False, objective="Jtrace", ntime=5)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    with pytest.raises(capi.QuandaryAmdError, match="REDUCED cost"):
+        opt.gradient_local(sp.params0)
+    opt.close(); h.close()
+
+
 def test_stepper_level_forward_and_adjoint_with_host_seeds():
     """qd_forward / qd_adjoint (host-pointer entry points = solveODE / solveAdjointODE for a batch):
     seed the adjoint with an arbitrary cotangent and compare the gradient with finite differences of
