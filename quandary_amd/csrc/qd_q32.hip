@@ -168,15 +168,45 @@ struct Q32 {
     return y;
   }
 
-  // gradient contraction: A = s_b x_b + s_k x_k, B = x_b - x_k (QubitStencil::ladder), all from LDS
-  __device__ __forceinline__ void ladder(const f2* __restrict__ sx, int k, int j, f2& A, f2& B) const {
-    const unsigned it = opaque((unsigned)(threadIdx.x | ((unsigned)j << TB)));
-    const f2 xb = sx[it ^ (1u << brabit(k))], xk = sx[it ^ (1u << ketbit(k))];
-    const bool a = (it >> brabit(k)) & 1, ap = (it >> ketbit(k)) & 1;
-    A.x = (a ? -xb.x : xb.x) + (ap ? -xk.x : xk.x);
-    A.y = (a ? -xb.y : xb.y) + (ap ? -xk.y : xk.y);
-    B.x = xb.x - xk.x;
-    B.y = xb.y - xk.y;
+  // Gradient contraction of all the thread's slots (QubitStencil::ladder: A = s_b x_b + s_k x_k, B = x_b - x_k with the digit signs
+  // s = -1 for digit 1; include/mastereq.hpp:553-604 for two levels), summed over the slots BEFORE the signs are applied:
+  //   cf[2k]     += sum_j  B_j.y w_j.x - B_j.x w_j.y
+  //   cf[2k + 1] += s_b sum_j (x_b,j . w_j) + s_k sum_j (x_k,j . w_j)
+  // The bra digit is a thread invariant for every oscillator, the ket digit for k >= SB and a compile-time constant of the slot below;
+  // neighbours come from the thread-invariant byte offsets of apply() (one address per oscillator and side, the slot is an immediate
+  // offset), the ket neighbours of the slot oscillators from the thread's own registers.  8 fused operations per (slot, oscillator) and
+  // no select - the per-pair form recomputed two addresses, two digit tests and four sign selects for every pair (32 instructions per
+  // pair, 640 per step of the 2^5 system).  Products in R, sums in fp64 (fp32-mixed: QD_PRECISION_F32MIXED, include/quandary_amd.h).
+  __device__ __forceinline__ void ladder_all(const f2* __restrict__ sx, const f2 (&z)[EPT], const f2 (&w)[EPT], double (&cf)[2 * Q]) const {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      double c0 = 0.0, tb = 0.0, tk = 0.0;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const f2 xb = at(sx, ab[k], j);
+        const f2 xk = k < SB ? z[slotflip(j, k)] : at(sx, ak[k], j);
+        const bool kneg = k < SB && slotbit(j, k);  // (compile-time)
+        if constexpr (sizeof(R) == 8) {
+          c0 = fma(xb.y, w[j].x, c0);
+          c0 = fma(-xb.x, w[j].y, c0);
+          c0 = fma(-xk.y, w[j].x, c0);
+          c0 = fma(xk.x, w[j].y, c0);
+          tb = fma(xb.x, w[j].x, tb);
+          tb = fma(xb.y, w[j].y, tb);
+          tk = fma(kneg ? -xk.x : xk.x, w[j].x, tk);
+          tk = fma(kneg ? -xk.y : xk.y, w[j].y, tk);
+        } else {
+          c0 += (double)rfma(xb.y - xk.y, w[j].x, -(xb.x - xk.x) * w[j].y);
+          tb += (double)rfma(xb.x, w[j].x, xb.y * w[j].y);
+          const R t = rfma(xk.x, w[j].x, xk.y * w[j].y);
+          tk += (double)(kneg ? -t : t);
+        }
+      }
+      const bool a = (tid >> brabit(k)) & 1, ap = k >= SB && ((tid >> ketbit(k)) & 1);
+      cf[2 * k] += c0;
+      cf[2 * k + 1] += (a ? -tb : tb) + (ap ? -tk : tk);
+    }
   }
 };
 
@@ -736,19 +766,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
     double cf[2 * Q];
 #pragma unroll
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
-    {
-      const f2* sx = tm.vec();
-#pragma unroll
-      for (int j = 0; j < EPT; j++) {
-#pragma unroll
-        for (int k = 0; k < Q; k++) {
-          f2 Av, Bv;
-          tm.st.ladder(sx, k, j, Av, Bv);
-          cf[2 * k] += (double)rfma(Bv.y, kb[j].x, -Bv.x * kb[j].y);
-          cf[2 * k + 1] += (double)rfma(Av.x, kb[j].x, Av.y * kb[j].y);
-        }
-      }
-    }
+    tm.st.ladder_all(tm.vec(), z, kb, cf);
     tm.template sum_store<2 * Q>(cf, [&](int g) -> double* { return A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q + g; });
     // xbar += M^T kbar
     tm.publish(kb);
