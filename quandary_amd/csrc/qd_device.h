@@ -268,40 +268,36 @@ __device__ __forceinline__ void block_sum_f32v(float (&v)[NV], double* red) {
   }
 }
 
-// Block-wide sums of NV values that are only STORED: *dst(i) = total of v[i] (dst(i) may return null: nothing stored).  Same barrier
-// structure as block_sum (one __syncthreads() in multi-wave blocks, `red` = one of the caller's two alternating slots); the wave level is
-// wave_reduce_scatter(), the totals over the waves are formed by NV threads instead of by every thread.
+// Block-wide sums of NV values that are only STORED: *dst(i) = total of v[i] (dst(i) may return null: nothing stored), in two halves.
+// block_sum_post: the wave level (wave_reduce_scatter); a one-wave block stores at once, a multi-wave block leaves one partial sum per
+// wave and value in `red` (one of the caller's two alternating slots).  block_sum_collect, AFTER a barrier of the caller (the one that
+// publishes the next exchange vector: the reduction has no barrier of its own): NV threads add the partial sums in wave order and store.
 template <int NV, bool ONEWAVE, typename F>
-__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* red, F&& dst) {
+__device__ __forceinline__ void block_sum_post(const double (&v)[NV], double* red, F&& dst) {
   constexpr int K = ((NV + 1) / 2 + 1) / 2;
   double o[K];
   wave_reduce_scatter<NV>(v, o);
   const int lane = threadIdx.x & 63, r = lane >> 4;
-  if (ONEWAVE) {
-    if ((lane & 15) == 0) {
-#pragma unroll
-      for (int m = 0; m < K; m++) {
-        const int g = wave_scatter_index<NV>(r, m);
-        if (g >= 0)
-          if (double* d = dst(g)) *d = o[m];
-      }
-    }
-    return;
-  }
+  if ((lane & 15) != 0) return;
   const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  if ((lane & 15) == 0) {
 #pragma unroll
-    for (int m = 0; m < K; m++) {
-      const int g = wave_scatter_index<NV>(r, m);
-      if (g >= 0) red[g * nw + wave] = o[m];
+  for (int m = 0; m < K; m++) {
+    const int g = wave_scatter_index<NV>(r, m);
+    if (g < 0) continue;
+    if (ONEWAVE) {
+      if (double* d = dst(g)) *d = o[m];
+    } else {
+      red[g * nw + wave] = o[m];
     }
   }
-  __syncthreads();
-  if ((int)threadIdx.x < NV) {
-    double t = 0.0;
-    for (int w = 0; w < nw; w++) t += red[threadIdx.x * nw + w];
-    if (double* d = dst((int)threadIdx.x)) *d = t;
-  }
+}
+template <int NV, bool ONEWAVE, typename F>
+__device__ __forceinline__ void block_sum_collect(const double* red, F&& dst) {
+  if (ONEWAVE || (int)threadIdx.x >= NV) return;
+  const int nw = (blockDim.x + 63) >> 6;
+  double t = 0.0;
+  for (int w = 0; w < nw; w++) t += red[threadIdx.x * nw + w];
+  if (double* d = dst((int)threadIdx.x)) *d = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2004,12 +2000,17 @@ struct Team {
     redslot ^= 1;
   }
 
-  // Team-wide sums of NV values that are only STORED (block_sum_store)
+  // Team-wide sums of NV values that are only STORED (block_sum_post / block_sum_collect): post, then a barrier of the caller, then collect
+  double* pend;
   template <int NV, typename F>
-  __device__ __forceinline__ void sum_store(const double (&v)[NV], F&& dst) {
-    double* red = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
+  __device__ __forceinline__ void sum_store_post(const double (&v)[NV], F&& dst) {
+    pend = L.red + redslot * NRED * ((blockDim.x + 63) >> 6);
     redslot ^= 1;
-    block_sum_store<NV, V::ONEWAVE>(v, red, dst);
+    block_sum_post<NV, V::ONEWAVE>(v, pend, dst);
+  }
+  template <int NV, typename F>
+  __device__ __forceinline__ void sum_store_collect(F&& dst) const {
+    block_sum_collect<NV, V::ONEWAVE>(pend, dst);
   }
 
   __device__ __forceinline__ float sum_f32(float v) {
@@ -3014,12 +3015,13 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
     double cf[2 * Q * ICPB];
 #pragma unroll
     for (int i = 0; i < 2 * Q * ICPB; i++) cf[i] = 0.0;
-    auto store_coeffs = [&]() {
-      tm.template sum_store<2 * Q * ICPB>(cf, [&](int g) -> double* {
-        const int q = ICPB == 1 ? 0 : g / (2 * Q), i = ICPB == 1 ? g : g % (2 * Q);
-        return tm.icvalid(q) ? A.coeff + ((size_t)(tm.ic0 + q) * A.nsub + s) * 2 * Q + i : nullptr;
-      });
+    // (the coefficient sums are completed behind the barrier that publishes the next vector: store_coeffs, tm.publish, collect_coeffs)
+    auto coeff_dst = [&](int g) -> double* {
+      const int q = ICPB == 1 ? 0 : g / (2 * Q), i = ICPB == 1 ? g : g % (2 * Q);
+      return tm.icvalid(q) ? A.coeff + ((size_t)(tm.ic0 + q) * A.nsub + s) * 2 * Q + i : nullptr;
     };
+    auto store_coeffs = [&]() { tm.template sum_store_post<2 * Q * ICPB>(cf, coeff_dst); };
+    auto collect_coeffs = [&]() { tm.template sum_store_collect<2 * Q * ICPB>(coeff_dst); };
     if (ee) {
       // ExplEuler::evolveBWD (timestepper.cpp:506-520): gradient with dt * x_adj against x_{n-1}, then
       // x_adj += dt M(tstop)^T x_adj.  The table row of sub-step s holds M(tstart); M(tstop) is row s+1
@@ -3042,6 +3044,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       c1.g = S.dense ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
       tm.st.prep(S, tm.L, c1);
       tm.publish(xb);
+      collect_coeffs();
       double2 t[EPT];
       tm.template apply_all<true>(S, c1, xb, t);
 #pragma unroll
@@ -3103,6 +3106,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
       store_coeffs();
       // xbar += M^T kbar
       tm.publish(kb);
+      collect_coeffs();
       double2 t[EPT];
       tm.template apply_all<true>(S, c, kb, t);
 #pragma unroll

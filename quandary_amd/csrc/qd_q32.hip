@@ -277,11 +277,17 @@ struct Team32 {
     redslot ^= 1;
   }
 
+  // sums that are only stored (block_sum_post / block_sum_collect of qd_device.h): post, a barrier of the caller, collect
+  double* pend;
   template <int NV, typename F>
-  __device__ __forceinline__ void sum_store(const double (&v)[NV], F&& dst) {
-    double* r = red + redslot * NRED * NW;
+  __device__ __forceinline__ void sum_store_post(const double (&v)[NV], F&& dst) {
+    pend = red + redslot * NRED * NW;
     redslot ^= 1;
-    block_sum_store<NV, ONEWAVE>(v, r, dst);
+    block_sum_post<NV, ONEWAVE>(v, pend, dst);
+  }
+  template <int NV, typename F>
+  __device__ __forceinline__ void sum_store_collect(F&& dst) const {
+    block_sum_collect<NV, ONEWAVE>(pend, dst);
   }
 
   // block-wide sum of two floats; contains the one barrier of a solver iteration (multi-wave blocks)
@@ -767,9 +773,11 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
 #pragma unroll
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
     tm.st.ladder_all(tm.vec(), z, kb, cf);
-    tm.template sum_store<2 * Q>(cf, [&](int g) -> double* { return A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q + g; });
+    auto coeff_dst = [&](int g) -> double* { return A.coeff + ((size_t)ic * A.nsub + s) * 2 * Q + g; };
+    tm.template sum_store_post<2 * Q>(cf, coeff_dst);
     // xbar += M^T kbar
-    tm.publish(kb);
+    tm.publish(kb);  // (its barrier also completes the coefficient sums)
+    tm.template sum_store_collect<2 * Q>(coeff_dst);
     f2 t[EPT];
     tm.template apply_all<true>(kb, t);
     tm.unpark(xb);
