@@ -87,6 +87,27 @@ def test_objective_and_gradient_vs_oracle(kw, penalties):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("kw", [
+    pytest.param(dict(nlevels=[2] * 6, lindblad=False, objective="Jfrobenius", init="diagonal"), id="2^6-schroedinger-one-wave"),
+    pytest.param(dict(nlevels=[2] * 7, lindblad=False, jkl=0.002, detuned=True, target="pure", objective="Jmeasure", init="diagonal"), id="2^7-schroedinger-two-waves"),
+    pytest.param(dict(nlevels=[2] * 8, lindblad=False, target="pure", objective="Jfrobenius", init="pure, 1, 0, 1, 0, 0, 1, 0, 0"), id="2^8-schroedinger-four-waves"),
+    pytest.param(dict(nlevels=[3, 2, 2, 2, 2, 2], lindblad=False, nessential=[2, 2, 2, 2, 2, 2], target="pure", objective="Jmeasure", init="pure, 1, 0, 0, 1, 0, 1"), id="3x2^5-schroedinger-guard"),
+    pytest.param(dict(nlevels=[2, 2, 3], lindblad=True, init="diagonal", target="pure", objective="Jmeasure"), id="2x2x3-lindblad"),
+])
+def test_gradient_with_six_to_eight_oscillators(kw):
+    """Six, seven and eight oscillators (the reference's matrix-free templates stop at five, `src/mastereq.cpp:2977-3239`; its sparse path
+    and this library go on): 12, 14 and 16 gradient coefficients per adjoint step - the padded levels of the wave reduce-scatter
+    (`wave_reduce_scatter<NV>`: NV not a multiple of four) and its cross-wave half."""
+    sp, h, orc = _pair(kw, ntime=12, penalties=True)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) / np.linalg.norm(og) < 1e-8
+    opt.close(); h.close(); orc.close()
+
+
 COL_SHAPES = [SHAPES[3], SHAPES[5], SHAPES[7],
               pytest.param(dict(nlevels=[3, 3, 3], lindblad=True, nessential=[2, 3, 2], jkl=0.004, detuned=True, init="diagonal, 1"), id="3x3x3-lindblad")]
 
