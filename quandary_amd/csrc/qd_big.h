@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
   vm_drain();
   for (int s = 0; s < A.nsub; s++) {
     StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     scalarize<Q>(c, jpairs);
     c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     if (A.traj) {
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     tm.tsync();
     for (int s = A.nsub - 1; s >= 0; s--) {
       StepC<Q> c1;
-      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);  // M(tstop of step s) = row s + 1
+      load_step_k<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);  // M(tstop of step s) = row s + 1
       scalarize<Q>(c1, jpairs);
       c1.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
       const double hneg = -to_scalar(A.ctl[(size_t)s * A.cs]);
@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
       tm.tsync();  // the adjoint solve reads xbar in place
     }
     StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, jpairs);
     scalarize<Q>(c, jpairs);
     c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)s * S.N * S.N : nullptr;
     double cf[2 * Q];
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
           if (tid == i) co[i] = cf[i];
       }
       StepC<Q> c1;
-      load_step<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
+      load_step_k<Q>(A.ctl + (size_t)(s + 1) * A.cs, c1, jpairs);
       scalarize<Q>(c1, jpairs);
       c1.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) + (size_t)(s + 1) * S.N * S.N : nullptr;
       for (int e = tid; e < eend; e += nt) KB[e] = tm.template apply<true>(S, c1, XB, e);
@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_apply_big(const DevSys S, const d
   for (int e = tid; e < eend; e += nt) X[e] = make_double2(x0[e], x0[dim + e]);
   tm.tsync();
   StepC<Q> c;
-  load_step<Q>(ctlrow, c, S.npairs > 0);
+  load_step_k<Q>(ctlrow, c, S.npairs > 0);
   scalarize<Q>(c, S.npairs > 0);
   c.g = DENSE ? reinterpret_cast<const double2*>(S.gtab) : nullptr;  // one-row table of the test hook
   double* yo = yout + (size_t)ic * 2 * dim;

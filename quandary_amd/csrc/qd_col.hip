@@ -275,24 +275,6 @@ struct ColLean {
   }
 };
 
-// Wave-uniform table entries through the SCALAR memory path (constant address space: s_load into scalar registers).  The tables are
-// written by kernels that completed before the sweep was launched.  A vector load with immediate use makes the wave wait for
-// `vmcnt(0)` - the counter retires in order, so the wait also drains every store issued before it: in a gradient evaluation the stage
-// stores of the previous step (a full store round trip per step in front of the first instruction of the next one).  Scalar loads
-// count on lgkmcnt, need no vector registers and no v_readfirstlane.
-typedef const __attribute__((address_space(4))) double* qd_kptr;
-__device__ __forceinline__ double kload(const double* p) { return *(qd_kptr)p; }
-template <int Q>
-__device__ __forceinline__ void load_step_scalar(const double* row, StepC<Q>& c) {
-  qd_kptr r = (qd_kptr)row;
-  c.h = r[0];
-#pragma unroll
-  for (int k = 0; k < Q; k++) {
-    c.p[k] = r[2 + k];
-    c.q[k] = r[2 + Q + k];
-  }
-}
-
 // per-workgroup machinery: buffers, reductions, the Neumann solver
 template <int Q, int EPT, bool SPLIT = false, bool USLOT = false>
 struct ColTeam {
@@ -605,7 +587,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 
   for (int s = s_lo; s < s_hi; s++) {
     StepC<Q> c;
-    load_step_scalar<Q>(A.ctl + (size_t)s * A.cs, c);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
     if (SPLIT) tm.template set_alpha<false>(0.5 * c.h);
     if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
     // the sub-step in stage form (ColTeam::stage): x is the right-hand side of the solve and stays in registers
@@ -752,7 +734,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
       }
     }
     StepC<Q> c;
-    load_step_scalar<Q>(A.ctl + (size_t)s * A.cs, c);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z of the sub-step was stored by the forward sweep
     if (SPLIT) tm.template set_alpha<true>(0.5 * c.h);
     double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
@@ -822,7 +804,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_apply_col(const DevSys
 #pragma unroll
   for (int j = 0; j < EPT; j++) x[j] = tm.st.ok(j) ? make_double2(x0[tm.st.elem(j)], x0[dim + tm.st.elem(j)]) : make_double2(0.0, 0.0);
   StepC<Q> c;
-  load_step<Q>(ctlrow, c, false);
+  load_step_k<Q>(ctlrow, c, false);
   scalarize<Q>(c, false);
   tm.publish(x);
   if (transpose) tm.template apply_all<true>(c, x, y);

@@ -327,9 +327,35 @@ __device__ __forceinline__ void load_step(const double* __restrict__ row, StepC<
     }
   }
 }
+// The same through the SCALAR memory path (constant address space: s_load into scalar registers; the tables were written by kernels that
+// completed before the sweep was launched) - for the many-wave kernels (qd_col.hip, qd_q32.hip, qd_big.h): no vector registers, no
+// v_readfirstlane, and no coupling with the vector-memory counter, which retires in order - a vector load with immediate use also waits
+// for every store issued before it (the stage stores of the previous step in a gradient evaluation).  NOT for the one-wave kernels of
+// this file: scalar loads share lgkmcnt with LDS and return out of order, so every LDS wait of the solver loop behind a prefetched row
+// becomes lgkmcnt(0) and exposes the scalar load (one-lease A/B: 2^4 Schroedinger gradient 2.40 -> 3.52 ms, 2^4 Lindblad forward 2.68 ->
+// 3.41; 2^5 gradient 36.7 -> 36.2, 2^20-element state 19.9 -> 19.2).
+typedef const __attribute__((address_space(4))) double* qd_kptr;
+__device__ __forceinline__ double kload(const double* p) { return *(qd_kptr)p; }
+template <int Q>
+__device__ __forceinline__ void load_step_k(const double* row, StepC<Q>& c, bool with_pairs) {
+  constexpr int NP = Q * (Q - 1) / 2;
+  qd_kptr r = (qd_kptr)row;
+  c.h = r[0];
+#pragma unroll
+  for (int k = 0; k < Q; k++) {
+    c.p[k] = r[2 + k];
+    c.q[k] = r[2 + Q + k];
+  }
+  if (with_pairs) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      c.cs[k] = r[2 + 2 * Q + k];
+      c.sn[k] = r[2 + 2 * Q + NP + k];
+    }
+  }
+}
 
-// Moves a wave-uniform double from vector to scalar registers (the table rows are fetched with vector
-// loads because the compiler cannot prove them read-only).
+// Moves a wave-uniform double from vector to scalar registers.
 __device__ __forceinline__ double to_scalar(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }

@@ -635,7 +635,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
   vm_drain();
   for (int s = 0; s < A.nsub; s++) {
     StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
     tm.st.prep(c);
     const R hf = uniform((R)c.h);
     f2 xs[EPT];
@@ -743,7 +743,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
       }
     }
     StepC<Q> c;
-    load_step<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
     tm.st.prep(c);
     const R hf = uniform((R)c.h);
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694).  The primal stage z = x + h/2 k of the sub-step (:640-652) was stored by
@@ -813,7 +813,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
 #pragma unroll
   for (int j = 0; j < EPT; j++) x[j] = to_r2<R>(make_double2(x0[tm.elem(j)], x0[DIM + tm.elem(j)]));
   StepC<Q> c;
-  load_step<Q>(ctlrow, c, false);
+  load_step_k<Q>(ctlrow, c, false);
   tm.st.prep(c);
   tm.publish(x);
   if (transpose) tm.template apply_all<true>(x, y);
