@@ -608,6 +608,22 @@ template <> struct Traj<double> {
   }
 };
 
+// The stored primal stages are private to a forward / adjoint pair of THESE kernels (never read by the host): one 16-byte access per
+// element in fp64 too (the trajectory proper keeps the [u; v] blocks qd_get_state reads).  qd_handle records the layout a forward sweep
+// stored (ztraj_fmt) and refuses an adjoint sweep of another kernel family on it.
+template <typename R> struct ZTraj : Traj<R> {};
+typedef double traj_d2 __attribute__((ext_vector_type(2)));
+template <> struct ZTraj<double> {
+  __device__ __forceinline__ static void store(double* base, size_t state, int dim, int e, double2 v) {
+    traj_d2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<traj_d2*>(base) + state * dim + e);
+  }
+  __device__ __forceinline__ static double2 load(const double* base, size_t state, int dim, int e) {
+    const traj_d2 t = __builtin_nontemporal_load(reinterpret_cast<const traj_d2*>(base) + state * dim + e);
+    return make_double2(t.x, t.y);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
@@ -659,7 +675,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
         f2 z;
         z.x = rfma((R)0.5 * hf, k[j].x, xr.x);
         z.y = rfma((R)0.5 * hf, k[j].y, xr.y);
-        Traj<R>::store(A.ztraj, (size_t)s * A.nb + ic, DIM, tm.elem(j), z);
+        ZTraj<R>::store(A.ztraj, (size_t)s * A.nb + ic, DIM, tm.elem(j), z);
       }
     }
 #pragma unroll
@@ -767,7 +783,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
     // gradient coefficients x^T dM/dp_k z, x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604): products in R, fp64 sums
     f2 z[EPT];
 #pragma unroll
-    for (int j = 0; j < EPT; j++) z[j] = Traj<R>::load(A.ztraj, (size_t)s * A.nb + ic, DIM, tm.elem(j));
+    for (int j = 0; j < EPT; j++) z[j] = ZTraj<R>::load(A.ztraj, (size_t)s * A.nb + ic, DIM, tm.elem(j));
     tm.publish(z);
     double cf[2 * Q];
 #pragma unroll

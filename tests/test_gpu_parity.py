@@ -1178,6 +1178,28 @@ def test_chunked_gradient_when_the_trajectory_does_not_fit(kw, one_pass):
     opt.close(); h.close()
 
 
+def test_adjoint_refuses_stages_stored_by_another_kernel_family():
+    """The stored primal stages are private to a forward / adjoint kernel pair (the 2^5 kernels keep them interleaved, the general kernels
+    as [u; v] blocks): an option that changes the kernel family between the two sweeps must not be served silently."""
+    sp = synthetic_spec([2, 2, 2, 2, 2], lindblad=True, ntime=3, init="diagonal, 1")
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    nb = opt.ninit_local
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(nb)])
+    h.set_params(sp.params0)
+    h.forward(x0, store_trajectory=True)
+    g_ref = h.adjoint(np.ones_like(x0), np.zeros((nb, 3)))
+    h.forward(x0, store_trajectory=True)
+    h.set_option("no_lean64", 1)
+    # (qd_set_option already invalidates the stored trajectory; the layout tag of the stages is the second line of defence)
+    with pytest.raises(capi.QuandaryAmdError, match="forward sweep"):
+        h.adjoint(np.ones_like(x0), np.zeros((nb, 3)))
+    h.forward(x0, store_trajectory=True)  # the general kernels on their own stages: the same gradient
+    g = h.adjoint(np.ones_like(x0), np.zeros((nb, 3)))
+    np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-13 * np.linalg.norm(g_ref))
+    opt.close(); h.close()
+
+
 def test_error_paths():
     sp = synthetic_spec([2, 2], lindblad=False, ntime=5)
     h = capi.Handle(sp)
