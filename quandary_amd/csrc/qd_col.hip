@@ -275,6 +275,8 @@ struct ColLean {
   }
 };
 
+typedef double col_d2 __attribute__((ext_vector_type(2)));
+
 // per-workgroup machinery: buffers, reductions, the Neumann solver
 template <int Q, int EPT, bool SPLIT = false, bool USLOT = false>
 struct ColTeam {
@@ -594,7 +596,16 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     tm.publish(x);
     double2 z[EPT];
     napply += tm.stage(A, c, 0.5 * c.h, x, z);
-    if (A.ztraj) store_state(A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim, z, true);  // read back by the adjoint sweep instead of repeating this solve
+    if (A.ztraj && tm.st.rowok) {  // the primal stage, read back by the adjoint sweep instead of repeating this solve: private to
+      // this kernel pair, kept interleaved (one 16-byte streaming access per element; qd_handle tags the layout: ztraj_fmt)
+      col_d2* dst = reinterpret_cast<col_d2*>(A.ztraj) + ((size_t)s * A.nb + ic) * dim;
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (tm.st.colok(j)) {
+          const col_d2 t = {z[j].x, z[j].y};
+          __builtin_nontemporal_store(t, dst + tm.st.elem_now(j));
+        }
+    }
 #pragma unroll
     for (int j = 0; j < EPT; j++) {  // x_{n+1} = x + h k = 2 z - x
       x[j].x = fma(2.0, z[j].x, -x[j].x);
@@ -749,7 +760,18 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     for (int i = 0; i < 2 * Q; i++) cf[i] = 0.0;
     {
       double2 z[EPT];
-      load_state(A.ztraj, s, z);
+      {
+        const col_d2* src = reinterpret_cast<const col_d2*>(A.ztraj) + ((size_t)s * A.nb + ic) * dim;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          if (tm.st.ok(j)) {
+            const col_d2 t = __builtin_nontemporal_load(src + tm.st.elem_now(j));
+            z[j] = make_double2(t.x, t.y);
+          } else {
+            z[j] = make_double2(0.0, 0.0);
+          }
+        }
+      }
       tm.publish(z);
       // gradient coefficients x^T dM/dp_k z and x^T dM/dq_k z with x := kbar (mastereq.hpp:553-604)
 #pragma unroll

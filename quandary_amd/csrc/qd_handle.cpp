@@ -949,7 +949,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
-  if (a.ztraj) ztraj_fmt = precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : 0;
+  if (a.ztraj) ztraj_fmt = precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, opts, stream));
   else if (use_col(cfg)) {
@@ -1174,7 +1174,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
-  if (a.ztraj && ztraj_fmt != (precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : 0))
+  if (a.ztraj && ztraj_fmt != (precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0))
     return fail(QD_ERR_STATE, "qd_adjoint: the primal stages were stored by another kernel family (options or precision changed since the forward sweep): repeat the forward sweep");
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, opts, stream));
