@@ -577,10 +577,8 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_forward_big(const SweepArgs A) {
       for (int e = tid; e < eend; e += nt) {
         const double2 k = K[e];
         double2 v = X[e];
-        if (zdst) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
-          zdst[e] = fma(0.5 * c.h, k.x, v.x);
-          zdst[dim + e] = fma(0.5 * c.h, k.y, v.y);
-        }
+        if (zdst)  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve (interleaved pairs)
+          reinterpret_cast<double2*>(zdst)[e] = make_double2(fma(0.5 * c.h, k.x, v.x), fma(0.5 * c.h, k.y, v.y));
         v.x = fma(c.h, k.x, v.x);
         v.y = fma(c.h, k.y, v.y);
         X[e] = v;
@@ -810,7 +808,7 @@ __global__ void __launch_bounds__(BIG_BLOCK) k_adjoint_big(const SweepArgs A) {
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z = x + h/2 k (:640-652) was stored by the forward sweep
     {
       const double* zsrc = A.ztraj + ((size_t)s * A.nb + ic) * 2 * dim;
-      for (int e = tid; e < eend; e += nt) Z[e] = make_double2(zsrc[e], zsrc[dim + e]);
+      for (int e = tid; e < eend; e += nt) Z[e] = reinterpret_cast<const double2*>(zsrc)[e];
     }
     int its;
     {

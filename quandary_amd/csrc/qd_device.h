@@ -2622,6 +2622,18 @@ struct Team {
 // the two and keeps `s_waitcnt vmcnt(0..1)` in front of the first use of the carried state in EVERY pass - directly behind the prefetch
 // of the next control row, whose L2/HBM latency (~0.25 us of a ~1 us step of the one-wave kernels) was thereby exposed on every step.
 // An explicit wait before the loop is seen by that pass and removes the in-loop one.
+// The stored primal stages (SweepArgs::ztraj) are private to a forward / adjoint pair of kernels and never read by the host: interleaved
+// (re, im) pairs, one 16-byte streaming access per element (the trajectory proper keeps the [u; v] blocks qd_get_state reads).
+typedef double qd_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stage_store(double* ztraj, size_t state, int dim, int e, double re, double im) {
+  const qd_d2v t = {re, im};
+  __builtin_nontemporal_store(t, reinterpret_cast<qd_d2v*>(ztraj) + state * dim + e);
+}
+__device__ __forceinline__ double2 stage_load(const double* ztraj, size_t state, int dim, int e) {
+  const qd_d2v t = __builtin_nontemporal_load(reinterpret_cast<const qd_d2v*>(ztraj) + state * dim + e);
+  return make_double2(t.x, t.y);
+}
+
 __device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), expcnt / lgkmcnt untouched
 
 template <int Q, bool LIND, int VAR, bool QUBIT, bool GM, bool PLAIN = false>
@@ -2723,11 +2735,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_forward(const SweepArgs 
       if (A.ztraj) {  // the primal stage z = x + h/2 k: read back by the adjoint sweep instead of repeating this solve
 #pragma unroll
         for (int j = 0; j < EPT; j++)
-          if (tm.ok(j)) {
-            double* dst = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-            __builtin_nontemporal_store(fma(0.5 * c.h, k[j].x, x[j].x), dst + tm.st.it[j]);
-            __builtin_nontemporal_store(fma(0.5 * c.h, k[j].y, x[j].y), dst + dim + tm.st.it[j]);
-          }
+          if (tm.ok(j)) stage_store(A.ztraj, (size_t)s * A.nb + tm.ic(j), dim, tm.st.it[j], fma(0.5 * c.h, k[j].x, x[j].x), fma(0.5 * c.h, k[j].y, x[j].y));
       }
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
@@ -2928,10 +2936,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
   StepC<Q> cn;
   auto load_stage = [&](int ss, double2(&dst)[ZAHEAD ? EPT : 1]) {
 #pragma unroll
-    for (int j = 0; j < (ZAHEAD ? EPT : 0); j++) {
-      const double* src = A.ztraj + ((size_t)ss * A.nb + tm.ic(j)) * 2 * dim;
-      dst[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
-    }
+    for (int j = 0; j < (ZAHEAD ? EPT : 0); j++) dst[j] = stage_load(A.ztraj, (size_t)ss * A.nb + tm.ic(j), dim, tm.st.it[j]);
   };
   if (ZAHEAD && !ee && A.nsub > 0) {
     load_stage(A.nsub - 1, znext);
@@ -3096,8 +3101,7 @@ __global__ void __launch_bounds__(Variant<VAR>::MAXB) k_adjoint(const SweepArgs 
         if (ZAHEAD) {
           z[j] = znow[ZAHEAD ? j : 0];
         } else {
-          const double* src = A.ztraj + ((size_t)s * A.nb + tm.ic(j)) * 2 * dim;
-          z[j] = make_double2(__builtin_nontemporal_load(src + tm.st.it[j]), __builtin_nontemporal_load(src + dim + tm.st.it[j]));
+          z[j] = stage_load(A.ztraj, (size_t)s * A.nb + tm.ic(j), dim, tm.st.it[j]);
         }
       }
       tm.publish(z);

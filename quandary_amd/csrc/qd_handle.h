@@ -146,7 +146,7 @@ struct qd_handle {
   unsigned long long* d_napply = nullptr;
   int last_nb = 0;
   bool traj_valid = false;
-  int ztraj_fmt = 0;  // layout of the stored primal stages: 0 = [u; v] blocks (general kernels), 1 = fp32-mixed, 2 = interleaved fp64 (qd_q32.hip), 3 = interleaved fp64 (qd_col.hip)
+  int ztraj_fmt = 0;  // layout of the stored primal stages: 1 = fp32 pairs (fp32-mixed), 0 / 2 / 3 = fp64 pairs written by the general / 2^5 / lean column kernels (element order of the family)
   double last_mean_applies = 0.0, last_fwd_ms = 0.0, last_adj_ms = 0.0;
   bool accumulate_fwd_ms = false;  // chunked re-propagation (qd_optim_adjoint_local): add the chunks' forward times up
 
