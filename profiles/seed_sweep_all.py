@@ -1,6 +1,6 @@
 """Wide random sweep of the parity criterion of tests/test_gpu_parity.py (run on the GPU box): every seed in [LO, HI), every solver
 setting.  A case passes if it meets the plain tolerance (objective parts 1e-7 relative, gradient 1e-8 of its norm + 1e-13) or - gmres
-requests only - the stopping-error criterion of helpers.check_parity (no farther from the exact discrete solution than the
+requests, and counted separately for the few Neumann requests that need it - the stopping-error criterion of helpers.check_parity (no farther from the exact discrete solution than the
 reference-tolerance oracle, factor 1.25 + 1 % of abstol).  Prints every case that passes neither, and a summary.
 
 usage: python profiles/seed_sweep_all.py LO HI"""
@@ -32,7 +32,16 @@ for seed in range(lo, hi):
         opt = capi.Optim(h, sp)
         val, g = opt.evalGradF(sp.params0)
         try:
-            n[check_parity(sp, val, g, oval, og, obj_abs=1e-11, msg=kw)] += 1
+            try:
+                n[check_parity(sp, val, g, oval, og, obj_abs=1e-11, msg=kw)] += 1
+            except AssertionError as e:
+                if "without a gmres request" not in str(e):
+                    raise
+                # a Neumann request beyond 1e-8: the same criterion against the exact discrete solution (helpers.check_parity, any_solver)
+                check_parity(sp, val, g, oval, og, obj_abs=1e-11, msg=kw, any_solver=True)
+                n["stopping-error (neumann request)"] = n.get("stopping-error (neumann request)", 0) + 1
+                print(json.dumps(dict(seed=seed, mode=mode, solver=h.last_solver, kw=kw, dev=float(np.linalg.norm(g - og)), gnorm=float(np.linalg.norm(og)),
+                                      note="neumann request: passes the stopping-error criterion")), flush=True)
         except AssertionError as e:
             n["FAILED"] += 1
             print(json.dumps(dict(seed=seed, mode=mode, solver=h.last_solver, kw=kw, dev=float(np.linalg.norm(g - og)), gnorm=float(np.linalg.norm(og)),

@@ -122,21 +122,24 @@ def tight_oracle(sp):
         sp.solver.abstol, sp.solver.maxiter, sp.solver.linsolve = keep
 
 
-def check_parity(sp, val, g, oval, og, alpha=None, obj_abs=1e-12, grad_abs=1e-13, msg=None):
+def check_parity(sp, val, g, oval, og, alpha=None, obj_abs=1e-12, grad_abs=1e-13, msg=None, any_solver=False):
     """Objective parts at the reference harness tolerance (rtol 1e-7), gradient at 1e-8 of its norm against the oracle.
 
     A gmres request may miss that by the ORACLE's own stopping error: both sides stop at residual <= abstol = 1e-10 per linear system
     (src/timestepper.cpp:535-550), which over a long time grid or on a tiny gradient norm exceeds 1e-8 relative.  Such an evaluation is then
     held against the exact discrete solution (tight_oracle) instead and must be no farther from it than the reference-tolerance oracle is -
     factor 1.25 (classical against modified Gram-Schmidt stop at slightly different points of the same method) plus 1 % of abstol - and
-    its deviation from the oracle must itself be of the order of abstol.  Returns "plain" or "stopping-error" (which of the two applied)."""
+    its deviation from the oracle must itself be of the order of abstol.  Returns "plain" or "stopping-error" (which of the two applied).
+    any_solver (the wide sweeps of profiles/seed_sweep_all.py): the same criterion for a Neumann request - the reference's Neumann iteration
+    stops on an update norm <= abstol as well (src/timestepper.cpp:713-720), and on gradient norms of 1e-5 its own distance from the exact
+    discrete solution (1e-12 ... 1e-11) exceeds 1e-8 relative (profiles/r4_neumann_marginal_probe.txt)."""
     plain = all(val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=obj_abs) for k in OBJ_KEYS)
     if g is not None:
         plain = plain and np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + grad_abs
     if plain:
         return "plain"
     from quandary_amd import capi
-    assert sp.solver.linsolve == capi.LINSOLVE["gmres"], ("beyond the tolerance without a gmres request", msg)
+    assert any_solver or sp.solver.linsolve == capi.LINSOLVE["gmres"], ("beyond the tolerance without a gmres request", msg)
     tight = tight_oracle(sp)
     a = sp.params0 if alpha is None else alpha
     if g is not None:
