@@ -140,7 +140,7 @@ struct TuneOpts {
   int f32_sb = -1;         // "f32_sb": slot bits of the fp32-mixed 2^4 kernel
   int lean64_sb = 0;       // "lean64_sb": elements per thread of the fp64 2^5 kernels as a power of two (0 = automatic: 2 elements on 512 threads for batches of
                            // at most one state per CU, else 4 on 256; 1 / 2 force)
-  int no_lean64 = 0;       // "no_lean64": 2^5 Lindblad on the general slot kernel
+  int no_lean64 = 0;       // "no_lean64": 2^5 / 2^4 Lindblad on the general slot kernels
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
   double standin_tau = 1e-3;  // "standin_tau": error-estimate factor of the stationary iterations that serve gmres requests (0 = plain update-norm rule)
