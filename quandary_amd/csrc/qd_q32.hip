@@ -29,6 +29,14 @@
 namespace qd {
 
 constexpr float F32_SOLVER_TOL = 2.384185791015625e-07f;  // 2^-22
+// Measurement builds (profiles/q32_ab.sh): scheduling fence after every QD_Q32_FENCE-th slot of a thread (1 in the product)
+#ifndef QD_Q32_FENCE
+#define QD_Q32_FENCE 1
+#endif
+template <int EPT>
+__device__ __forceinline__ void q32_fence(int j) {
+  if ((j % QD_Q32_FENCE) == QD_Q32_FENCE - 1) slot_fence<EPT>();
+}
 
 // R = float: the fp32-mixed sweeps.  R = double: the same lean kernel structure in full fp64 (every value below is a
 // double, the "accumulators" and the exchange vector coincide) - the throughput kernel of the 2^5 Lindblad system in
@@ -64,7 +72,7 @@ struct Q32 {
   R qb[Q], qk[Q];                // q_k with the sign of the bra / ket (k >= SB) digit of this thread [per step]
   R p[Q], q[Q];                  // controls of the current sub-step (wave-uniform)
 
-  __device__ __forceinline__ void init(const DevSys& S) {
+  __device__ __forceinline__ void init(const DevSys& S, bool = false) {
     const unsigned tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
@@ -210,6 +218,191 @@ struct Q32 {
   }
 };
 
+#ifndef QD_F32_UNPACKED
+// fp32-mixed on packed arithmetic [r5].  An element is a (re, im) pair in one 64-bit register pair and every stencil term is ONE
+// v_pk_fma_f32 on it, with broadcast halves of coefficient pairs (op_sel / op_sel_hi) and whole-pair negation (neg_lo + neg_hi) as
+// operand modifiers.  Coefficients are kept two to a register pair - (q_bra, q_ket) lists, T1 coefficients of two oscillators, (Delta, d)
+// of a slot - and the wave-uniform (p_k, q_k) pairs stay in scalar registers, so the pairs cost no more registers than the scalar layout
+// (round 2's compiler-vectorised attempt spilt 102 registers on half-empty pairs).  Products are those of the scalar code; the sums are
+// reassociated (see apply).  What it buys, measured (profiles/r5_rate_probe.json, profiles/r5_q32_ab.txt): on this chip v_fma_f32 issues
+// in 2.56 cycles per wave and SIMD at the reported clock (122.9 TFLOP/s, NOT the fp64 rate: v_fma_f64 4.27 cycles, 73.7), v_pk_fma_f32
+// in 4.41 (142.6 TFLOP/s) - packing halves the instruction count of the solver pass (314 -> 195 vector instructions, 128 of them packed)
+// and shortens its vector-pipe time by 9 %; the 2^5 forward sweep is unchanged within the lease noise (8.88 / 9.16 against 8.94 / 9.00 ms),
+// the gradient evaluation 1.5 % faster (21.3 / 21.6 against 21.7 / 21.9 ms).  -DQD_F32_UNPACKED builds the scalar form for that A/B.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pkv(const float2 a) { return (pk2){a.x, a.y}; }
+__device__ __forceinline__ float2 pkf(const pk2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ pk2 pk_fma(const pk2 a, const pk2 b, const pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pk2 bc(const float a) { return (pk2){a, a}; }
+__device__ __forceinline__ pk2 swp(const pk2 a) { return (pk2){a.y, a.x}; }
+
+template <int Q, int SB>
+struct Q32<Q, SB, float> {
+  typedef float R;
+  typedef float2 f2;
+  static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
+  static constexpr bool ONEWAVE = NT == 64;
+  static constexpr int BPC = 4;
+  static constexpr int MINW = (Q == 5 && SB == 1) ? 2 : (BPC * NT / 256 > 0 ? BPC * NT / 256 : 1);
+  static constexpr unsigned EB = sizeof(f2), ESH = 3;
+  static constexpr unsigned SLOT_BYTES = EB << TB;
+  static_assert(NT >= 64 && NT <= 1024, "block size");
+
+  __device__ static constexpr int brabit(int k) { return Q - 1 - k; }
+  __device__ static constexpr int ketbit(int k) { return 2 * Q - 1 - k; }
+  __device__ static constexpr int slotbit(int j, int k) { return (j >> (SB - 1 - k)) & 1; }
+  __device__ static constexpr int slotflip(int j, int k) { return j ^ (1 << (SB - 1 - k)); }
+
+  // Per-thread coefficients, two to a register pair (component c of a list lives in pair c / 2, half c % 2 - compile-time indices):
+  //   tq: q_k with the sign of the bra digit (c = k), then with the sign of the ket digit for k >= SB (c = Q + k - SB)   [per step]
+  //   tl: thread part of the T1 off-diagonal coefficient of oscillator k, forward OR transposed (init's argument)
+  static constexpr int NTQ = 2 * Q - SB;
+  pk2 cd[EPT];                   // (Delta, d) of slot j
+  unsigned ab[Q], ak[Q], al[Q];  // byte offsets (slot 0) of the bra / ket (k >= SB) / T1 neighbour of oscillator k
+  pk2 tl[(Q + 1) / 2];
+  pk2 tq[(NTQ + 1) / 2];
+  pk2 pq[Q];                     // (p_k, q_k) of the current sub-step (wave-uniform: scalar registers)
+  // A broadcast / swapped / negated operand is free only while instruction selection sees the pair it is built from in the SAME basic
+  // block (op_sel, neg_lo, neg_hi); loop-invariant code motion would otherwise materialise every (c, c) and (p, -p) pair in registers
+  // outside the solver loop - twice the coefficient registers.  here() pins a pair to its point of use (no instruction).
+  __device__ __forceinline__ static pk2 here(pk2 v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  }
+  // (a v_readfirstlane that survives: the builtin is folded away on a value the compiler already knows to be uniform, and the fp32
+  // conversion of a uniform double still lives in a vector register)
+  __device__ __forceinline__ static float to_sgpr(float v) {
+    asm volatile("" : "+v"(v));  // (opaque: the compiler no longer knows the value to be uniform and keeps the instruction)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+  }
+  __device__ __forceinline__ static pk2 here_s(pk2 v) {
+    asm volatile("" : "+s"(v));
+    return v;
+  }
+
+  __device__ __forceinline__ void init(const DevSys& S, bool trans = false) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int it = (int)(tid | ((unsigned)j << TB));
+      double hd = 0.0, hdp = 0.0, d = 0.0;
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const int a = (it >> brabit(k)) & 1, ap = (it >> ketbit(k)) & 1;
+        hd += S.detune[k] * a;
+        hdp += S.detune[k] * ap;
+        d += S.g2[k] * (a * ap - 0.5 * (a + ap)) - S.g1[k] / 2.0 * (a + ap);
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          const int b = (it >> brabit(l)) & 1, bp = (it >> ketbit(l)) & 1;
+          hd -= S.xikl[pair] * a * b;
+          hdp -= S.xikl[pair] * ap * bp;
+          pair++;
+        }
+      }
+      cd[j] = (pk2){(float)(hd - hdp), (float)d};
+    }
+#pragma unroll
+    for (int i = 0; i < (Q + 1) / 2; i++) tl[i] = (pk2){0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (NTQ + 1) / 2; i++) tq[i] = (pk2){0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const unsigned bb = 1u << brabit(k), kb = 1u << ketbit(k);
+      ab[k] = (tid ^ bb) << ESH;
+      ak[k] = k >= SB ? (tid ^ kb) << ESH : 0u;
+      al[k] = k >= SB ? (tid ^ bb ^ kb) << ESH : ab[k];
+      // forward: both digits 0 (the neighbour has both set); transposed: both 1.  The ket digit of a slot oscillator is a slot bit.
+      const bool bra = ((tid & bb) != 0) == trans;
+      const bool ket = k < SB || (((tid & kb) != 0) == trans);
+      tl[k / 2][k % 2] = (bra && ket) ? (float)S.g1off[k] : 0.f;
+      pq[k] = (pk2){0.f, 0.f};
+    }
+  }
+
+  __device__ __forceinline__ void prep(const StepC<Q>& c) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const float pu = to_sgpr((float)c.p[k]), qu = to_sgpr((float)c.q[k]);
+      pq[k] = (pk2){pu, qu};
+      tq[k / 2][k % 2] = ((tid >> brabit(k)) & 1) ? -qu : qu;
+      if (k >= SB) tq[(Q + k - SB) / 2][(Q + k - SB) % 2] = ((tid >> ketbit(k)) & 1) ? -qu : qu;
+    }
+  }
+
+  __device__ __forceinline__ static pk2 at(const f2* __restrict__ sx, unsigned byteoff, int slot) {
+    return *reinterpret_cast<const pk2*>(reinterpret_cast<const char*>(sx) + byteoff + (unsigned)slot * SLOT_BYTES);
+  }
+
+  // y = M x (TRANS = false) or M^T x at slot j: the scalar template above, two components per instruction.  TRANS must be the
+  // argument init() was called with (the T1 coefficients).
+  template <bool TRANS>
+  __device__ __forceinline__ f2 apply(const f2* __restrict__ sx, int j, const f2 (&xall)[EPT]) {
+    const pk2 xs = pkv(xall[j]);
+    // (the pinned value replaces the member: no copy is kept for the next slot)
+    const pk2 cdj = cd[j] = here(cd[j]);
+#pragma unroll
+    for (int i = 0; i < (NTQ + 1) / 2; i++) tq[i] = here(tq[i]);
+#pragma unroll
+    for (int i = 0; i < (Q + 1) / 2; i++) tl[i] = here(tl[i]);
+    // Every p-term and the Hamiltonian diagonal have the form s J(v), J(v) = (v.y, -v.x): they are accumulated as U = sum s v with plain
+    // broadcast coefficients and rotated once at the end, A = V + J(U) - a per-half negation is the one operand form instruction
+    // selection does not fold (it rebuilds the pair with v_xor + v_mov), whole-vector negation and broadcasts it does.
+    pk2 U = bc(cdj.x) * xs, V = {0.f, 0.f}, l1 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      const pk2 pqk = pq[k] = here_s(pq[k]);
+      const pk2 xb = at(sx, ab[k], j);
+      U = pk_fma(bc(pqk.x), xb, U);
+      V = pk_fma(bc(tq[k / 2][k % 2]), xb, V);
+      pk2 xk;
+      if (k < SB) {  // ket neighbour = own slot with the slot bit flipped; the sign of the slot bit is a constant
+        xk = pkv(xall[slotflip(j, k)]);
+        V = pk_fma(bc(pqk.y), slotbit(j, k) ? -xk : xk, V);
+      } else {
+        xk = at(sx, ak[k], j);
+        V = pk_fma(bc(tq[(Q + k - SB) / 2][(Q + k - SB) % 2]), xk, V);
+      }
+      U = pk_fma(bc(pqk.x), -xk, U);
+      // T1 off-diagonal: forward needs both digits 0 (the neighbour has both set), transposed both 1
+      const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
+      if (slot_ok) {
+        const pk2 xl = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+        l1 = pk_fma(bc(tl[k / 2][k % 2]), xl, l1);
+      }
+    }
+    const pk2 A = {V.x + U.y, V.y - U.x};
+    return pkf(pk_fma(bc(cdj.y), xs, TRANS ? -A : A) + l1);
+  }
+
+  // gradient contraction (see the scalar template): products and the sums over a thread's slots in packed fp32, everything after in fp64
+  //   c0 = sum_j (x_b - x_k)_j.y w_j.x - (x_b - x_k)_j.x w_j.y,  tb = sum_j x_b,j . w_j,  tk = sum_j (+-) x_k,j . w_j
+  __device__ __forceinline__ void ladder_all(const f2* __restrict__ sx, const f2 (&z)[EPT], const f2 (&w)[EPT], double (&cf)[2 * Q]) const {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      pk2 c0 = {0.f, 0.f}, tb = {0.f, 0.f}, tk = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const pk2 wj = pkv(w[j]);
+        const pk2 xb = at(sx, ab[k], j);
+        const pk2 xk = k < SB ? pkv(z[slotflip(j, k)]) : at(sx, ak[k], j);
+        const bool kneg = k < SB && slotbit(j, k);  // (compile-time)
+        c0 = pk_fma(swp(xb - xk), (pk2){wj.x, -wj.y}, c0);
+        tb = pk_fma(xb, wj, tb);
+        tk = pk_fma(kneg ? -xk : xk, wj, tk);
+      }
+      const bool a = (tid >> brabit(k)) & 1, ap = k >= SB && ((tid >> ketbit(k)) & 1);
+      const double tbd = (double)tb.x + (double)tb.y, tkd = (double)tk.x + (double)tk.y;
+      cf[2 * k] += (double)c0.x + (double)c0.y;
+      cf[2 * k + 1] += (a ? -tbd : tbd) + (ap ? -tkd : tkd);
+    }
+  }
+};
+#endif  // QD_F32_UNPACKED
+
 // per-workgroup state of the sweeps: LDS exchange buffers, reduction scratch, the Neumann solver (GM: + in-kernel GMRES)
 template <int Q, int SB, typename R, bool GM = false>
 struct Team32 {
@@ -226,14 +419,14 @@ struct Team32 {
   int cur, redslot;
   static constexpr bool PARK = EPT > 1;
 
-  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem) {
+  __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, bool trans = false) {
     buf = reinterpret_cast<f2*>(smem);
     red = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM);
     acc = reinterpret_cast<double2*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW);
     ksc = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0));
     cur = 0;
     redslot = 0;
-    st.init(S);
+    st.init(S, trans);  // (the packed fp32 stencil keeps the T1 coefficients of one direction only)
   }
   static size_t lds_bytes() {
     return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0) + (GM ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
@@ -262,12 +455,12 @@ struct Team32 {
   }
 
   template <bool TRANS>
-  __device__ __forceinline__ void apply_all(const f2 (&x)[EPT], f2 (&y)[EPT]) const {
+  __device__ __forceinline__ void apply_all(const f2 (&x)[EPT], f2 (&y)[EPT]) {
     const f2* sx = vec();
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       y[j] = st.template apply<TRANS>(sx, j, x);
-      slot_fence<EPT>();  // keeps the LDS reads of one slot from being hoisted above the arithmetic of the previous one
+      q32_fence<EPT>(j);  // keeps the LDS reads of one slot from being hoisted above the arithmetic of the previous one
     }
   }
 
@@ -339,19 +532,43 @@ struct Team32 {
       f2* dst = buf + (cur ^ 1) * DIM;
       f2 w[EPT];
       R dl = 0;
+#ifndef QD_F32_UNPACKED
+      if constexpr (F32) {  // update and squared difference on (re, im) pairs
+        pk2 dl2 = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < EPT; j++) {
-        const f2 t = st.template apply<TRANS>(src, j, y);
-        w[j].x = rfma(alpha, t.x, b[j].x);
-        w[j].y = rfma(alpha, t.y, b[j].y);
-        const R dx = y[j].x - w[j].x, dy = y[j].y - w[j].y;
-        dl = rfma(dx, dx, rfma(dy, dy, dl));
-        dst[elem(j)] = w[j];
-        slot_fence<EPT>();
+        for (int j = 0; j < EPT; j++) {
+          const pk2 t = pkv(st.template apply<TRANS>(src, j, y));
+          const pk2 wj = pk_fma(bc(alpha), t, pkv(b[j]));
+          const pk2 dj = pkv(y[j]) - wj;
+          dl2 = pk_fma(dj, dj, dl2);
+          w[j] = pkf(wj);
+          dst[elem(j)] = w[j];
+          q32_fence<EPT>(j);
+        }
+        dl = dl2.x + dl2.y;
+      } else
+#endif
+      {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const f2 t = st.template apply<TRANS>(src, j, y);
+          w[j].x = rfma(alpha, t.x, b[j].x);
+          w[j].y = rfma(alpha, t.y, b[j].y);
+          const R dx = y[j].x - w[j].x, dy = y[j].y - w[j].y;
+          dl = rfma(dx, dx, rfma(dy, dy, dl));
+          dst[elem(j)] = w[j];
+          q32_fence<EPT>(j);
+        }
       }
 #pragma unroll
       for (int j = 0; j < EPT; j++) y[j] = w[j];
       float d = F32 ? (float)dl : (float)fmin((double)(dl * scale), 1e30), n2 = (float)nb2;
+#ifdef QD_Q32_NOSTOP  // measurement build: three iterations per solve, no reduction (results meaningless)
+      team_sync<ONEWAVE>();
+      cur ^= 1;
+      if (iter == 2) { iter++; break; }
+      continue;
+#endif
       sum2_f32(d, n2);  // the barrier that makes dst readable
       cur ^= 1;
       if (iter == 0) {
@@ -730,7 +947,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
   TM tm;
-  tm.init(S, smem);
+  tm.init(S, smem, true);
   const int ic = blockIdx.x;
   double2 xb[EPT];  // the adjoint state: fp64 accumulators
   {
@@ -822,7 +1039,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
   typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   TM tm;
-  tm.init(S, smem);
+  tm.init(S, smem, transpose != 0);
   const int ic = blockIdx.x;
   f2 x[EPT], y[EPT];
   const double* x0 = xin + (size_t)ic * 2 * DIM;
