@@ -233,7 +233,9 @@ _PMC = None
 
 def pmc_traffic(name, mode, units_per_launch):
     """HBM bytes per launch from the committed PMC passes (profiles/pmc_latest.json; FETCH_SIZE x 2 + WRITE_SIZE as
-    the guide prescribes for gfx950), scaled to this launch's number of units; None when not profiled."""
+    the guide prescribes for gfx950), scaled to this launch's number of units, and where that figure comes from:
+    (traffic, source) - (None, None) when not profiled.  source names the summary file, the date and the kernel-source
+    hash the profile was taken on (profiles/srchash.py); stale = the sources of this tree differ."""
     global _PMC
     if _PMC is None:
         try:
@@ -241,9 +243,23 @@ def pmc_traffic(name, mode, units_per_launch):
         except Exception:  # noqa: BLE001
             _PMC = {}
     ent = _PMC.get(f"{name}_{mode}", {})
+    if not ent:
+        return None, None
+    src = {"file": ent.get("source"), "date": ent.get("date"), "csrc_hash": ent.get("csrc_hash"), "counted_in_this_run": False}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from srchash import csrc_hash
+        now = csrc_hash(ROOT)
+        src["csrc_hash_now"] = now
+        src["stale"] = ent.get("csrc_hash") != now
+        if src["stale"]:
+            print(f"bench.py: roofline.traffic of {name}_{mode} comes from {ent.get('source')} taken on kernel sources "
+                  f"{ent.get('csrc_hash')} ({ent.get('date')}); this tree is {now} - re-run profiles/collect.sh", file=sys.stderr)
+    except Exception:  # noqa: BLE001
+        src["stale"] = None
     if ent.get("hbm_bytes_per_unit") is not None:
-        return ent["hbm_bytes_per_unit"] * units_per_launch
-    return ent.get("hbm_bytes_per_launch")
+        return ent["hbm_bytes_per_unit"] * units_per_launch, src
+    return ent.get("hbm_bytes_per_launch"), src
 
 
 class Runner:
@@ -319,8 +335,8 @@ class Runner:
         vk = "fp32_valu" if self.dtype == "f32mixed" else "fp64_valu"
         spec_peak = FP32_PEAK_TFLOPS if self.dtype == "f32mixed" else FP64_PEAK_TFLOPS
         # (a gmres request served by a stationary iteration runs the Neumann kernels: only the Krylov kernels have a profile of their own)
-        traffic = pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_krylov" if self.handle.last_solver == "krylov" else ""),
-                              self.mode, units_per_launch)
+        traffic, traffic_source = pmc_traffic(self.name + ("_f32" if self.dtype == "f32mixed" else "") + ("_krylov" if self.handle.last_solver == "krylov" else ""),
+                                              self.mode, units_per_launch)
         hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "algorithmic_bytes_per_unit": alg_bytes}
         valu = {"achieved": valu_achieved, "peak": spec_peak, "unit": "TFLOP/s", "frac": valu_achieved / spec_peak,
@@ -335,7 +351,7 @@ class Runner:
         primary = hbm if hbm_bound else valu
         roof = {
             "bound": "hbm" if hbm_bound else vk, "achieved": primary["achieved"], "peak": primary["peak"], "unit": primary["unit"],
-            "frac": primary["frac"], "traffic": traffic,
+            "frac": primary["frac"], "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "k_forward" if self.mode == "fwd" else "k_forward+k_adjoint",
             "kernel_ms_per_launch": kern_s * 1e3, "units_per_launch": units_per_launch,
             "algorithmic_bytes_per_unit": alg_bytes,
@@ -511,6 +527,8 @@ def main():
         backend = "nccl" if ndev >= world else "host"
     if multi and backend in ("gloo", "host"):
         local_rank = local_rank % max(ndev, 1)  # ranks may share a GPU in this mode
+        if world > max(ndev, 1):  # (the time-sliced sweeps wait longer for a predecessor when other processes use the device: qd_col.hip)
+            os.environ.setdefault("QD_DEVICE_SHARERS", str(-(-world // max(ndev, 1))))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     comm = make_comm(backend, rank, world, local_rank, allow_fallback=fallback_ok) if multi else None
@@ -592,7 +610,7 @@ def main():
         rg.close()
         if rank == 0:
             g = {"mode": gcfg["mode"], "ntime": gcfg["ntime"], "value": gval, "grad_wall_ms": gel / steps * 1e3,
-                 "kernel_ms_per_launch": groof["kernel_ms_per_launch"], "hbm_frac": groof["frac"],
+                 "kernel_ms_per_launch": groof["kernel_ms_per_launch"], "roofline_bound": groof["bound"], "roofline_frac": groof["frac"],
                  "allreduce_ms_per_step": {"objective_sums": gar[0] / steps, "gradient": gar[1] / steps}}
             if not weak:
                 try:
@@ -689,8 +707,11 @@ def main():
                 # the CPU baseline runs the REFERENCE's Neumann iteration (~13 applications per step on this system), the headline the
                 # diagonal-split one (~8): gpu_over_cpu folds that algorithmic change in.  The same iteration on both sides:
                 same = [w for w in out["workloads"] if w.get("n") == "c4" and w.get("m") == "fwd" and w.get("o") == {"neumann_split": 0} and "v" in w]
-                if same:
-                    out["gpu_over_cpu_reference_iteration"] = same[0]["v"] / out["cpu_baseline"]["value"]
+                if same:  # lead with the like-for-like ratio; the mixed one keeps its own name
+                    out["gpu_over_cpu_mixed_iterations"] = out["gpu_over_cpu"]
+                    out["gpu_over_cpu"] = same[0]["v"] / out["cpu_baseline"]["value"]
+                    out["gpu_over_cpu_note"] = ("gpu_over_cpu: GPU and CPU both on the reference's Neumann iteration (workloads entry c4 fwd neumann_split=0); "
+                                                "gpu_over_cpu_mixed_iterations: the headline's diagonal-split iteration against the CPU's reference iteration")
     if rank == 0 and multi and not weak:
         # The same workload on ONE GPU (rank 0 alone, after the timed region): the one-GPU point of this strong-scaling series in
         # the same line.

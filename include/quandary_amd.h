@@ -357,10 +357,12 @@ typedef struct qd_comm qd_comm;
 int qd_comm_unique_id(unsigned char id[QD_COMM_ID_BYTES]);
 int qd_comm_create(const unsigned char id[QD_COMM_ID_BYTES], int rank, int nranks, int device_ordinal, qd_comm** out);
 /* MPI-free bootstrap through a path every rank can see.  RCCL backend: rank 0 writes the id file, every other rank echoes the token it read
- * (path.ack<rank>) and rank 0 confirms with path.go before anyone calls ncclCommInitRank - a leftover file of a crashed run is never used;
+ * together with a nonce of its own (path.ack<rank>) and rank 0 answers each echo with path.go<rank> carrying that nonce; a rank enters
+ * ncclCommInitRank only on a go file that returns its own nonce - leftover files of a crashed run are never acted upon;
  * QD_JOB_ID (when the launcher sets one) additionally separates jobs.  Host backend (below): the path only names the shared-memory segment.
- * Backend: environment QD_COMM_BACKEND = rccl | host | auto (default auto: host when nranks exceeds the number of visible GPUs, i.e. when
- * ranks share a device, which RCCL refuses). */
+ * Backend: environment QD_COMM_BACKEND = rccl | host | auto (default auto: host when the ranks OF THIS NODE - QD_LOCAL_SIZE, set by the
+ * launchers; nranks without it - exceed the visible GPUs, i.e. when ranks share a device, which RCCL refuses; refused when such a launch
+ * spans nodes). */
 int qd_comm_create_from_file(const char* path, int rank, int nranks, int device_ordinal, double timeout_s, qd_comm** out);
 /* HOST backend: the ranks of ONE node reduce through a POSIX shared-memory segment named after `name` (the same string on every rank of a
  * job, different for concurrent jobs).  Same call sites and buffers as the RCCL backend (qd_optim_evalF_dist / evalGradF_dist,

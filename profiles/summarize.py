@@ -102,7 +102,10 @@ def main():
         if names:
             latest_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json")
             latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
-            latest[key] = {"hbm_bytes_per_launch": tot, "units_per_launch": units,
+            import datetime
+            from srchash import csrc_hash
+            latest[key] = {"csrc_hash": csrc_hash(), "date": datetime.date.today().isoformat(),
+                           "hbm_bytes_per_launch": tot, "units_per_launch": units,
                            "hbm_bytes_per_unit": (tot / units) if units else None, "kernels": names, "source": f"profiles/{tag}_summary.json",
                            "correction": "FETCH_SIZE x2 (gfx950, calibrated on this kernel's 8-byte loads) + WRITE_SIZE, units of 1 KiB"}
             json.dump(latest, open(latest_path, "w"), indent=1)

@@ -504,8 +504,9 @@ struct ColTeam {
 // A.sched set the sweep is cut into A.nslice slices of whole time steps and a resident grid draws (slice, initial condition) tasks from
 // a counter, slice-major: the tail shrinks to one SLICE.  Slice k of an initial condition waits for slice k - 1 (a flag per initial
 // condition, released at agent scope after the state has been written back; the predecessor was drawn earlier, hence is running or
-// done: no deadlock whatever the dispatch order) and picks the state up from the carry buffer.  A wait that exceeds ~4 s raises the
-// error word instead of hanging the device.
+// done: no deadlock whatever the dispatch order) and picks the state up from the carry buffer.  A wait that exceeds A.sched_ticks (4 s x
+// the processes sharing the device x the slice length in thousands of steps, qd_handle::arm_slices) raises the error word instead of
+// hanging the device.
 //   sched[0] task counter | sched[1] error word | sched[2 + ic] slices of ic completed
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sched_next(unsigned* sched, unsigned* slot) {
@@ -515,12 +516,12 @@ __device__ __forceinline__ int sched_next(unsigned* sched, unsigned* slot) {
   return __builtin_amdgcn_readfirstlane((int)*slot);
 }
 // wait until `want` slices of initial condition ic are complete; false after the time limit
-__device__ __forceinline__ bool sched_wait(unsigned* sched, int ic, unsigned want) {
+__device__ __forceinline__ bool sched_wait(unsigned* sched, int ic, unsigned want, unsigned long long limit) {
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();  // 100 MHz
     while (__hip_atomic_load(sched + 2 + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 400000000ull) {
+      if (wall_clock64() - t0 > limit) {
         atomicExch(sched + 1, 1u);
         break;
       }
@@ -559,7 +560,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
   for (int task = A.sched ? sched_next(A.sched, &task_slot) : (int)blockIdx.x; task < ntask; task = A.sched ? sched_next(A.sched, &task_slot) : ntask) {
   const int ic = task % A.nb, sl = task / A.nb;
   const int s_lo = slice_start(A, sl), s_hi = slice_start(A, sl + 1);
-  if (sl > 0 && !sched_wait(A.sched, ic, (unsigned)sl)) return;
+  if (sl > 0 && !sched_wait(A.sched, ic, (unsigned)sl, A.sched_ticks)) return;
   double2 x[EPT];
   {
     // slice 0 starts from the initial condition, every other one from where its predecessor left the state (the carry = xT)
@@ -683,7 +684,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
   // backwards in time: task slice sl covers the time slice nslice - 1 - sl
   const int ic = task % A.nb, sl = task / A.nb;
   const int s_lo = slice_start(A, A.nslice - 1 - sl), s_hi = slice_start(A, A.nslice - sl);
-  if (sl > 0 && !sched_wait(A.sched, ic, (unsigned)sl)) return;
+  if (sl > 0 && !sched_wait(A.sched, ic, (unsigned)sl, A.sched_ticks)) return;
   double2 xb[EPT];
   {
     const double* xbT = (sl > 0 ? A.stash : A.xbarT) + (size_t)ic * 2 * dim;  // (the carry of the adjoint state: SweepArgs::stash)

@@ -22,6 +22,9 @@
 #include <string>
 #include <vector>
 #include <sys/stat.h>
+#include <signal.h>
+#include <cerrno>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -119,6 +122,7 @@ struct HostSeg {
   int pad_;
   HostFlag hello[kHostMaxRanks], ack[kHostMaxRanks];    // bootstrap handshake
   HostFlag arrive[kHostMaxRanks], done[kHostMaxRanks];  // per-round sequence numbers
+  HostFlag pid[kHostMaxRanks];                          // process ids (liveness of a peer a collective waits for)
   // followed by nranks slots of kHostSlot doubles
   double* slot(int r) { return reinterpret_cast<double*>(reinterpret_cast<char*>(this) + sizeof(HostSeg)) + (size_t)r * kHostSlot; }
 };
@@ -132,7 +136,7 @@ struct HostRing {
 };
 }  // namespace qd
 
-static constexpr unsigned long long kHostMagic = 0x51444853484d3031ull;  // "QDHSHM01"
+static constexpr unsigned long long kHostMagic = 0x51444853484d3032ull;  // "QDHSHM02"
 
 static size_t host_seg_bytes(int nranks) { return sizeof(qd::HostSeg) + sizeof(double) * qd::kHostSlot * (size_t)nranks; }
 
@@ -165,6 +169,26 @@ static bool spin_until(P pred, double timeout_s) {
     if ((spins & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
     if (spins < 20000) sched_yield();
     else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
+// Collectives have no time limit of their own: the ranks of the host backend share a GPU, their sweeps serialise, and the arrival skew of a
+// large or chunked gradient evaluation is legitimately long (RCCL has no such limit either).  A wait ends when pred() holds, when a peer
+// PROCESS is gone (checked once a second: kill(pid, 0)), or after QD_COMM_COLLECTIVE_TIMEOUT_S (default one day).
+static int host_wait(qd::HostRing* g, const std::function<bool()>& pred) {
+  static const double limit = [] {
+    const char* e = getenv("QD_COMM_COLLECTIVE_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 86400.0;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    if (spin_until(pred, 1.0)) return 0;
+    for (int r = 0; r < g->nranks; r++) {
+      const long p = (long)g->seg->pid[r].v.load(std::memory_order_acquire);
+      if (r != g->rank && p > 0 && kill((pid_t)p, 0) != 0 && errno == ESRCH) return 1 + r;
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return -1;
   }
 }
 
@@ -253,6 +277,7 @@ extern "C" int qd_comm_create_host(const char* name, int rank, int nranks, int d
       seg = nullptr;
     }
   }
+  seg->pid[rank].v.store((unsigned long long)getpid(), std::memory_order_release);
   qd_comm* c = new qd_comm();
   c->rank = rank;
   c->nranks = nranks;
@@ -280,20 +305,23 @@ static int host_allreduce(qd::HostRing* g, double* buf, size_t n, int op) {
     const size_t m = std::min(qd::kHostSlot, n - off);
     const unsigned long long seq = ++g->seq;
     // my slot is free once every rank has finished reading the previous round
-    if (!spin_until([&] {
-          for (int r = 0; r < g->nranks; r++)
-            if (s->done[r].v.load(std::memory_order_acquire) < seq - 1) return false;
-          return true;
-        }, g->timeout_s))
-      return fail(QD_ERR_STATE, "qd_comm (host): timed out waiting for the previous round to drain");
+    auto why = [&](int w, const char* what) {
+      return fail(QD_ERR_STATE, std::string("qd_comm (host): ") + what + (w > 0 ? ": the process of rank " + std::to_string(w - 1) + " is gone" : ": collective time limit (QD_COMM_COLLECTIVE_TIMEOUT_S)"));
+    };
+    int w = host_wait(g, [&] {
+      for (int r = 0; r < g->nranks; r++)
+        if (s->done[r].v.load(std::memory_order_acquire) < seq - 1) return false;
+      return true;
+    });
+    if (w) return why(w, "waiting for the previous round to drain");
     std::memcpy(s->slot(g->rank), buf + off, sizeof(double) * m);
     s->arrive[g->rank].v.store(seq, std::memory_order_release);
-    if (!spin_until([&] {
-          for (int r = 0; r < g->nranks; r++)
-            if (s->arrive[r].v.load(std::memory_order_acquire) < seq) return false;
-          return true;
-        }, g->timeout_s))
-      return fail(QD_ERR_STATE, "qd_comm (host): timed out waiting for the other ranks in an all-reduce (a rank died or called a different collective)");
+    w = host_wait(g, [&] {
+      for (int r = 0; r < g->nranks; r++)
+        if (s->arrive[r].v.load(std::memory_order_acquire) < seq) return false;
+      return true;
+    });
+    if (w) return why(w, "waiting for the other ranks in an all-reduce");
     const double* s0 = s->slot(0);
     if (op == 1) {
       for (size_t i = 0; i < m; i++) {
@@ -417,12 +445,19 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
       return fail(QD_ERR_INVALID, std::string("QD_COMM_BACKEND: unknown backend ") + b + " (rccl | host | auto)");
   }
   if (!host && !(getenv("QD_COMM_BACKEND") && std::strcmp(getenv("QD_COMM_BACKEND"), "rccl") == 0)) {
+    // automatic: the shared-memory backend only when the ranks OF THIS NODE outnumber its GPUs (they then share devices, which RCCL
+    // refuses).  QD_LOCAL_SIZE = ranks on this node (set by the launchers; a launch that spans nodes has local < nranks and keeps RCCL:
+    // a POSIX segment does not reach the other nodes); without it the global count stands in.
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) {
       (void)hipGetLastError();
       ndev = 0;
     }
-    host = nranks > ndev;
+    const char* ls = getenv("QD_LOCAL_SIZE");
+    const int local = ls && atoi(ls) > 0 ? atoi(ls) : nranks;
+    host = local > ndev;
+    if (host && local < nranks)
+      return fail(QD_ERR_UNSUPPORTED, "qd_comm_create_from_file: more ranks per node than GPUs on a launch that spans nodes (the shared-memory backend is node-local)");
   }
   if (host) {
     // the segment is named after the path (all ranks of a job pass the same one) and the job id
@@ -432,7 +467,13 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
     for (char ch : name) h = (h ^ (unsigned char)ch) * 1099511628211ull;
     return qd_comm_create_host(("f" + std::to_string(h)).c_str(), rank, nranks, device_ordinal, timeout_s, out);
   }
-  const std::string idp = path, gop = idp + ".go";
+  // Handshake: rank 0 publishes {token, id}; rank k echoes {token, n_k} with a nonce n_k of its own; rank 0 answers every echo with a
+  // go file FOR THAT RANK carrying {token, n_k}.  A rank only enters ncclCommInitRank on a go file that returns its own nonce, which only
+  // a live rank 0 that read this run's echo can have written - the leftovers of a run killed inside ncclCommInitRank (an id file and go
+  // files with matching tokens) are never acted upon, whoever starts first.
+  const std::string idp = path;
+  auto gop = [&](int k) { return idp + ".go" + std::to_string(k); };
+  auto ackp = [&](int k) { return idp + ".ack" + std::to_string(k); };
   const unsigned long long nonce = job_nonce();
   const auto t0 = std::chrono::steady_clock::now();
   auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
@@ -440,19 +481,25 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
   if (rank == 0) {
     // leftovers of an earlier run
     (void)remove(idp.c_str());
-    (void)remove(gop.c_str());
-    for (int r = 1; r < nranks; r++) (void)remove((idp + ".ack" + std::to_string(r)).c_str());
+    (void)remove((idp + ".go").c_str());  // (the single go file of earlier builds)
+    for (int r = 1; r < nranks; r++) {
+      (void)remove(gop(r).c_str());
+      (void)remove(ackp(r).c_str());
+    }
     std::memcpy(f.magic, kIdMagic, sizeof f.magic);
     f.nonce = nonce;
     f.token = random_token();
     int r = qd_comm_unique_id(f.id);
     if (r) return r;
     if (!write_atomically(idp, &f, sizeof f)) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish the id file");
+    std::vector<unsigned long long> peer(nranks, 0ull);
     for (int k = 1; k < nranks; k++) {
-      const std::string ap = idp + ".ack" + std::to_string(k);
       for (;;) {
-        unsigned long long t = 0;
-        if (read_whole(ap, &t, sizeof t) && t == f.token) break;
+        unsigned long long t[2] = {0, 0};
+        if (read_whole(ackp(k), t, sizeof t) && t[0] == f.token && t[1]) {
+          peer[k] = t[1];
+          break;
+        }
         if (expired()) {
           (void)remove(idp.c_str());
           return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank " + std::to_string(k) + " to confirm the id");
@@ -460,35 +507,36 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
         std::this_thread::sleep_for(std::chrono::milliseconds(10));
       }
     }
-    if (nranks > 1 && !write_atomically(gop, &f.token, sizeof f.token)) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish the go file");
+    for (int k = 1; k < nranks; k++) {
+      const unsigned long long g[2] = {f.token, peer[k]};
+      if (!write_atomically(gop(k), g, sizeof g)) return fail(QD_ERR_INVALID, "qd_comm_create_from_file: cannot publish a go file");
+    }
   } else {
-    const std::string ap = idp + ".ack" + std::to_string(rank);
+    const unsigned long long mine = random_token();
     unsigned long long echoed = 0;
     for (;;) {
       IdFile g;
       if (read_whole(idp, &g, sizeof g) && std::memcmp(g.magic, kIdMagic, sizeof g.magic) == 0 && (!nonce || g.nonce == nonce)) {
         if (g.token != echoed) {
           f = g;
-          if (write_atomically(ap, &g.token, sizeof g.token)) echoed = g.token;
+          const unsigned long long e[2] = {g.token, mine};
+          if (write_atomically(ackp(rank), e, sizeof e)) echoed = g.token;
         }
       }
-      unsigned long long go = 0;
-      if (echoed && read_whole(gop, &go, sizeof go) && go == echoed) break;
+      unsigned long long go[2] = {0, 0};
+      if (echoed && read_whole(gop(rank), go, sizeof go) && go[0] == echoed && go[1] == mine) break;
       if (expired())
         return fail(QD_ERR_STATE, "qd_comm_create_from_file: timed out waiting for rank 0 (no id file of this job, or rank 0 never confirmed it)");
       std::this_thread::sleep_for(std::chrono::milliseconds(10));
     }
   }
   int r = qd_comm_create(f.id, rank, nranks, device_ordinal, out);
-  // the bootstrap files have served: every rank removes its echo, rank 0 the id (the go file stays until the next run's rank 0 removes it -
-  // a rank may still be on its way to read it)
-  if (rank > 0) (void)remove((idp + ".ack" + std::to_string(rank)).c_str());
-  else {
+  // the bootstrap files have served: every rank removes its echo and its go file, rank 0 the id
+  if (rank > 0) {
+    (void)remove(ackp(rank).c_str());
+    (void)remove(gop(rank).c_str());
+  } else {
     (void)remove(idp.c_str());
-    if (r == QD_OK && nranks > 1) {
-      // after ncclCommInitRank returned on rank 0 every rank has entered it, i.e. has read the go file
-      (void)remove(gop.c_str());
-    }
   }
   return r;
 }

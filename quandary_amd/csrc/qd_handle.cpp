@@ -855,6 +855,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
 int qd_handle::arm_slices(qd::SweepArgs& a, int nb, int which) {
   a.nslice = col_slices(nb, tg.ntime, opts);
   a.sched = nullptr;
+  a.sched_ticks = 0;
   if (a.nslice <= 1) {
     a.nslice = 1;
     return QD_OK;
@@ -865,6 +866,17 @@ int qd_handle::arm_slices(qd::SweepArgs& a, int nb, int which) {
   unsigned* p = reinterpret_cast<unsigned*>(d_sched.p + (which ? dbl : 0));
   QD_HIP(hipMemsetAsync(p, 0, sizeof(unsigned) * words, stream));
   a.sched = p;
+  {  // how long a slice may wait for its predecessor: a healthy one takes a slice length of its own plus whatever the device spends
+     // on the kernels of other processes that share it (several ranks on one GPU: QD_SHARE_GPUS, bench.py --dist-backend host)
+    double s = opts.sched_wait_s;
+    if (!(s > 0.0)) {
+      const char* e = getenv("QD_DEVICE_SHARERS");
+      const int sharers = e && atoi(e) > 1 ? atoi(e) : 1;
+      const double steps = (double)tg.ntime / a.nslice;
+      s = 4.0 * sharers * (steps > 1000.0 ? steps / 1000.0 : 1.0);
+    }
+    a.sched_ticks = (unsigned long long)(s * 1e8);
+  }
   if (which) {
     if ((r = d_stash.ensure((size_t)nb * 2 * S.dim))) return r;
     a.stash = d_stash.p;

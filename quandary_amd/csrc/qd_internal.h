@@ -119,6 +119,7 @@ struct SweepArgs {
   // (sched = nullptr: one workgroup per initial condition); the adjoint state is carried from slice to slice in `stash`
   int nslice;
   unsigned* sched;
+  unsigned long long sched_ticks;  // wall_clock64 ticks (100 MHz) a slice may wait for its predecessor before the error word is raised
   double* stash;        // [2][nb][2*dim] staging area of the several-elements-per-thread variants (adjoint state / midpoint state
                         // parked in L2/HBM while a linear solve runs, instead of compiler-chosen scratch spills)
 };
@@ -152,6 +153,8 @@ struct TuneOpts {
                            // iteration contracts fast (-1 = there, 0 = never: always the Krylov kernels, 1 = wherever it is built)
   int neumann_split = -1;  // "neumann_split": diagonal-split Neumann iteration (-1 = where it pays, 0 = never, 1 = wherever it is built)
   double traj_budget_mb = 0.0;  // "traj_budget_mb": pretend the trajectory budget is this small (chunked re-propagation)
+  double sched_wait_s = 0.0;    // "sched_wait_s": seconds a time slice may wait for its predecessor (0 = automatic: 4 s x the processes that share the
+                                // device (QD_DEVICE_SHARERS, set by the launchers that put several ranks on one GPU) x the slice length in units of 1000 steps)
   int set(const char* key, const char* value);  // 0 = ok, -1 = unknown key / bad value
   void load_env();
 };

@@ -18,6 +18,7 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <set>
 #include <random>
 #include <sstream>
 #include <string>
@@ -52,15 +53,36 @@ struct Config : std::map<std::string, std::string> {
     }
   }
   bool has(const std::string& k) const { return count(k) > 0; }
-  std::string str(const std::string& k, const std::string& d) const { return has(k) ? at(k) : d; }
-  double dbl(const std::string& k, double d) const { return has(k) ? atof(at(k).c_str()) : d; }
-  int integer(const std::string& k, int d) const { return has(k) ? atoi(at(k).c_str()) : d; }
+  // Every parameter that is asked for is recorded once, with the value that was used (the file's text, or the default), in the order of
+  // the first query: config_log.dat of the reference (export_param, include/config.hpp:141-148; written by src/main.cpp:382-393) - a
+  // complete config file of the run that a later run can be started from.
+  mutable std::vector<std::pair<std::string, std::string>> asked;
+  mutable std::set<std::string> seen;
+  template <typename T>
+  void note(const std::string& k, const T& d) const {
+    if (!seen.insert(k).second) return;
+    std::ostringstream v;
+    v.precision(17);
+    if (has(k)) v << at(k);
+    else v << d;
+    asked.emplace_back(k, v.str());
+  }
+  std::string log_text() const {
+    std::string t;
+    for (auto& kv : asked) t += kv.first + " = " + kv.second + "\n";
+    return t;
+  }
+  std::string str(const std::string& k, const std::string& d) const { note(k, d); return has(k) ? at(k) : d; }
+  double dbl(const std::string& k, double d) const { note(k, d); return has(k) ? atof(at(k).c_str()) : d; }
+  int integer(const std::string& k, int d) const { note(k, d); return has(k) ? atoi(at(k).c_str()) : d; }
   bool boolean(const std::string& k, bool d) const {
+    note(k, d ? "true" : "false");
     if (!has(k)) return d;
     const std::string& v = at(k);
     return v == "yes" || v == "true" || v == "True" || v == "TRUE" || v == "YES" || v == "1";
   }
   strvec vstr(const std::string& k, const std::string& d) const {
+    note(k, d);
     strvec out;
     std::stringstream ss(has(k) ? at(k) : d);
     std::string t;
@@ -69,6 +91,7 @@ struct Config : std::map<std::string, std::string> {
   }
   std::vector<double> vdbl(const std::string& k, double d) const {
     std::vector<double> out;
+    note(k, d);
     if (!has(k)) return {d};
     for (auto& t : vstr(k, "")) out.push_back(atof(t.c_str()));
     return out;
@@ -830,11 +853,13 @@ int main(int argc, char** argv) {
   // multi-GPU: one process per GPU.  The reference's front end starts `mpirun -np <ncores> quandary config.cfg --quiet` with ncores a
   // divisor of the number of initial conditions (quandary.py:506-519, :1431-1450); this executable links no MPI and takes rank and size
   // from the launcher's environment (launch_env).  The ranks shard the initial conditions over the GPUs of the node:
-  //   ranks <= GPUs              one rank per GPU, RCCL (src/main.cpp:133-177 with np_init = ranks)
-  //   ranks >  GPUs (default)    the first `nactive` ranks work, nactive = the largest divisor of ninit that is <= the number of GPUs;
-  //                              the surplus ranks have nothing to do and exit 0 at once (a CPU-sized core count from quandary.py
-  //                              must not put several processes on one GPU or fail the run)
+  //   default                    the first `nactive` ranks work, one per GPU over RCCL (src/main.cpp:133-177 with np_init = nactive):
+  //                              nactive = the largest divisor of ninit that is <= min(ranks, GPUs of the node) - the reference takes
+  //                              np_init = min(ninit, size) and gives the rest to PETSc (src/main.cpp:140-153); here the surplus ranks have
+  //                              nothing to do and exit 0 at once, so that a CPU-sized core count from quandary.py (`mpirun -np 8` for 4 initial
+  //                              conditions, or 8 ranks on a one-GPU box) neither fails the run nor puts several processes on one GPU
   //   QD_SHARE_GPUS = 1          every rank works, rank r on GPU r mod ndev, reductions through the shared-memory backend
+  //   several nodes              one rank per GPU is required (local ranks <= local GPUs); RCCL; ninit must divide by the rank count
   Evaluator ev;
   const LaunchEnv le = launch_env();
   ev.rank = le.rank;
@@ -845,24 +870,28 @@ int main(int argc, char** argv) {
     const int ndev = qd_device_count();
     if (ndev < 1) die("no HIP device visible");
     const bool share = getenv("QD_SHARE_GPUS") && atoi(getenv("QD_SHARE_GPUS")) != 0;
+    const bool multinode = le.local_size > 0 && le.local_size < ev.nranks;
     const int ninit_global = count_initial_conditions(P);
-    if (le.local_size > 0 && le.local_size < ev.nranks && le.local_size > ndev && !share)
-      die("more ranks per node than GPUs on a multi-node launch: start one rank per GPU");
-    int nactive = ev.nranks;
-    if (ev.nranks > ndev && !share && !(le.local_size > 0 && le.local_size < ev.nranks)) {
-      nactive = 1;
-      for (int d = std::min(ndev, ev.nranks); d >= 1; d--)
+    if (multinode && le.local_size > ndev) die("more ranks per node than GPUs on a multi-node launch: start one rank per GPU");
+    if (!multinode && !share && (ev.nranks > ndev || ninit_global % ev.nranks != 0)) {
+      int nactive = 1;
+      for (int d = std::min(std::min(ndev, ev.nranks), ninit_global); d >= 1; d--)
         if (ninit_global % d == 0) {
           nactive = d;
           break;
         }
       if (ev.rank >= nactive) return 0;  // surplus rank: nothing to do, nothing to write
       if (ev.rank == 0 && !quiet)
-        printf("%d ranks were started on %d GPU(s): %d rank(s) work, the others exit.\n", ev.nranks, ndev, nactive);
+        printf("%d ranks were started for %d initial conditions on %d GPU(s): %d rank(s) work, the others exit.\n", ev.nranks, ninit_global, ndev, nactive);
       ev.nranks = nactive;
     }
     if (ninit_global % ev.nranks != 0) die("the number of initial conditions must be a multiple of the number of working ranks (src/main.cpp:150-153)");
     device = getenv("QD_DEVICE") ? atoi(getenv("QD_DEVICE")) : (le.local_rank >= 0 ? le.local_rank : ev.rank) % ndev;
+    // what the library needs to know about the launch (qd_comm_create_from_file: backend by ranks per node; qd_col.hip: scheduler time
+    // limit by processes per device)
+    const int local = multinode ? le.local_size : ev.nranks;
+    setenv("QD_LOCAL_SIZE", std::to_string(local).c_str(), 1);
+    if (local > ndev) setenv("QD_DEVICE_SHARERS", std::to_string((local + ndev - 1) / ndev).c_str(), 0);
   }
   if (ev.rank != 0) quiet = true;
   Output out;
@@ -932,6 +961,20 @@ int main(int argc, char** argv) {
   }
   const std::string runtype = P.cfg.str("runtype", "simulation");
   std::vector<double> x = P.params0, grad(x.size(), 0.0);
+  // config_log.dat (src/main.cpp:382-393): every parameter the run asked for with the value it used, a config file in its own right.
+  // Written before the run like the reference's and once more at the end (the optimiser reads its parameters when it starts).
+  auto write_config_log = [&](bool announce) {
+    if (ev.rank != 0) return;
+    const std::string fn = out.datadir + "/config_log.dat";
+    std::ofstream lf(fn);
+    if (!lf.is_open()) {
+      fprintf(stderr, "Unable to open %s\n", fn.c_str());
+      return;
+    }
+    lf << P.cfg.log_text();
+    if (announce && !quiet) printf("File written: %s\n", fn.c_str());
+  };
+  write_config_log(true);
   const auto t0 = std::chrono::steady_clock::now();
   qd_objective_value v{};
   double gnorm = 0.0;
@@ -977,6 +1020,7 @@ int main(int argc, char** argv) {
     fclose(tf);
   }
   fclose(out.optimfile);
+  write_config_log(false);
   if (ev.c) {
     (void)qd_comm_barrier(ev.c);
     qd_comm_destroy(ev.c);

@@ -92,6 +92,31 @@ def test_simulation_cases(case, patterns, tmp_path, gmres_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["AxC_initDiag0", "pipulse", "xgate_sparsemat"])
+def test_config_log_is_a_config_file_of_the_same_run(case, tmp_path):
+    """config_log.dat (src/main.cpp:382-393, export_param include/config.hpp:141-148): every parameter the run asked for with the value it
+    used.  It parses with the Python front end's parser into the same problem, and the driver started FROM it writes the same files."""
+    from quandary_amd import config
+
+    out = _run(case, str(tmp_path))
+    log = os.path.join(out, "config_log.dat")
+    assert os.path.exists(log)
+    first = {f: open(os.path.join(out, f)).read() for f in ("optim_history.dat", "params.dat")}
+    a = config.build_spec(config.parse_config_text(open(os.path.join(GOLDEN, case, case + ".cfg")).read()), cfg_dir=str(tmp_path))
+    b = config.build_spec(config.parse_config_text(open(log).read()), cfg_dir=str(tmp_path))
+    assert a.ninit == b.ninit and a.dim == b.dim and a.time.ntime == b.time.ntime and a.time.dt == b.time.dt
+    np.testing.assert_array_equal(a.params0, b.params0)
+    keys = dict(l.replace(" ", "").strip().split("=", 1) for l in open(log) if "=" in l)
+    for k in ("nlevels", "ntime", "dt", "runtype", "datadir", "linearsolver_type", "timestepper", "optim_regul"):
+        assert k in keys, k  # (defaults are recorded as well)
+    shutil.copy(log, os.path.join(tmp_path, "again.cfg"))
+    r = subprocess.run([EXE, "again.cfg", "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f, text in first.items():
+        assert open(os.path.join(out, f)).read() == text, f
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,patterns,grad_rtol", [
     ("AxC_grad_initBasis0", ["expected*.dat"], 1e-8),
     ("AxC_grad_schroedinger", ["rho*.dat"], 1e-8),
