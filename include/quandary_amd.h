@@ -48,10 +48,10 @@
  * Supported sizes (QD_ERR_UNSUPPORTED beyond): state dimension dim <= QD_MAX_DIM = 2^22 (one
  * workgroup owns one initial condition; up to 4096 the state lives in the CU's LDS, above it the
  * vectors of a step live in global memory and are exchanged through L2; IMR family);
- * Lindblad 1..5 oscillators (like the
- * reference's matrix-free templates), Schroedinger 1..8; at most 256 / 64 / 32 / 16
- * levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied
- * Hamiltonians: 1..5 oscillators, table of G(t) <= 16 GB.  Control segments: "spline", "spline0", "step" and
+ * 1..8 oscillators, Schroedinger and Lindblad (the reference's matrix-free templates stop at five, its sparse-matrix path does
+ * not: six to eight Lindblad oscillators run on the general stencil - 2^6, dim 4096, in LDS, anything larger in global memory);
+ * at most 256 / 64 / 32 / 16 levels per oscillator for <= 4 / 5 / 6 / 7-8 oscillators; user-supplied
+ * Hamiltonians: 1..8 oscillators, table of G(t) <= 16 GB.  Control segments: "spline", "spline0", "step" and
  * "spline_amplitude" (the last one forward only, as in the reference: src/oscillator.cpp:350-356).  There is no CPU
  * fallback.
  */

@@ -135,10 +135,6 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
       return fail(QD_ERR_UNSUPPORTED, "qd_create: too many levels per oscillator for this number of oscillators (packed digits: 256/64/32/16 levels for <=4/5/6/7-8 oscillators)");
     }
   }
-  if (S.Q > 5 && S.lindblad) {
-    delete h;
-    return fail(QD_ERR_UNSUPPORTED, "qd_create: Lindblad kernels are instantiated for 1..5 oscillators (as the reference's matrix-free path); Schroedinger for 1..8");
-  }
   S.N = (int)N;
   S.dim = (int)dim;
   for (int k = 0; k < S.Q; k++) {
@@ -336,7 +332,6 @@ extern "C" int qd_set_hamiltonian(qd_handle* h, const double* hsys_re, const dou
   if (!h || !hsys_re || !hsys_im) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: null system Hamiltonian");
   if ((hc_re == nullptr) != (hc_im == nullptr)) return fail(QD_ERR_INVALID, "qd_set_hamiltonian: give both parts of the control Hamiltonians or neither");
   // (dim <= 1024: the LDS kernels V11-V13 / V15; beyond: the global-memory sweeps of qd_big.h with the dense operator)
-  if (h->S.Q > 5) return fail(QD_ERR_UNSUPPORTED, "qd_set_hamiltonian: the dense-operator kernels are instantiated for 1..5 oscillators");
   QD_HIP(qd::use_device(h->device));
   const size_t nn = (size_t)h->S.N * h->S.N;
   if ((double)h->sched_t.size() * (double)nn * 16.0 > 16e9)
@@ -738,18 +733,23 @@ bool qd_handle::gmres_as_split(const qd::LaunchCfg& cfg, double* kappa2) const {
 
 // The gates depend on the CURRENT control parameters, and an optimiser's line search compares objectives far below the solver
 // tolerance: a solver that changes between two evaluations shows up as a jump.  The decision is therefore latched per handle: taken at
-// the first sweep (bound <= 0.3), kept while the stationary iteration still provably contracts fast enough for the tripled iteration
-// cap (bound <= 0.6: 0.6^60 ~ 5e-14), and given up for good - Krylov kernels from then on - the first time it does not.  At most one
-// switch in the life of a handle; qd_set_option / qd_set_hamiltonian / qd_set_precision start over.
+// the first sweep (bound <= 0.3), kept while the stationary iteration still provably reaches the tolerance within its iteration cap,
+// and given up for good - Krylov kernels from then on - the first time it does not.  The cap is three times linearsolver_maxiter
+// (the reference's default 10 -> 30 applications), so "provably" is bound^cap <= 1e-13: 0.37 at the default, 0.6 from maxiter 20 on
+// (never above 0.6); a small maxiter lowers the entry gate the same way.  At most one switch in the life of a handle;
+// qd_set_option / qd_set_hamiltonian / qd_set_precision start over.
 bool qd_handle::latched_substitution(int kind, double bound) const {
-  if (!params_set) return bound <= 0.3;  // (a query before the first qd_set_params sees no controls: answer, but decide nothing)
+  const double cap = 3.0 * std::max(1, sol.maxiter);
+  const double reach = std::pow(1e-13, 1.0 / cap);  // contraction per application that gets from ||b|| ~ 1 to 1e-13 within the cap
+  const double enter = std::min(0.3, reach), keep = std::min(0.6, reach);
+  if (!params_set) return bound <= enter;  // (a query before the first qd_set_params sees no controls: answer, but decide nothing)
   if (sub_latch == -1) {
-    if (bound <= 0.3) sub_latch = kind;
+    if (bound <= enter) sub_latch = kind;
     else if (kind == 2) sub_latch = 0;  // (the split gate is asked first and leaves the decision to the Neumann gate)
     return sub_latch == kind;
   }
   if (sub_latch != kind) return false;
-  if (bound <= 0.6) return true;
+  if (bound <= keep) return true;
   sub_latch = 0;
   return false;
 }

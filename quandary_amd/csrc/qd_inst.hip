@@ -34,6 +34,10 @@ constexpr bool variant_built() {
   // least two levels: dim >= 2^Q, or 4^Q for Lindblad) - the five-oscillator Lindblad unit alone took 6 minutes
   constexpr long kMinDim = kLind ? (1L << (2 * QD_Q)) : (1L << QD_Q);
   constexpr bool fits0 = kMinDim <= 64, fits1 = kMinDim <= 256, fits2 = kMinDim <= 1024;
+  // six to eight oscillators, Lindblad (beyond the reference's matrix-free templates, mastereq.cpp:2977-3239): the eight-elements-per-thread
+  // LDS kernel for 2^6 (dim 4096, the only such system that fits a CU) and the global-memory kernels
+  if (kLind && QD_Q >= 6 && !kDense) return (VAR == 4 && QD_Q == 6) || VAR == 16;
+  if (kDense && QD_Q >= 6) return VAR == 16 || (!kLind && ((VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2)));
   if (kDense) return (VAR == 11 && fits0) || (VAR == 12 && fits1) || (VAR == 13 && fits2) || (kLind && VAR == 15 && QD_Q <= 4) || (kLind && VAR == 17 && QD_Q <= 5) || VAR == 16;
   if (!kQubit) return (VAR == 0 && fits0) || (VAR == 1 && fits1) || (VAR == 2 && fits2) || VAR == 4 || (kLind && (VAR == 9 || VAR == 14)) || VAR == 16;
   if (kQubitDim <= 64) return VAR == 0;

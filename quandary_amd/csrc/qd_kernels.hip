@@ -450,6 +450,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmre
   bool qubit = true;
   for (int k = 0; k < S.Q; k++) qubit = qubit && S.n[k] == 2 && S.ness[k] == 2;
   if (S.dense) qubit = false;
+  if (S.lindblad && S.Q > 5) qubit = false;  // (the all-qubit Lindblad stencils are instantiated for 1..5 oscillators: general stencil)
   c.qubit = S.dense ? 2 : qubit ? 1 : 0;
   c.noplain = o.no_plain;
   const bool gm = want_gmres && !o.force_neumann;
@@ -466,6 +467,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmre
   };
   auto built = [&](int v) {  // mirrors variant_built() in qd_inst.hip
     if (S.dense) return (v >= 11 && v <= 13) || (v == 15 && S.lindblad && S.N == 16) || (v == 17 && S.lindblad && S.N > 16 && S.N <= 32);
+    if (S.lindblad && S.Q > 5) return v == 4 && S.Q == 6;
     if (!qubit) return v <= 2 || v == 4 || (S.lindblad && (v == 9 || v == 14));
     return dim <= 64 ? v == 0 : dim <= 256 ? v == 1 : v == 2;
   };
@@ -476,6 +478,7 @@ LaunchCfg pick_config(const DevSys& S, int nb, const TuneOpts& o, bool want_gmre
   // column layout when most of its 64 lanes (= rows) are used; measured: N = 36 V4 8.6M vs V9 7.2M units/s,
   // N = 49 4.3M vs 6.7M, N = 64 3.3M vs 5.2M
   // ... the lean column kernels (qd_col.hip) already from N = 33 (measured below), the general column kernel from N = 44
+  else if (S.lindblad && S.Q > 5) var = 4;
   else var = (fits(QD_COL_DEFAULT) && (S.N >= 44 || (!gm && S.N >= o.col_min_n && collean_available(S, o)))) ? QD_COL_DEFAULT : 4;
   if (S.dense) var = dim <= 64 ? 11 : dim <= 256 ? 12 : 13;  // qd_set_hamiltonian limits dim to 1024
   // matrix cores for the dense operator and (adjoint sweep) for the gradient contraction's 2Q commutators per step; the option no_mfma
@@ -626,17 +629,20 @@ void TuneOpts::load_env() {
 QD_DECL_Q(0, 0) QD_DECL_Q(1, 0) QD_DECL_Q(0, 1) QD_DECL_Q(1, 1)
 // Schroedinger only: 6..8 oscillators (beyond the reference's matrix-free templates, which stop at 5)
 QD_DECL(6, 0, 0) QD_DECL(7, 0, 0) QD_DECL(8, 0, 0) QD_DECL(6, 0, 1) QD_DECL(7, 0, 1) QD_DECL(8, 0, 1)
+// ... and Lindblad on the general stencil [r5]
+QD_DECL(6, 1, 0) QD_DECL(7, 1, 0) QD_DECL(8, 1, 0)
 // dense user-Hamiltonian operator
 QD_DECL_Q(0, 2) QD_DECL_Q(1, 2)
+QD_DECL(6, 0, 2) QD_DECL(7, 0, 2) QD_DECL(8, 0, 2) QD_DECL(6, 1, 2) QD_DECL(7, 1, 2) QD_DECL(8, 1, 2)
 
 #define QD_DECLT(q, l) hipError_t inst_bigtable_##q##_##l##_0(const DevSys&, double*, unsigned*, hipStream_t);
 QD_DECLT(1, 0) QD_DECLT(2, 0) QD_DECLT(3, 0) QD_DECLT(4, 0) QD_DECLT(5, 0) QD_DECLT(6, 0) QD_DECLT(7, 0) QD_DECLT(8, 0)
-QD_DECLT(1, 1) QD_DECLT(2, 1) QD_DECLT(3, 1) QD_DECLT(4, 1) QD_DECLT(5, 1)
+QD_DECLT(1, 1) QD_DECLT(2, 1) QD_DECLT(3, 1) QD_DECLT(4, 1) QD_DECLT(5, 1) QD_DECLT(6, 1) QD_DECLT(7, 1) QD_DECLT(8, 1)
 typedef hipError_t (*table_fn)(const DevSys&, double*, unsigned*, hipStream_t);
 static const table_fn big_tab[2][8] = {{inst_bigtable_1_0_0, inst_bigtable_2_0_0, inst_bigtable_3_0_0, inst_bigtable_4_0_0, inst_bigtable_5_0_0,
                                         inst_bigtable_6_0_0, inst_bigtable_7_0_0, inst_bigtable_8_0_0},
                                        {inst_bigtable_1_1_0, inst_bigtable_2_1_0, inst_bigtable_3_1_0, inst_bigtable_4_1_0, inst_bigtable_5_1_0,
-                                        nullptr, nullptr, nullptr}};
+                                        inst_bigtable_6_1_0, inst_bigtable_7_1_0, inst_bigtable_8_1_0}};
 hipError_t launch_big_table(const DevSys& S, double* ecoef, unsigned* edig, hipStream_t st) {
   if (S.Q < 1 || S.Q > 8 || !big_tab[S.lindblad ? 1 : 0][S.Q - 1]) return hipErrorInvalidValue;
   return big_tab[S.lindblad ? 1 : 0][S.Q - 1](S, ecoef, edig, st);
@@ -647,15 +653,15 @@ typedef hipError_t (*apply_fn)(const DevSys&, const double*, int, const double*,
 #define QD_ROW(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b, nullptr, nullptr, nullptr}
 #define QD_ROW8(base, l, b) {base##1_##l##_##b, base##2_##l##_##b, base##3_##l##_##b, base##4_##l##_##b, base##5_##l##_##b, base##6_##l##_##b, base##7_##l##_##b, base##8_##l##_##b}
 // index [qubit][lindblad][Q-1]
-static const sweep_fn fwd_tab[3][2][8] = {{QD_ROW8(inst_forward_, 0, 0), QD_ROW(inst_forward_, 1, 0)},
+static const sweep_fn fwd_tab[3][2][8] = {{QD_ROW8(inst_forward_, 0, 0), QD_ROW8(inst_forward_, 1, 0)},
                                           {QD_ROW8(inst_forward_, 0, 1), QD_ROW(inst_forward_, 1, 1)},
-                                          {QD_ROW(inst_forward_, 0, 2), QD_ROW(inst_forward_, 1, 2)}};
-static const sweep_fn adj_tab[3][2][8] = {{QD_ROW8(inst_adjoint_, 0, 0), QD_ROW(inst_adjoint_, 1, 0)},
+                                          {QD_ROW8(inst_forward_, 0, 2), QD_ROW8(inst_forward_, 1, 2)}};
+static const sweep_fn adj_tab[3][2][8] = {{QD_ROW8(inst_adjoint_, 0, 0), QD_ROW8(inst_adjoint_, 1, 0)},
                                           {QD_ROW8(inst_adjoint_, 0, 1), QD_ROW(inst_adjoint_, 1, 1)},
-                                          {QD_ROW(inst_adjoint_, 0, 2), QD_ROW(inst_adjoint_, 1, 2)}};
-static const apply_fn app_tab[3][2][8] = {{QD_ROW8(inst_apply_, 0, 0), QD_ROW(inst_apply_, 1, 0)},
+                                          {QD_ROW8(inst_adjoint_, 0, 2), QD_ROW8(inst_adjoint_, 1, 2)}};
+static const apply_fn app_tab[3][2][8] = {{QD_ROW8(inst_apply_, 0, 0), QD_ROW8(inst_apply_, 1, 0)},
                                           {QD_ROW8(inst_apply_, 0, 1), QD_ROW(inst_apply_, 1, 1)},
-                                          {QD_ROW(inst_apply_, 0, 2), QD_ROW(inst_apply_, 1, 2)}};
+                                          {QD_ROW8(inst_apply_, 0, 2), QD_ROW8(inst_apply_, 1, 2)}};
 
 hipError_t launch_forward(const SweepArgs& a, const LaunchCfg& cfg, hipStream_t st) {
   if (a.S.Q < 1 || a.S.Q > 8 || !fwd_tab[cfg.qubit][a.S.lindblad ? 1 : 0][a.S.Q - 1]) return hipErrorInvalidValue;

@@ -93,6 +93,12 @@ def test_objective_and_gradient_vs_oracle(kw, penalties):
     pytest.param(dict(nlevels=[2] * 8, lindblad=False, target="pure", objective="Jfrobenius", init="pure, 1, 0, 1, 0, 0, 1, 0, 0"), id="2^8-schroedinger-four-waves"),
     pytest.param(dict(nlevels=[3, 2, 2, 2, 2, 2], lindblad=False, nessential=[2, 2, 2, 2, 2, 2], target="pure", objective="Jmeasure", init="pure, 1, 0, 0, 1, 0, 1"), id="3x2^5-schroedinger-guard"),
     pytest.param(dict(nlevels=[2, 2, 3], lindblad=True, init="diagonal", target="pure", objective="Jmeasure"), id="2x2x3-lindblad"),
+    # [r5] Lindblad beyond five oscillators (the reference: sparse-matrix path only, src/mastereq.cpp:192-655): 2^6 is dim 4096 - the largest
+    # state of the LDS kernels (eight elements per thread, general stencil); more levels or oscillators run in global memory (qd_big.h)
+    pytest.param(dict(nlevels=[2] * 6, lindblad=True, init="diagonal, 0, 1"), id="2^6-lindblad-lds"),
+    pytest.param(dict(nlevels=[2] * 6, lindblad=True, jkl=0.002, detuned=True, target="pure", objective="Jmeasure", init="pure, 1, 0, 1, 0, 0, 1"), id="2^6-lindblad-jkl"),
+    pytest.param(dict(nlevels=[3, 2, 2, 2, 2, 2], lindblad=True, nessential=[2, 2, 2, 2, 2, 2], target="pure", objective="Jmeasure", init="pure, 1, 0, 0, 1, 0, 1"), id="3x2^5-lindblad-guard-global"),
+    pytest.param(dict(nlevels=[2] * 7, lindblad=True, target="pure", objective="Jfrobenius", init="pure, 1, 0, 1, 0, 0, 1, 0"), id="2^7-lindblad-global"),
 ])
 def test_gradient_with_six_to_eight_oscillators(kw):
     """Six, seven and eight oscillators (the reference's matrix-free templates stop at five, `src/mastereq.cpp:2977-3239`; its sparse path
@@ -488,6 +494,10 @@ DENSE_SHAPES += [
     # beyond dim 1024 (QD_ERR_UNSUPPORTED in round 1): the dense operator inside the global-memory sweeps of qd_big.h
     pytest.param(dict(nlevels=[6, 6], lindblad=True, nessential=[3, 3], target="pure", objective="Jfrobenius", init="diagonal, 0"), id="dense-6x6-lindblad-dim1296"),
     pytest.param(dict(nlevels=[40, 30], lindblad=False, target="pure", objective="Jmeasure", init="pure, 1, 2"), id="dense-1200-schroedinger"),
+    # [r5] user Hamiltonians on more than five oscillators (src/hamiltonianfilereader.cpp:22-57 has no such cap)
+    pytest.param(dict(nlevels=[2] * 6, lindblad=False, init="diagonal, 0, 1", objective="Jfrobenius"), id="dense-2^6-schroedinger"),
+    pytest.param(dict(nlevels=[2] * 7, lindblad=False, target="pure", objective="Jmeasure", init="pure, 1, 0, 1, 0, 0, 1, 0"), id="dense-2^7-schroedinger"),
+    pytest.param(dict(nlevels=[2] * 6, lindblad=True, target="pure", objective="Jmeasure", init="pure, 1, 0, 1, 0, 0, 1"), id="dense-2^6-lindblad-dim4096"),
 ]
 
 
