@@ -407,7 +407,7 @@ int qd_set_option(qd_handle* h, const char* key, const char* value);
 int qd_get_precision(const qd_handle* h);
 /* Measurement hook: nrep chained forward applications y <- M(t) (1e-3 y) on nb states, starting from x, in fp32 by the
  * stencil kernel (mfma = 0) or as the dense Kronecker-factor product G rho - rho G on the fp32 matrix cores (mfma = 1,
- * five qubits only); *ms = device time of the launch.  DESIGN.md records the comparison. */
+ * five qubits only); *ms = device time of the launch.  profiles/HISTORY.md (section 4) records the comparison. */
 int qd_bench_apply_f32(qd_handle* h, double t, const double* x, double* y, int nb, int nrep, int mfma, double* ms);
 
 #ifdef __cplusplus

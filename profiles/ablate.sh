@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: phase ablation of the small-system solver iteration ("cycle account").  Builds the forward
+# Runs ON THE GPU BOX: phase ablation of the small-system solver iteration (profiles/HISTORY.md section 4, "cycle account").  Builds the forward
 # kernels of the 2x2x2 (C2) and 2^4 (q4) Lindblad systems with QD_ABLATE = 1 .. 7 (qd_device.h), links one library per mode next to the
 # product's objects and times `bench.py --workload c2 / q4` with each.  The ablated results are meaningless (no oracle check).
 set -u

@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
 //   Y = G rho - rho G + (dissipators),   G = -i H(t)  (N x N complex, N = 32)
 // on the fp32 matrix cores, v_mfma_f32_32x32x2_f32, one wave per initial condition and 32 x 32 tile.  Per application
 // 2 complex 32x32x32 products = 8 real ones = 128 MFMA instructions of 64 cycles each, against ~220 two-cycle VALU
-// instructions per wave for the stencil: the measurement (qd_bench_apply_f32) is recorded in DESIGN.md.
+// instructions per wave for the stencil: the measurement (qd_bench_apply_f32) is recorded in profiles/HISTORY.md (section 4).
 // Layouts (cdna_hip_programming.md section 3): A operand lane l holds A[i = l & 31][k = l >> 5], B operand B[k = l >> 5][j = l & 31],
 // C/D: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
 // ---------------------------------------------------------------------------------------------

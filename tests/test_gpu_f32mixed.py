@@ -143,7 +143,7 @@ def test_f32_is_opt_in_and_rejected_where_not_built():
 def test_mfma_f32_dense_product_vs_stencil():
     """The MFMA question, measured: Y = G rho - rho G on v_mfma_f32_32x32x2_f32 (one wave per initial condition) against
     the fp32 stencil kernel on 1024 initial conditions of the 2^5 Lindblad system; both agree with the fp64 oracle, the
-    timings go to gpurun_out/mfma_f32_vs_stencil.json (DESIGN.md quotes them)."""
+    timings go to gpurun_out/mfma_f32_vs_stencil.json (profiles/HISTORY.md quotes them)."""
     sp = _spec(5, "diagonal, 0", 10)
     h, orc = capi.Handle(sp), Oracle(sp)
     h.set_params(sp.params0)

@@ -152,7 +152,7 @@ LEANCOL_SHAPES = [
     pytest.param(dict(nlevels=[3, 3, 5], lindblad=True, nessential=[2, 3, 4], target="pure", objective="Jmeasure", init="diagonal, 2"), id="3x3x5-N45"),
     pytest.param(dict(nlevels=[2, 4, 7], lindblad=True, target="pure", objective="Jfrobenius", init="diagonal, 0"), id="2x4x7-N56"),
     pytest.param(dict(nlevels=[7, 9], lindblad=True, detuned=True, target="pure", objective="Jmeasure", init="diagonal, 1"), id="7x9-N63"),
-    # 33 <= N < 44: lanes 33..43 of 64 in use, still ahead of the eight-elements-per-thread kernel (1.1-1.8 x)
+    # 33 <= N < 44: lanes 33..43 of 64 in use, still ahead of the eight-elements-per-thread kernel (1.1-1.8 x, profiles/HISTORY.md section 4)
     pytest.param(dict(nlevels=[2, 20], lindblad=True, nessential=[2, 18], target="pure", objective="Jtrace", init="diagonal, 1"), id="2x20-N40"),
     pytest.param(dict(nlevels=[5, 7], lindblad=True, target="pure", objective="Jfrobenius", init="diagonal, 0"), id="5x7-N35"),
 ]
