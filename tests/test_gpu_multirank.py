@@ -179,6 +179,9 @@ def test_driver_under_mpirun_as_quandary_py_launches_it(case, np_, share, tmp_pa
     assert "optim_history.dat" in names and len(names) > 3
     for n in names:
         assert os.path.exists(os.path.join(db, n)), n
+        if n == "config_log.dat":  # (text: the parameters of the run, the same under any launcher)
+            assert open(os.path.join(da, n)).read() == open(os.path.join(db, n)).read()
+            continue
         x, y = _load(os.path.join(da, n)), _load(os.path.join(db, n))
         assert x.shape == y.shape, n
         np.testing.assert_allclose(y, x, rtol=1e-9, atol=1e-12, err_msg=n)
