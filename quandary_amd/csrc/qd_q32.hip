@@ -509,6 +509,24 @@ struct Team32 {
     b = sb;
   }
 
+  // the same for one value (every iteration but the first: ||b||^2 is only needed once)
+  __device__ __forceinline__ void sum1_f32(float& a) {
+    a = wave_sum_f32(a);
+    if (ONEWAVE) {
+      team_sync<true>();
+      return;
+    }
+    float* rf = reinterpret_cast<float*>(red + redslot * NRED * NW);
+    redslot ^= 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) rf[wave] = a;
+    __syncthreads();
+    float sa = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) sa += rf[w];
+    a = sa;
+  }
+
   // Solve (I - alpha M^{(T)}) y = b by the reference's Neumann iteration (timestepper.cpp:697-727).
   // Returns the number of RHS applications; on exit y is in registers.  The squared update norm is only compared
   // with a threshold: it is accumulated per thread in R and reduced over the workgroup in fp32, scaled by 1/abstol^2
@@ -569,7 +587,11 @@ struct Team32 {
       if (iter == 2) { iter++; break; }
       continue;
 #endif
-      sum2_f32(d, n2);  // the barrier that makes dst readable
+      // (the barrier that makes dst readable.  fp64 sweeps have no use for ||b||^2: one value - C5 14.85 -> 14.53 ms, 2^4 2.45 -> 2.35,
+      //  profiles/r5_q32_ab2.txt; fp32-mixed needs it in the first iteration only, but a branch on the iteration number costs more than
+      //  the second value: 2^4 2.05 -> 2.45 ms)
+      if constexpr (F32) sum2_f32(d, n2);
+      else sum1_f32(d);
       cur ^= 1;
       if (iter == 0) {
         d0 = d;
