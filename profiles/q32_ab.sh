@@ -5,11 +5,13 @@
 # timed through the C ABI: forward sweep and gradient evaluation, best kernel time of REPS evaluations (HIP events of the handle).
 set -u
 R=$PWD; C=$R/quandary_amd/csrc; T=/tmp/q32ab; mkdir -p $T
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -Wall -Wno-unused-function -fno-slp-vectorize"
-OBJS=$(ls $C/build/*.o | grep -v "qd_q32.o" | tr '\n' ' ')
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -Wall -Wno-unused-function"
+SRC=${SRC:-qd_q32}
+XF=""; [ "$SRC" = "qd_q32" ] && XF="-fno-slp-vectorize"
+OBJS=$(ls $C/build/*.o | grep -v "$SRC.o" | tr '\n' ' ')
 for v in "$@"; do
   n=${v%%:*}; f=${v#*:}
-  ( cd $C && /opt/rocm/bin/hipcc $FLAGS $f -c qd_q32.hip -o $T/q32_$n.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $T/lib_$n.so $OBJS $T/q32_$n.o -ldl ) &
+  ( cd $C && /opt/rocm/bin/hipcc $FLAGS $XF $f -c $SRC.hip -o $T/q32_$n.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $T/lib_$n.so $OBJS $T/q32_$n.o -ldl ) &
 done
 wait
 cat > $T/t.py <<'PY'

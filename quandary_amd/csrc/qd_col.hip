@@ -435,10 +435,12 @@ struct ColTeam {
       }
       const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
       st.flip();
-      if (iter == 0) d0 = dprev = d;
-      if (d < thr && standin_ok(A.standin_tau2, d, dprev, thr)) { iter++; break; }
-      if (d < rel2 * d0) { iter++; break; }
+      // (one exit branch per pass, first-iteration values by selects [r5]: 637.6 -> 632.3 ms on the 3600 x 2500 sweep, same counts)
+      d0 = iter == 0 ? d : d0;
+      const float dp = iter == 0 ? d : dprev;
+      const bool stop = (d < thr && standin_ok(A.standin_tau2, d, dp, thr)) | (d < rel2 * d0);
       dprev = d;
+      if (stop) { iter++; break; }
     }
     return iter;
   }
@@ -488,10 +490,12 @@ struct ColTeam {
         }
         continue;
       }
-      if (iter == 0) d0 = dprev = d;
-      if (d < thr && standin_ok(A.standin_tau2, d, dprev, thr)) { iter++; break; }
-      if (d < rel2 * d0) { iter++; break; }
+      // (one exit branch per pass, first-iteration values by selects [r5]: 637.6 -> 632.3 ms on the 3600 x 2500 sweep, same counts)
+      d0 = iter == 0 ? d : d0;
+      const float dp = iter == 0 ? d : dprev;
+      const bool stop = (d < thr && standin_ok(A.standin_tau2, d, dp, thr)) | (d < rel2 * d0);
       dprev = d;
+      if (stop) { iter++; break; }
     }
     return iter + 1;
   }

@@ -593,14 +593,15 @@ struct Team32 {
       if constexpr (F32) sum2_f32(d, n2);
       else sum1_f32(d);
       cur ^= 1;
-      if (iter == 0) {
-        d0 = d;
-        if (F32) tol2 = fmaxf(abs2, F32_SOLVER_TOL * F32_SOLVER_TOL * n2);
-      }
-      // (fp32-mixed: the iterates cannot get below their fp32 floor - no error-estimate rule there)
-      if (F32 ? d <= tol2 : (d < 1.f && standin_ok(A.standin_tau2, d, iter == 0 ? d : dprev, 1.f))) { iter++; break; }
-      if (d < rel2 * d0) { iter++; break; }
+      // One exit branch per iteration, the first iteration's values by selects [r5]: two exits and a block under `iter == 0` cost the
+      // 2^4 forward sweep 7 % (fp32-mixed 2.05 -> 1.91 ms, fp64 2.35 -> 2.26; profiles/r5_q32_ab3.txt).  Same decisions, same counts.
+      // (fp32-mixed: the iterates cannot get below their fp32 floor - no error-estimate rule there; n2 is the same in every iteration)
+      const bool first = iter == 0;
+      d0 = first ? d : d0;
+      if (F32) tol2 = fmaxf(abs2, F32_SOLVER_TOL * F32_SOLVER_TOL * n2);
+      const bool stop = (F32 ? d <= tol2 : (d < 1.f && standin_ok(A.standin_tau2, d, first ? d : dprev, 1.f))) | (d < rel2 * d0);
       dprev = d;
+      if (stop) { iter++; break; }
     }
     return iter;
   }
