@@ -175,6 +175,19 @@ static bool spin_until(P pred, double timeout_s) {
 // Collectives have no time limit of their own: the ranks of the host backend share a GPU, their sweeps serialise, and the arrival skew of a
 // large or chunked gradient evaluation is legitimately long (RCCL has no such limit either).  A wait ends when pred() holds, when a peer
 // PROCESS is gone (checked once a second: kill(pid, 0)), or after QD_COMM_COLLECTIVE_TIMEOUT_S (default one day).
+// (a process that has exited but has not been reaped by its launcher yet still answers kill(pid, 0): state Z in /proc/<pid>/stat)
+static bool process_alive(long pid) {
+  if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) return false;
+  char path[64], buf[512];
+  snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+  FILE* f = fopen(path, "r");
+  if (!f) return true;  // (no procfs: kill's answer stands)
+  const size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  const char* rp = strrchr(buf, ')');  // the command name may contain spaces and parentheses
+  return !(rp && rp[1] == ' ' && (rp[2] == 'Z' || rp[2] == 'X'));
+}
 static int host_wait(qd::HostRing* g, const std::function<bool()>& pred) {
   static const double limit = [] {
     const char* e = getenv("QD_COMM_COLLECTIVE_TIMEOUT_S");
@@ -186,7 +199,7 @@ static int host_wait(qd::HostRing* g, const std::function<bool()>& pred) {
     if (spin_until(pred, 1.0)) return 0;
     for (int r = 0; r < g->nranks; r++) {
       const long p = (long)g->seg->pid[r].v.load(std::memory_order_acquire);
-      if (r != g->rank && p > 0 && kill((pid_t)p, 0) != 0 && errno == ESRCH) return 1 + r;
+      if (r != g->rank && p > 0 && !process_alive(p)) return 1 + r;
     }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return -1;
   }

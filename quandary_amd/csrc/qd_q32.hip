@@ -1314,11 +1314,17 @@ static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
   return a.nb <= 256 ? 1 : 2;
 }
 hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+#ifdef QD_Q32_Q4_SB1
+  if (a.S.Q == 4 && !a.use_gmres) return go_fwd<4, 1, double>(a, st);
+#endif
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves (stationary iterations only)
   if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
   return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
 }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+#ifdef QD_Q32_Q4_SB1
+  if (a.S.Q == 4 && !a.use_gmres) return go_adj<4, 1, double>(a, st);
+#endif
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double>(a, st);
   if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
   return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);

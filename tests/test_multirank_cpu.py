@@ -219,3 +219,59 @@ def test_file_bootstrap_picks_the_host_backend_when_ranks_outnumber_gpus(tmp_pat
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+
+
+def test_file_bootstrap_decides_on_the_ranks_of_this_node(tmp_path, monkeypatch):
+    """the automatic backend choice counts the ranks OF THIS NODE (QD_LOCAL_SIZE, set by the launchers), not the
+    global rank count - a launch that spans nodes with more ranks per node than GPUs is refused at once (a POSIX segment does not reach
+    the other nodes) instead of timing out in the shared-memory bootstrap; a dead peer ends a collective without waiting for a timer."""
+    import ctypes as C
+
+    from quandary_amd import capi
+
+    lib = capi.load_library()
+    monkeypatch.delenv("QD_COMM_BACKEND", raising=False)
+    monkeypatch.setenv("QD_LOCAL_SIZE", "2")  # two of four ranks on this node, no GPU visible here
+    comm = C.c_void_p()
+    rc = lib.qd_comm_create_from_file(str(tmp_path / ".id").encode(), 0, 4, 0, 5.0, C.byref(comm))
+    assert rc != 0 and "spans nodes" in lib.qd_last_error().decode()
+
+
+def _dying_worker(rank, name, q):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+
+    from quandary_amd import capi
+
+    lib = capi.load_library()
+    comm = C.c_void_p()
+    rc = lib.qd_comm_create_host(name.encode(), rank, 2, 0, 30.0, C.byref(comm))
+    if rc != 0:
+        q.put((rank, "error", lib.qd_last_error().decode()))
+        return
+    if rank == 1:
+        os._exit(0)  # gone without a word, before the collective
+    import time
+
+    v = np.array([1.0, 2.0])
+    t0 = time.time()
+    rc = lib.qd_comm_allreduce(comm, capi.dptr(v), 2, 0)
+    q.put((rank, "done", (rc, lib.qd_last_error().decode(), time.time() - t0)))
+
+
+def test_host_collective_fails_when_a_peer_process_is_gone():
+    import multiprocessing as mp
+    import uuid
+
+    name = "d" + uuid.uuid4().hex[:12]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dying_worker, args=(r, name, q)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    rank, status, out = q.get(timeout=120)
+    assert (rank, status) == (0, "done"), out
+    rc, msg, dt = out
+    assert rc != 0 and "is gone" in msg and dt < 20.0, out  # (liveness is checked once a second; the bootstrap timeout was 30 s)
+    for p in procs:
+        p.join(timeout=60)
