@@ -1298,7 +1298,8 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
 }
 
 // fp64 instantiation of the lean slot kernel: the Neumann sweeps of the 2^5 Lindblad system in QD_PRECISION_F64 and [r4] of the 2^4
-// one (the 4-qubit open system: forward sweep 2.70 -> 2.46 ms against the general kernel, gradient evaluation equal)
+// one (the 4-qubit open system: forward sweep 2.70 -> 2.46 ms against the general kernel, gradient evaluation equal; [r5] two waves of
+// two elements instead of four waves of one: 2.55 against 2.25 ms, not kept)
 bool lean64_available(const DevSys& S, const TuneOpts& o) {
   if (!S.lindblad || S.dense || S.hasJ || (S.Q != 5 && S.Q != 4)) return false;
   for (int k = 0; k < S.Q; k++)
@@ -1314,17 +1315,11 @@ static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
   return a.nb <= 256 ? 1 : 2;
 }
 hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
-#ifdef QD_Q32_Q4_SB1
-  if (a.S.Q == 4 && !a.use_gmres) return go_fwd<4, 1, double>(a, st);
-#endif
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves (stationary iterations only)
   if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
   return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
 }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
-#ifdef QD_Q32_Q4_SB1
-  if (a.S.Q == 4 && !a.use_gmres) return go_adj<4, 1, double>(a, st);
-#endif
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double>(a, st);
   if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
   return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);
