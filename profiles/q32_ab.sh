@@ -25,12 +25,13 @@ for name in os.environ.get("WL", "c5").split():
     for dt in os.environ.get("DT", "f32mixed").split():
         sp = workload_spec(name, "gradient")
         sp.precision = dt
-        h = capi.Handle(sp); o = capi.Optim(h, sp)
+        shard = int(os.environ.get("SHARD", "1"))  # SHARD=N: shard 0 of N (what one GPU of an N-GPU run does between the collectives)
+        h = capi.Handle(sp); o = capi.Optim(h, sp) if shard == 1 else capi.Optim(h, sp, rank=0, nranks=shard)
         bf = bg = bgf = bga = 1e9
         for i in range(reps):
-            o.evalF(sp.params0); bf = min(bf, h.forward_ms)
+            (o.evalF(sp.params0) if shard == 1 else o.forward_local(sp.params0, False)); bf = min(bf, h.forward_ms)
         for i in range(reps):
-            o.evalGradF(sp.params0)
+            (o.evalGradF(sp.params0) if shard == 1 else o.gradient_local(sp.params0))
             if h.forward_ms + h.adjoint_ms < bg: bg, bgf, bga = h.forward_ms + h.adjoint_ms, h.forward_ms, h.adjoint_ms
         print("%-14s %s %-8s applies %.3f  fwd %.3f ms   grad %.3f ms (fwd %.3f + adj %.3f)" % (os.environ["VAR"], name, dt, h.mean_applies, bf, bg, bgf, bga), flush=True)
         o.close(); h.close()
