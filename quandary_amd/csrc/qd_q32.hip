@@ -131,22 +131,46 @@ struct Q32 {
     return *reinterpret_cast<const f2*>(reinterpret_cast<const char*>(sx) + byteoff + (unsigned)slot * SLOT_BYTES);
   }
 
+  // The LDS neighbours of slot j, fetched into one object apart from the arithmetic on them [r5]: with the reads written inside the loop
+  // over the oscillators the compiler interleaved them with the fp64 chains; all of them first is 12 % on the 2^4 sweeps, whose four
+  // waves sit alone on their SIMDs (forward 2.26 -> 1.99 ms, gradient 5.44 -> 4.70; 2^5 unchanged).  Issuing the next pass's first slot
+  // together with the partial sums of the stopping test (one LDS round trip less in the dependent chain) was measured on top of it
+  // and lost: 2.10 ms.
+  struct Nb {
+    f2 xb[Q], xk[Q], xl[Q];
+  };
+  template <bool TRANS>
+  __device__ __forceinline__ void load(const f2* __restrict__ sx, int j, Nb& n) const {
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      n.xb[k] = at(sx, ab[k], j);
+      if (k >= SB) n.xk[k] = at(sx, ak[k], j);
+      const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
+      if (slot_ok) n.xl[k] = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+    }
+  }
   // y = M x (TRANS = false) or M^T x at slot j; see QubitSlotStencil::apply for the derivation
   template <bool TRANS>
   __device__ __forceinline__ f2 apply(const f2* __restrict__ sx, int j, const f2 (&xall)[EPT]) const {
+    Nb n;
+    load<TRANS>(sx, j, n);
+    return apply_nb<TRANS>(j, xall, n);
+  }
+  template <bool TRANS>
+  __device__ __forceinline__ f2 apply_nb(int j, const f2 (&xall)[EPT], const Nb& n) const {
     const f2 xs = xall[j];
     R hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0, gi = 0;
     R l1r = 0, l1i = 0;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
-      const f2 xb = at(sx, ab[k], j);
+      const f2 xb = n.xb[k];
       f2 xk;
       R sqk;
       if (k < SB) {  // ket neighbour = own slot with the slot bit flipped; the sign of the slot bit is a constant
         xk = xall[slotflip(j, k)];
         sqk = slotbit(j, k) ? -q[k] : q[k];
       } else {
-        xk = at(sx, ak[k], j);
+        xk = n.xk[k];
         sqk = qk[k];
       }
       R& ar = (k & 1) ? gr : hr;
@@ -162,7 +186,7 @@ struct Q32 {
       // T1 off-diagonal: forward needs both digits 0 (the neighbour has both set), transposed both 1
       const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
       if (slot_ok) {
-        const f2 xl = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+        const f2 xl = n.xl[k];
         const R l1 = TRANS ? l1t[k] : l1f[k];
         l1r = rfma(l1, xl.x, l1r);
         l1i = rfma(l1, xl.y, l1i);
@@ -350,11 +374,21 @@ struct Q32<Q, SB, float> {
     // Every p-term and the Hamiltonian diagonal have the form s J(v), J(v) = (v.y, -v.x): they are accumulated as U = sum s v with plain
     // broadcast coefficients and rotated once at the end, A = V + J(U) - a per-half negation is the one operand form instruction
     // selection does not fold (it rebuilds the pair with v_xor + v_mov), whole-vector negation and broadcasts it does.
+    // (all LDS neighbours of the slot first, then the arithmetic: see Nb of the scalar template; here 2^4 forward 1.92 -> 1.84 ms,
+    //  gradient 4.84 -> 4.57, 2^5 forward 8.6 -> 8.4)
+    pk2 nxb[Q], nxk[Q], nxl[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      nxb[k] = at(sx, ab[k], j);
+      if (k >= SB) nxk[k] = at(sx, ak[k], j);
+      const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
+      if (slot_ok) nxl[k] = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+    }
     pk2 U = bc(cdj.x) * xs, V = {0.f, 0.f}, l1 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < Q; k++) {
       const pk2 pqk = pq[k] = here_s(pq[k]);
-      const pk2 xb = at(sx, ab[k], j);
+      const pk2 xb = nxb[k];
       U = pk_fma(bc(pqk.x), xb, U);
       V = pk_fma(bc(tq[k / 2][k % 2]), xb, V);
       pk2 xk;
@@ -362,15 +396,14 @@ struct Q32<Q, SB, float> {
         xk = pkv(xall[slotflip(j, k)]);
         V = pk_fma(bc(pqk.y), slotbit(j, k) ? -xk : xk, V);
       } else {
-        xk = at(sx, ak[k], j);
+        xk = nxk[k];
         V = pk_fma(bc(tq[(Q + k - SB) / 2][(Q + k - SB) % 2]), xk, V);
       }
       U = pk_fma(bc(pqk.x), -xk, U);
       // T1 off-diagonal: forward needs both digits 0 (the neighbour has both set), transposed both 1
       const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
       if (slot_ok) {
-        const pk2 xl = at(sx, al[k], k < SB ? slotflip(j, k) : j);
-        l1 = pk_fma(bc(tl[k / 2][k % 2]), xl, l1);
+        l1 = pk_fma(bc(tl[k / 2][k % 2]), nxl[k], l1);
       }
     }
     const pk2 A = {V.x + U.y, V.y - U.x};
