@@ -188,3 +188,68 @@ def test_driver_under_mpirun_as_quandary_py_launches_it(case, np_, share, tmp_pa
     t = _load(os.path.join(db, "timing.dat"))
     assert int(t[0][0]) == (np_ if share else 1)
     assert not glob.glob(os.path.join(db, "**", ".qd_comm_id*"), recursive=True)
+
+
+def _rccl_file_worker(rank, path, delay, q):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import time
+
+    from quandary_amd import capi
+
+    lib = capi.load_library()
+    time.sleep(delay)
+    comm = C.c_void_p()
+    t0 = time.time()
+    rc = lib.qd_comm_create_from_file(path.encode(), rank, 2, 0, 40.0, C.byref(comm))
+    msg = lib.qd_last_error().decode() if rc else ""
+    out = None
+    if rc == 0:  # (an RCCL build that accepts two ranks on one device: then the collective must work too)
+        v = np.array([1.0 + rank, 10.0 * (1 + rank)])
+        rc2 = lib.qd_comm_allreduce(comm, capi.dptr(v), 2, 0)
+        out = (rc2, v.tolist())
+        lib.qd_comm_destroy(comm)
+    q.put((rank, rc, msg, time.time() - t0, out))
+
+
+def test_rccl_file_bootstrap_with_two_ranks_and_leftovers_of_a_crashed_run(tmp_path, monkeypatch):
+    """The RCCL bootstrap of qd_comm_create_from_file with MORE THAN ONE rank on hardware: leftovers of a run killed inside
+    ncclCommInitRank - an id file and go / ack files carrying one matching token - lie in the directory, rank 1 starts a second before
+    rank 0.  Rank 1 must not act on them: both ranks complete the handshake on the id of THIS run (ncclGetUniqueId, echo with a nonce,
+    go file returning the nonce) and reach ncclCommInitRank together.  On a one-GPU box RCCL then refuses the second rank on the same
+    device - an error of RCCL, returned by both ranks, not a timeout of the handshake; a build that accepts it must reduce correctly."""
+    import multiprocessing as mp
+    import struct
+
+    monkeypatch.setenv("QD_COMM_BACKEND", "rccl")
+    monkeypatch.delenv("QD_JOB_ID", raising=False)
+    path = str(tmp_path / ".qd_comm_id")
+    stale = 0x1234567812345678
+    with open(path, "wb") as f:  # IdFile {magic[8], nonce, token, id[128]} of a dead run
+        f.write(b"QDCOMM03" + struct.pack("<QQ", 0, stale) + bytes(128))
+    for name in (path + ".go", path + ".go1", path + ".ack1"):
+        with open(name, "wb") as f:
+            f.write(struct.pack("<QQ", stale, stale))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_file_worker, args=(1, path, 0.0, q)), ctx.Process(target=_rccl_file_worker, args=(0, path, 1.0, q))]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in procs:
+            rank, rc, msg, dt, out = q.get(timeout=120)
+            res[rank] = (rc, msg, dt, out)
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    assert set(res) == {0, 1}, res
+    print("rccl two-rank bootstrap on one GPU:", {r: (v[0], v[1][:120], round(v[2], 2), v[3]) for r, v in res.items()})
+    for rank, (rc, msg, dt, out) in res.items():
+        assert "timed out" not in msg, (rank, msg)
+        if rc == 0:
+            assert out == (0, [3.0, 30.0]), (rank, out)
+        else:
+            assert "nccl" in msg.lower() or "rccl" in msg.lower() or "CommInitRank" in msg, (rank, msg)
