@@ -266,6 +266,8 @@ int qd_last_solver(const qd_handle* h);
  * v_fma_f64 micro-benchmark on the device and returns the sustained TFLOP/s in
  * *tflops (the fp64 peak is to be measured, not quoted). */
 int qd_measure_fp64_peak(int device_ordinal, double* tflops);
+/* the same with v_pk_fma_f32 (fp32-mixed sweeps: the packed form is what the 157.3 TFLOP/s fp32 vector peak is quoted for) */
+int qd_measure_fp32_peak(int device_ordinal, double* tflops);
 
 /* ---------------------------------------------------------------------------
  * Objective level: OptimProblem::evalF / evalGradF over the local shard of

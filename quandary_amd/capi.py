@@ -174,7 +174,7 @@ EXPORTS = [
     "qd_last_error", "qd_version", "qd_device_count", "qd_create", "qd_destroy", "qd_dim", "qd_dim_rho",
     "qd_dim_ess", "qd_ndesign", "qd_set_hamiltonian", "qd_set_params", "qd_eval_controls", "qd_apply_rhs", "qd_get_state",
     "qd_set_target", "qd_set_penalty", "qd_forward", "qd_adjoint", "qd_last_mean_applies",
-    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_last_team", "qd_last_solver", "qd_measure_fp64_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
+    "qd_last_forward_ms", "qd_last_adjoint_ms", "qd_last_team", "qd_last_solver", "qd_measure_fp64_peak", "qd_measure_fp32_peak", "qd_optim_create", "qd_optim_destroy", "qd_optim_ninit",
     "qd_optim_ninit_local", "qd_optim_initial_state", "qd_optim_target_state", "qd_optim_forward_local",
     "qd_optim_finalize", "qd_optim_adjoint_local", "qd_optim_gradient_local", "qd_optim_evalF", "qd_optim_evalGradF",
     "qd_comm_unique_id", "qd_comm_create", "qd_comm_create_from_file", "qd_comm_create_host", "qd_comm_backend", "qd_comm_destroy", "qd_comm_size", "qd_comm_rank",
@@ -229,6 +229,7 @@ def load_library(path=None):
     lib.qd_last_team.argtypes = [vp]
     lib.qd_last_solver.argtypes = [vp]
     lib.qd_measure_fp64_peak.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    lib.qd_measure_fp32_peak.argtypes = [C.c_int, C.POINTER(C.c_double)]
     lib.qd_optim_create.argtypes = [vp, C.POINTER(qd_objective), C.c_int, C.c_int, C.POINTER(vp)]
     lib.qd_optim_destroy.argtypes = [vp]
     lib.qd_optim_destroy.restype = None
@@ -275,6 +276,14 @@ def measure_fp64_peak(device=0):
     lib = load_library()
     v = C.c_double(0.0)
     _check(lib, lib.qd_measure_fp64_peak(device, C.byref(v)), "qd_measure_fp64_peak")
+    return v.value
+
+
+def measure_fp32_peak(device=0):
+    """Sustained packed-fp32 FMA rate of the device in TFLOP/s (v_pk_fma_f32, register-only micro-benchmark)."""
+    lib = load_library()
+    v = C.c_double(0.0)
+    _check(lib, lib.qd_measure_fp32_peak(device, C.byref(v)), "qd_measure_fp32_peak")
     return v.value
 
 

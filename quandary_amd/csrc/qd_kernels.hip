@@ -776,13 +776,33 @@ __global__ void __launch_bounds__(256) k_fma_peak(double* out, int iters, double
   if (s == 12345.678) out[0] = s;  // never true; keeps the chains alive
 }
 
-extern "C" int qd_measure_fp64_peak(int device_ordinal, double* tflops) {
+// the same for fp32 on packed pairs (v_pk_fma_f32: the form the fp32 vector peak is quoted for; profiles/r5_rate_probe.json)
+typedef float qd_pk2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_fma_peak_f32(double* out, int iters, float a, float b) {
+  qd_pk2 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = qd_pk2{(float)(threadIdx.x + i) * 1e-3f, (float)(threadIdx.x + 8 + i) * 1e-3f};
+  const qd_pk2 av = {a, a}, bv = {b, b};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = __builtin_elementwise_fma(v[i], av, bv);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += v[i].x + v[i].y;
+  if (s == 12345.678f) out[0] = s;  // never true; keeps the chains alive
+}
+
+static int measure_peak(int device_ordinal, double* tflops, bool f32, const char* who);
+extern "C" int qd_measure_fp64_peak(int device_ordinal, double* tflops) { return measure_peak(device_ordinal, tflops, false, "qd_measure_fp64_peak"); }
+extern "C" int qd_measure_fp32_peak(int device_ordinal, double* tflops) { return measure_peak(device_ordinal, tflops, true, "qd_measure_fp32_peak"); }
+static int measure_peak(int device_ordinal, double* tflops, bool f32, const char* who) {
   if (!tflops) {
-    qd::set_error("qd_measure_fp64_peak: null output");
+    qd::set_error(std::string(who) + ": null output");
     return QD_ERR_INVALID;
   }
   if (hipSetDevice(device_ordinal) != hipSuccess) {
-    qd::set_error("qd_measure_fp64_peak: no such device");
+    qd::set_error(std::string(who) + ": no such device");
     return QD_ERR_DEVICE;
   }
   hipDeviceProp_t prop;
@@ -793,12 +813,16 @@ extern "C" int qd_measure_fp64_peak(int device_ordinal, double* tflops) {
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   const int blocks = prop.multiProcessorCount * 16, threads = 256, iters = 1 << 15;
-  hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999, 1e-9);  // warm-up (clock ramp)
+  auto go = [&] {
+    if (f32) hipLaunchKernelGGL(k_fma_peak_f32, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999f, 1e-9f);
+    else hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999, 1e-9);
+  };
+  go();  // warm-up (clock ramp)
   hipError_t err = hipSuccess;
   float ms = 0.f;
   for (int rep = 0; rep < 3; rep++) {  // best of three
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_fma_peak, dim3(blocks), dim3(threads), 0, 0, d, iters, 0.999999, 1e-9);
+    go();
     (void)hipEventRecord(e1, 0);
     err = hipEventSynchronize(e1);
     float m = 0.f;
@@ -810,9 +834,9 @@ extern "C" int qd_measure_fp64_peak(int device_ordinal, double* tflops) {
   (void)hipEventDestroy(e1);
   (void)hipFree(d);
   if (err != hipSuccess || ms <= 0.f) {
-    qd::set_error("qd_measure_fp64_peak: kernel failed");
+    qd::set_error(std::string(who) + ": kernel failed");
     return QD_ERR_DEVICE;
   }
-  *tflops = 2.0 * 8.0 * (double)iters * (double)blocks * (double)threads / (ms * 1e-3) / 1e12;
+  *tflops = (f32 ? 2.0 : 1.0) * 2.0 * 8.0 * (double)iters * (double)blocks * (double)threads / (ms * 1e-3) / 1e12;
   return QD_OK;
 }
