@@ -988,7 +988,7 @@ int qd_handle::forward_finish(double* energy) {
   const bool store = pending_store;
   QD_HIP(hipStreamSynchronize(stream));
   if (sliced_fwd && reinterpret_cast<const unsigned*>(h_sched.p)[0] != 0u)
-    return fail(QD_ERR_DEVICE, "forward sweep: a time slice waited more than four seconds for its predecessor (time-sliced scheduling, option col_slices)");
+    return fail(QD_ERR_DEVICE, "forward sweep: a time slice waited longer than its limit for its predecessor (time-sliced scheduling: options col_slices, sched_wait_s)");
   unsigned long long nap = 0;
   std::memcpy(&nap, h_res.p + 6 * (size_t)nb, sizeof nap);
   float ms = 0.f;
@@ -1206,7 +1206,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
 int qd_handle::adjoint_finish(bool accumulate) {
   QD_HIP(hipStreamSynchronize(stream));
   if (sliced_adj && reinterpret_cast<const unsigned*>(h_sched.p)[1] != 0u)
-    return fail(QD_ERR_DEVICE, "adjoint sweep: a time slice waited more than four seconds for its predecessor (time-sliced scheduling, option col_slices)");
+    return fail(QD_ERR_DEVICE, "adjoint sweep: a time slice waited longer than its limit for its predecessor (time-sliced scheduling: options col_slices, sched_wait_s)");
   float ms = 0.f;
   QD_HIP(hipEventElapsedTime(&ms, ev2, ev3));
   last_adj_ms = accumulate ? last_adj_ms + ms : ms;

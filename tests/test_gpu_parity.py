@@ -195,6 +195,25 @@ def test_lean_column_kernels(kw, stepper, split):
     opt.close(); h.close(); orc.close()
 
 
+def test_a_slice_that_waits_beyond_its_limit_raises_instead_of_hanging():
+    """Time-sliced column sweeps: slice k of an initial condition waits for slice k - 1; beyond the limit (option sched_wait_s; automatic:
+    4 s x processes sharing the device x slice length in thousands of steps) the sweep ends with an error, never a hung device.  With
+    fewer tasks than resident workgroups every slice is drawn at once, so slice 1 waits a whole slice for slice 0: a limit of 100 ns
+    must trip; the handle stays usable and the automatic limit gives the result of the unsliced sweep."""
+    sp = synthetic_spec(**{**LEANCOL_SHAPES[0].values[0], "ntime": 200, "penalties": False, "dt": 0.002, "init": "basis, 0"})
+    sp.options = {"col_slices": 4, "sched_wait_s": 1e-7}
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    with pytest.raises(capi.QuandaryAmdError, match="waited longer than its limit"):
+        opt.evalF(sp.params0)
+    h.set_option("sched_wait_s", "auto")
+    val = opt.evalF(sp.params0)
+    h.set_option("col_slices", 1)
+    val1 = opt.evalF(sp.params0)
+    assert val["objective"] == pytest.approx(val1["objective"], rel=1e-13)
+    opt.close(); h.close()
+
+
 @pytest.mark.parametrize("slices", [2, 5])
 @pytest.mark.parametrize("stepper,ntime", [("IMR", 13), ("IMR4", 7)])
 @pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[1], LEANCOL_SHAPES[2], LEANCOL_SHAPES[3]])
