@@ -23,7 +23,8 @@ from quandary_amd.workloads import workload_spec
 reps = int(os.environ.get("REPS", "6"))
 for name in os.environ.get("WL", "c5").split():
     for dt in os.environ.get("DT", "f32mixed").split():
-        sp = workload_spec(name, "gradient")
+        over = {"linearsolver_type": os.environ["LINSOLVE"]} if os.environ.get("LINSOLVE") else None  # LINSOLVE=gmres: the reference's default request
+        sp = workload_spec(name, "gradient", over)
         sp.precision = dt
         shard = int(os.environ.get("SHARD", "1"))  # SHARD=N: shard 0 of N (what one GPU of an N-GPU run does between the collectives)
         h = capi.Handle(sp); o = capi.Optim(h, sp) if shard == 1 else capi.Optim(h, sp, rank=0, nranks=shard)

@@ -278,7 +278,9 @@ struct ColLean {
 typedef double col_d2 __attribute__((ext_vector_type(2)));
 
 // per-workgroup machinery: buffers, reductions, the Neumann solver
-template <int Q, int EPT, bool SPLIT = false, bool USLOT = false>
+// SKIP: the solver skips stopping tests (stage / neumann below) - an instantiation of its own: compiled into the kernels that serve a
+// gmres request (which never skip) the second code path cost them 11 % (763 against 685 ms on the 3 x 20 workload)
+template <int Q, int EPT, bool SPLIT = false, bool USLOT = false, bool SKIP = false>
 struct ColTeam {
   typedef ColLean<Q, EPT, SPLIT, USLOT> ST;
   ST st;
@@ -415,9 +417,7 @@ struct ColTeam {
     }
     publish(y);
     float d0 = 1.f, dprev = 1.f;
-#ifndef QD_COL_ALWAYS_TEST
-    const int skip = (A.standin_tau2 == 0.f && !A.stop_residual && rel2 < 1e-30f) ? lastna - 2 : 0;
-#endif
+    const int skip = SKIP ? lastna - 2 : 0;  // (the launcher instantiates SKIP for the plain update-norm rule only)
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
       const unsigned wa = st.tb + (unsigned)st.dlt;
@@ -438,29 +438,27 @@ struct ColTeam {
         st.st(wa + (unsigned)j * COLB, w);
         slot_fence<EPT>();
       }
-#ifndef QD_COL_ALWAYS_TEST
-      const bool test = iter >= skip;  // (see stage())
-      float d = 1e30f;
-      if (test) d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
-      else __syncthreads();
-      st.flip();
-      if (!test) continue;
-      d0 = (iter == 0 || iter == skip) ? d : d0;
-      const float dp = (iter == 0 || iter == skip) ? d : dprev;
-#else
-      const float d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
-      st.flip();
-      // (one exit branch per pass, first-iteration values by selects [r5]: 637.6 -> 632.3 ms on the 3600 x 2500 sweep, same counts)
-      d0 = iter == 0 ? d : d0;
-      const float dp = iter == 0 ? d : dprev;
-#endif
+      float d = 1e30f, dp;
+      if constexpr (SKIP) {  // (see stage())
+        const bool test = iter >= skip;
+        if (test) d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
+        else __syncthreads();
+        st.flip();
+        if (!test) continue;
+        d0 = (iter == 0 || iter == skip) ? d : d0;
+        dp = (iter == 0 || iter == skip) ? d : dprev;
+      } else {
+        d = sum_f32((float)fmin(dl * inv_abs2, 1e30));  // contains the barrier that makes the new iterate readable
+        st.flip();
+        // (one exit branch per pass, first-iteration values by selects [r5]: 637.6 -> 632.3 ms on the 3600 x 2500 sweep, same counts)
+        d0 = iter == 0 ? d : d0;
+        dp = iter == 0 ? d : dprev;
+      }
       const bool stop = (d < thr && standin_ok(A.standin_tau2, d, dp, thr)) | (d < rel2 * d0);
       dprev = d;
       if (stop) { iter++; break; }
     }
-#ifndef QD_COL_ALWAYS_TEST
-    lastna = iter;
-#endif
+    if (SKIP) lastna = iter;
     return iter;
   }
 
@@ -480,9 +478,7 @@ struct ColTeam {
     float rel2 = A.rel2, thr = 1.f, d0 = 1.f, dprev = 1.f;
 #pragma unroll
     for (int j = 0; j < EPT; j++) z[j] = x[j];
-#ifndef QD_COL_ALWAYS_TEST
-    const int skip = (A.standin_tau2 == 0.f && !A.stop_residual && rel2 < 1e-30f) ? lastn - 3 : 0;
-#endif
+    const int skip = SKIP ? lastn - 3 : 0;  // (the launcher instantiates SKIP for the plain update-norm rule only)
     int iter;
     for (iter = -1; iter < A.maxiter; iter++) {
       const unsigned wa = st.tb + (unsigned)st.dlt;
@@ -503,44 +499,39 @@ struct ColTeam {
         st.st(wa + (unsigned)j * COLB, w);
         slot_fence<EPT>();
       }
-#ifndef QD_COL_ALWAYS_TEST
-      // [r5] The reduction of the update norm costs ~25 vector instructions and an LDS round trip behind the barrier.  Consecutive sub-steps
-      // converge after the same number of passes (the controls move slowly): under the reference's plain update-norm rule the passes up
-      // to two before the count of the previous sub-step only synchronise.  A solve that would have stopped earlier runs on to the first
-      // tested pass: more passes than the reference, never fewer (3600 x 2500 sweep: 8.238 -> 8.240 passes per step, 641 -> 614 ms;
-      // -DQD_COL_ALWAYS_TEST builds the reference's test-every-pass form).
-      const bool test = iter < 0 ? A.stop_residual != 0 : iter >= skip;
+      // [r5] SKIP: the reduction of the update norm costs ~25 vector instructions and an LDS round trip behind the barrier.  Consecutive
+      // sub-steps converge after the same number of passes (the controls move slowly): under the reference's plain update-norm rule the
+      // passes up to two before the count of the previous sub-step only synchronise.  A solve that would have stopped earlier runs on to
+      // the first tested pass: more passes than the reference, never fewer (3600 x 2500 sweep: 8.238 -> 8.240 passes per step, 635 -> 611 ms).
+      // Under the rule that stands in for GMRES the error estimate of the first tested pass has no predecessor to compare with and
+      // more passes are lost than tests saved (8.98 -> 9.60 passes, 685 -> 697 ms): those requests run the instantiation without SKIP.
+      bool test = true;
       float d = 1e30f;
-      if (test) d = sum_f32((float)fmin(dl * sc, 1e30));  // contains the barrier that makes the new iterate readable
-      else __syncthreads();
-#else
-      const float d = sum_f32((float)fmin(dl * sc, 1e30));  // contains the barrier that makes the new iterate readable
-#endif
+      if constexpr (SKIP) {
+        test = iter >= skip;
+        if (test) d = sum_f32((float)fmin(dl * sc, 1e30));  // contains the barrier that makes the new iterate readable
+        else __syncthreads();
+      } else {
+        d = sum_f32((float)fmin(dl * sc, 1e30));  // contains the barrier that makes the new iterate readable
+      }
       st.flip();
       if (iter < 0) {  // first pass: d = ||y_0||^2 / abstol^2
-        if (A.stop_residual) {
+        if (!SKIP && A.stop_residual) {
           thr = (float)fmin(fmax(A.reltol * A.reltol * (double)d, 1.0) / A.kappa2, 1e30);  // (d is capped at 1e30: conservative)
           rel2 = 0.f;
         }
         continue;
       }
-#ifndef QD_COL_ALWAYS_TEST
-      if (!test) continue;
+      if (SKIP && !test) continue;
       // (one exit branch per pass, first-iteration values by selects [r5]: 637.6 -> 632.3 ms on the 3600 x 2500 sweep, same counts)
-      d0 = (iter == 0 || iter == skip) ? d : d0;
-      const float dp = (iter == 0 || iter == skip) ? d : dprev;
-#else
-      // (one exit branch per pass, first-iteration values by selects [r5]: 637.6 -> 632.3 ms on the 3600 x 2500 sweep, same counts)
-      d0 = iter == 0 ? d : d0;
-      const float dp = iter == 0 ? d : dprev;
-#endif
+      const bool first = iter == 0 || (SKIP && iter == skip);
+      d0 = first ? d : d0;
+      const float dp = first ? d : dprev;
       const bool stop = (d < thr && standin_ok(A.standin_tau2, d, dp, thr)) | (d < rel2 * d0);
       dprev = d;
       if (stop) { iter++; break; }
     }
-#ifndef QD_COL_ALWAYS_TEST
-    lastn = iter + 1;
-#endif
+    if (SKIP) lastn = iter + 1;
     return iter + 1;
   }
 };
@@ -599,10 +590,10 @@ __device__ __forceinline__ int slice_start(const SweepArgs& A, int sl) {
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, bool SPLIT, bool USLOT = false>
+template <int Q, int EPT, bool SPLIT, bool USLOT = false, bool SKIP = false>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT, SPLIT, USLOT> TM;
+  typedef ColTeam<Q, EPT, SPLIT, USLOT, SKIP> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -723,10 +714,10 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, bool SPLIT, bool USLOT = false>
+template <int Q, int EPT, bool SPLIT, bool USLOT = false, bool SKIP = false>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef ColTeam<Q, EPT, SPLIT, USLOT> TM;
+  typedef ColTeam<Q, EPT, SPLIT, USLOT, SKIP> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
@@ -973,7 +964,10 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  auto kf = col_uslot<EPT>(a.S) ? k_forward_col<Q, EPT, SPLIT, true> : k_forward_col<Q, EPT, SPLIT, false>;
+  // (SKIP: stopping tests skipped - the plain update-norm rule only, see ColTeam::stage)
+  const bool skip = a.standin_tau2 == 0.f && !a.stop_residual && a.rel2 < 1e-30f;
+  auto kf = col_uslot<EPT>(a.S) ? (skip ? k_forward_col<Q, EPT, SPLIT, true, true> : k_forward_col<Q, EPT, SPLIT, true, false>)
+                                : (skip ? k_forward_col<Q, EPT, SPLIT, false, true> : k_forward_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
@@ -987,7 +981,9 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  auto kf = col_uslot<EPT>(a.S) ? k_adjoint_col<Q, EPT, SPLIT, true> : k_adjoint_col<Q, EPT, SPLIT, false>;
+  const bool skip = a.standin_tau2 == 0.f && !a.stop_residual && a.rel2 < 1e-30f;
+  auto kf = col_uslot<EPT>(a.S) ? (skip ? k_adjoint_col<Q, EPT, SPLIT, true, true> : k_adjoint_col<Q, EPT, SPLIT, true, false>)
+                                : (skip ? k_adjoint_col<Q, EPT, SPLIT, false, true> : k_adjoint_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
