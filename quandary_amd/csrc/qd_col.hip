@@ -52,6 +52,10 @@ struct ColLean {
   double cx[EPT][Q], cy[EPT][Q];  // sqrt(i'_k + 1) (0 at the top level), sqrt(i'_k) of the column of slot j
   int ocu[USLOT ? 1 : EPT][Q], ocd[USLOT ? 1 : EPT][Q];  // byte offset to the ket neighbour column up / down (0 where there is none)
   static __device__ __forceinline__ constexpr int us(int j) { return USLOT ? 0 : j; }
+  // (USLOT: the level indices of the oscillators k < L are the same in every column of the wave, hence their square roots too - one
+  //  scalar pair per oscillator instead of one per slot: 16 scalar registers less on 3 x 20, where the adjoint sweep spills ~160)
+  __device__ __forceinline__ double cxv(int j, int k) const { return cx[(USLOT && k != L) ? 0 : j][k]; }
+  __device__ __forceinline__ double cyv(int j, int k) const { return cy[(USLOT && k != L) ? 0 : j][k]; }
   int N, row, col0;
   bool rowok;
   unsigned char* smem;
@@ -231,8 +235,8 @@ struct ColLean {
     for (int k = 0; k < Q; k++) {
       double2 xu, xd, xup, xdp;
       nbrs(k, j, own, prev, next, xu, xd, xup, xdp);
-      const double er = fma(-cy[j][k], xdp.x, su[k] * xu.x), ei = fma(-cy[j][k], xdp.y, su[k] * xu.y);  // U1 - D2
-      const double fr = fma(cx[j][k], xup.x, -sd[k] * xd.x), fi = fma(cx[j][k], xup.y, -sd[k] * xd.y);  // U2 - D1
+      const double er = fma(-cyv(j, k), xdp.x, su[k] * xu.x), ei = fma(-cyv(j, k), xdp.y, su[k] * xu.y);  // U1 - D2
+      const double fr = fma(cxv(j, k), xup.x, -sd[k] * xd.x), fi = fma(cxv(j, k), xup.y, -sd[k] * xd.y);  // U2 - D1
       const double pk = TRANS ? -c.p[k] : c.p[k], qk = TRANS ? -c.q[k] : c.q[k];
       ar = fma(qk, er + fr, fma(pk, ei - fi, ar));
       ai = fma(qk, ei + fi, fma(-pk, er - fr, ai));
@@ -244,7 +248,7 @@ struct ColLean {
       } else {
         xl = TRANS ? ld(ard[k] + (unsigned)ocd[us(j)][k] + (unsigned)j * COLB) : ld(aru[k] + (unsigned)ocu[us(j)][k] + (unsigned)j * COLB);
       }
-      const double l1 = TRANS ? g1d[k] * cy[j][k] : g1u[k] * cx[j][k];
+      const double l1 = TRANS ? g1d[k] * cyv(j, k) : g1u[k] * cxv(j, k);
       ar = fma(l1, xl.x, ar);
       ai = fma(l1, xl.y, ai);
     }
@@ -255,8 +259,8 @@ struct ColLean {
   __device__ __forceinline__ void ladder(int k, int j, const double2 own, const double2 prev, const double2 next, double2& A, double2& B) const {
     double2 xu, xd, xup, xdp;
     nbrs(k, j, own, prev, next, xu, xd, xup, xdp);
-    const double er = fma(-cy[j][k], xdp.x, su[k] * xu.x), ei = fma(-cy[j][k], xdp.y, su[k] * xu.y);
-    const double fr = fma(cx[j][k], xup.x, -sd[k] * xd.x), fi = fma(cx[j][k], xup.y, -sd[k] * xd.y);
+    const double er = fma(-cyv(j, k), xdp.x, su[k] * xu.x), ei = fma(-cyv(j, k), xdp.y, su[k] * xu.y);
+    const double fr = fma(cxv(j, k), xup.x, -sd[k] * xd.x), fi = fma(cxv(j, k), xup.y, -sd[k] * xd.y);
     A.x = er + fr;
     A.y = ei + fi;
     B.x = er - fr;
