@@ -282,8 +282,8 @@ struct ColLean {
 typedef double col_d2 __attribute__((ext_vector_type(2)));
 
 // per-workgroup machinery: buffers, reductions, the Neumann solver
-// SKIP: the solver skips stopping tests (stage / neumann below) - an instantiation of its own: compiled into the kernels that serve a
-// gmres request (which never skip) the second code path cost them 11 % (763 against 685 ms on the 3 x 20 workload)
+// SKIP: the solver skips stopping tests (stage / neumann below) - an instantiation of its own (a request with a relative tolerance
+// that can bind, rel2 >= 1e-30, keeps the test-every-pass kernels; with both forms in one kernel the second code path cost 11 %)
 template <int Q, int EPT, bool SPLIT = false, bool USLOT = false, bool SKIP = false>
 struct ColTeam {
   typedef ColLean<Q, EPT, SPLIT, USLOT> ST;
@@ -421,7 +421,7 @@ struct ColTeam {
     }
     publish(y);
     float d0 = 1.f, dprev = 1.f;
-    const int skip = SKIP ? lastna - 2 : 0;  // (the launcher instantiates SKIP for the plain update-norm rule only)
+    const int skip = SKIP ? lastna - (A.standin_tau2 != 0.f ? 3 : 2) : 0;  // (one more tested pass where the error estimate needs a predecessor)
     int iter;
     for (iter = 0; iter < A.maxiter; iter++) {
       const unsigned wa = st.tb + (unsigned)st.dlt;
@@ -482,7 +482,7 @@ struct ColTeam {
     float rel2 = A.rel2, thr = 1.f, d0 = 1.f, dprev = 1.f;
 #pragma unroll
     for (int j = 0; j < EPT; j++) z[j] = x[j];
-    const int skip = SKIP ? lastn - 3 : 0;  // (the launcher instantiates SKIP for the plain update-norm rule only)
+    const int skip = SKIP ? lastn - (A.standin_tau2 != 0.f ? 4 : 3) : 0;
     int iter;
     for (iter = -1; iter < A.maxiter; iter++) {
       const unsigned wa = st.tb + (unsigned)st.dlt;
@@ -507,12 +507,13 @@ struct ColTeam {
       // sub-steps converge after the same number of passes (the controls move slowly): under the reference's plain update-norm rule the
       // passes up to two before the count of the previous sub-step only synchronise.  A solve that would have stopped earlier runs on to
       // the first tested pass: more passes than the reference, never fewer (3600 x 2500 sweep: 8.238 -> 8.240 passes per step, 635 -> 611 ms).
-      // Under the rule that stands in for GMRES the error estimate of the first tested pass has no predecessor to compare with and
-      // more passes are lost than tests saved (8.98 -> 9.60 passes, 685 -> 697 ms): those requests run the instantiation without SKIP.
+      // Under the rule that stands in for GMRES the error estimate of a tested pass needs the norm of its predecessor: one more pass is
+      // tested there (without it the first tested pass compares with itself and passes are lost: 8.98 -> 9.60, 685 -> 697 ms; with it
+      // 8.975 -> 8.979 passes, 675 -> 655 ms), and its first pass is reduced for ||y_0||.
       bool test = true;
       float d = 1e30f;
       if constexpr (SKIP) {
-        test = iter >= skip;
+        test = iter < 0 ? A.stop_residual != 0 : iter >= skip;
         if (test) d = sum_f32((float)fmin(dl * sc, 1e30));  // contains the barrier that makes the new iterate readable
         else __syncthreads();
       } else {
@@ -520,7 +521,7 @@ struct ColTeam {
       }
       st.flip();
       if (iter < 0) {  // first pass: d = ||y_0||^2 / abstol^2
-        if (!SKIP && A.stop_residual) {
+        if (A.stop_residual) {
           thr = (float)fmin(fmax(A.reltol * A.reltol * (double)d, 1.0) / A.kappa2, 1e30);  // (d is capped at 1e30: conservative)
           rel2 = 0.f;
         }
@@ -968,8 +969,8 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  // (SKIP: stopping tests skipped - the plain update-norm rule only, see ColTeam::stage)
-  const bool skip = a.standin_tau2 == 0.f && !a.stop_residual && a.rel2 < 1e-30f;
+  // (SKIP: stopping tests skipped, see ColTeam::stage)
+  const bool skip = a.rel2 < 1e-30f;
   auto kf = col_uslot<EPT>(a.S) ? (skip ? k_forward_col<Q, EPT, SPLIT, true, true> : k_forward_col<Q, EPT, SPLIT, true, false>)
                                 : (skip ? k_forward_col<Q, EPT, SPLIT, false, true> : k_forward_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
@@ -985,7 +986,7 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  const bool skip = a.standin_tau2 == 0.f && !a.stop_residual && a.rel2 < 1e-30f;
+  const bool skip = a.rel2 < 1e-30f;
   auto kf = col_uslot<EPT>(a.S) ? (skip ? k_adjoint_col<Q, EPT, SPLIT, true, true> : k_adjoint_col<Q, EPT, SPLIT, true, false>)
                                 : (skip ? k_adjoint_col<Q, EPT, SPLIT, false, true> : k_adjoint_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
