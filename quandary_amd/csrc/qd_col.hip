@@ -970,7 +970,7 @@ static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
   // (SKIP: stopping tests skipped, see ColTeam::stage)
-  const bool skip = a.rel2 < 1e-30f;
+  const bool skip = a.rel2 < 1e-30f && !a.col_noskip;
   auto kf = col_uslot<EPT>(a.S) ? (skip ? k_forward_col<Q, EPT, SPLIT, true, true> : k_forward_col<Q, EPT, SPLIT, true, false>)
                                 : (skip ? k_forward_col<Q, EPT, SPLIT, false, true> : k_forward_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
@@ -986,7 +986,7 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  const bool skip = a.rel2 < 1e-30f;
+  const bool skip = a.rel2 < 1e-30f && !a.col_noskip;
   auto kf = col_uslot<EPT>(a.S) ? (skip ? k_adjoint_col<Q, EPT, SPLIT, true, true> : k_adjoint_col<Q, EPT, SPLIT, true, false>)
                                 : (skip ? k_adjoint_col<Q, EPT, SPLIT, false, true> : k_adjoint_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);

@@ -838,6 +838,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.inv_abs2 = 1.0 / (a.abstol * a.abstol);
   a.rel2 = (float)(a.reltol * a.reltol);
   a.gmres_poly = h->gmres_poly_degree();
+  a.col_noskip = !h->opts.col_skip;
   a.nslice = 1;
   a.neumann_split = h->neumann_split_on();
   // penalties that need target data are only active when a target has been set

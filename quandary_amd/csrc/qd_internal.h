@@ -119,6 +119,7 @@ struct SweepArgs {
   // (sched = nullptr: one workgroup per initial condition); the adjoint state is carried from slice to slice in `stash`
   int nslice;
   unsigned* sched;
+  int col_noskip;  // lean column kernels: test the stopping rule in every pass (option col_skip = 0)
   unsigned long long sched_ticks;  // wall_clock64 ticks (100 MHz) a slice may wait for its predecessor before the error word is raised
   double* stash;        // [2][nb][2*dim] staging area of the several-elements-per-thread variants (adjoint state / midpoint state
                         // parked in L2/HBM while a linear solve runs, instead of compiler-chosen scratch spills)
@@ -146,6 +147,7 @@ struct TuneOpts {
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
   double standin_tau = 1e-3;  // "standin_tau": error-estimate factor of the stationary iterations that serve gmres requests (0 = plain update-norm rule)
   int no_plain = 0;        // "no_plain": 1 / 2 / 3 = forward / adjoint / both sweeps of the small systems on the general instantiation (A/B)
+  int col_skip = 1;        // "col_skip": the lean column solver skips stopping tests up to two / three passes before the previous sub-step's count (0 = test every pass)
   int col_slices = 0;      // "col_slices": time slices of the lean column sweeps (0 = automatic, 1 = none, k = force k)
   int col_min_n = 33;      // "col_min_n": smallest density-matrix dimension N the lean column kernels take over from the eight-elements-per-thread kernel
   int gmres_poly = 0;      // "gmres_poly": degree of the polynomial preconditioner (0 = tuned, 1 = none)
