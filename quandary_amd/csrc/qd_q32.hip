@@ -49,7 +49,7 @@ __device__ __forceinline__ double rfma(double a, double b, double c) { return fm
 __device__ __forceinline__ float uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ double uniform(double v) { return to_scalar(v); }
 
-template <int Q, int SB, typename R = float>
+template <int Q, int SB, typename R = float, bool HJ = false>
 struct Q32 {
   typedef typename Vec2<R>::type f2;
   static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
@@ -66,6 +66,15 @@ struct Q32 {
   __device__ static constexpr int slotbit(int j, int k) { return (j >> (SB - 1 - k)) & 1; }  // ket digit of oscillator k < SB in slot j
   __device__ static constexpr int slotflip(int j, int k) { return j ^ (1 << (SB - 1 - k)); }
 
+  // dipole-dipole coupling (mastereq.hpp:632-741 for two levels; one element per thread only: SB == 0): byte offsets of the element with
+  // the bra / ket digits of both oscillators of pair (k, l) flipped; coefficients of the current sub-step (prep): J_kl cos / sin
+  // (eta_kl t) where the two digits differ (else 0), the sine with the sign of the l digit (QubitStencil::apply of qd_device.h:
+  // h += J (sin A + cos (B.y, -B.x)), A = +-x_bra +-x_ket, B = x_bra - x_ket)
+  static constexpr int NP = Q * (Q - 1) / 2;
+  static constexpr bool JOK = HJ && SB == 0 && sizeof(R) == 8;
+  unsigned ajb[JOK ? NP : 1], ajk[JOK ? NP : 1];
+  R Jc[JOK ? NP : 1];  // J_kl (wave-uniform)
+  R pjs[JOK ? NP : 1], pjc[JOK ? NP : 1], qjs[JOK ? NP : 1], qjc[JOK ? NP : 1];
   R dw[EPT], dd[EPT];            // Delta = h(I) - h(I'), d = L2 + L1diag (mastereq.hpp:316-433)
   unsigned ab[Q], ak[Q], al[Q];  // byte offsets (slot 0) of the bra / ket (k >= SB) / T1 neighbour of oscillator k
   R l1f[Q], l1t[Q];              // thread part of the T1 off-diagonal coefficient, forward / transposed
@@ -113,6 +122,19 @@ struct Q32 {
       }
       qb[k] = qk[k] = p[k] = q[k] = (R)0;
     }
+    if constexpr (JOK) {
+      int pair = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++)
+#pragma unroll
+        for (int l = k + 1; l < Q; l++, pair++) {
+          const unsigned bm = (1u << brabit(k)) | (1u << brabit(l)), km = (1u << ketbit(k)) | (1u << ketbit(l));
+          ajb[pair] = (tid ^ bm) << ESH;
+          ajk[pair] = (tid ^ km) << ESH;
+          Jc[pair] = uniform((R)S.J[pair]);
+          pjs[pair] = pjc[pair] = qjs[pair] = qjc[pair] = (R)0;
+        }
+    }
   }
 
   // once per sub-step: controls as wave-uniform floats, digit signs folded into q
@@ -124,6 +146,20 @@ struct Q32 {
       q[k] = uniform((R)c.q[k]);
       qb[k] = ((tid >> brabit(k)) & 1) ? -q[k] : q[k];
       if (k >= SB) qk[k] = ((tid >> ketbit(k)) & 1) ? -q[k] : q[k];
+    }
+    if constexpr (JOK) {
+      int pr = 0;
+#pragma unroll
+      for (int k = 0; k < Q; k++)
+#pragma unroll
+        for (int l = k + 1; l < Q; l++, pr++) {
+          const R jc = Jc[pr] * uniform((R)c.cs[pr]), js = Jc[pr] * uniform((R)c.sn[pr]);
+          const unsigned a = (tid >> brabit(k)) & 1, b = (tid >> brabit(l)) & 1, ap = (tid >> ketbit(k)) & 1, bp = (tid >> ketbit(l)) & 1;
+          pjc[pr] = a != b ? jc : (R)0;
+          pjs[pr] = a != b ? (b ? -js : js) : (R)0;
+          qjc[pr] = ap != bp ? jc : (R)0;
+          qjs[pr] = ap != bp ? (bp ? -js : js) : (R)0;
+        }
     }
   }
 
@@ -138,6 +174,7 @@ struct Q32 {
   // and lost: 2.10 ms.
   struct Nb {
     f2 xb[Q], xk[Q], xl[Q];
+    f2 xjb[JOK ? NP : 1], xjk[JOK ? NP : 1];
   };
   template <bool TRANS>
   __device__ __forceinline__ void load(const f2* __restrict__ sx, int j, Nb& n) const {
@@ -147,6 +184,13 @@ struct Q32 {
       if (k >= SB) n.xk[k] = at(sx, ak[k], j);
       const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
       if (slot_ok) n.xl[k] = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+    }
+    if constexpr (JOK) {
+#pragma unroll
+      for (int pr = 0; pr < NP; pr++) {
+        n.xjb[pr] = at(sx, ajb[pr], j);
+        n.xjk[pr] = at(sx, ajk[pr], j);
+      }
     }
   }
   // y = M x (TRANS = false) or M^T x at slot j; see QubitSlotStencil::apply for the derivation
@@ -194,6 +238,14 @@ struct Q32 {
     }
     hr += gr;
     hi += gi;
+    if constexpr (JOK) {
+#pragma unroll
+      for (int pr = 0; pr < NP; pr++) {
+        const f2 xj = n.xjb[pr], xq = n.xjk[pr];
+        hr = rfma(pjs[pr], xj.x, rfma(pjc[pr], xj.y, rfma(qjs[pr], xq.x, rfma(-qjc[pr], xq.y, hr))));
+        hi = rfma(pjs[pr], xj.y, rfma(-pjc[pr], xj.x, rfma(qjs[pr], xq.y, rfma(qjc[pr], xq.x, hi))));
+      }
+    }
     f2 y;
     y.x = rfma(dd[j], xs.x, TRANS ? -hr : hr) + l1r;
     y.y = rfma(dd[j], xs.y, TRANS ? -hi : hi) + l1i;
@@ -261,7 +313,7 @@ __device__ __forceinline__ pk2 bc(const float a) { return (pk2){a, a}; }
 __device__ __forceinline__ pk2 swp(const pk2 a) { return (pk2){a.y, a.x}; }
 
 template <int Q, int SB>
-struct Q32<Q, SB, float> {
+struct Q32<Q, SB, float, false> {
   typedef float R;
   typedef float2 f2;
   static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
@@ -437,9 +489,9 @@ struct Q32<Q, SB, float> {
 #endif  // QD_F32_UNPACKED
 
 // per-workgroup state of the sweeps: LDS exchange buffers, reduction scratch, the Neumann solver (GM: + in-kernel GMRES)
-template <int Q, int SB, typename R, bool GM = false>
+template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
 struct Team32 {
-  typedef Q32<Q, SB, R> ST;
+  typedef Q32<Q, SB, R, HJ> ST;
   typedef typename ST::f2 f2;
   static constexpr int EPT = ST::EPT, NW = ST::NW, DIM = ST::DIM;
   static constexpr bool ONEWAVE = ST::ONEWAVE;
@@ -900,10 +952,10 @@ template <> struct ZTraj<double> {
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int SB, typename R, bool GM = false>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (GM && sizeof(R) == 4 ? 1 : 0))) k_forward_q32(const SweepArgs A) {
+template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> ((GM && sizeof(R) == 4) || HJ ? 1 : 0))) k_forward_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB, R, GM> TM;
+  typedef Team32<Q, SB, R, GM, HJ> TM;
   typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
@@ -924,7 +976,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
   vm_drain();
   for (int s = 0; s < A.nsub; s++) {
     StepC<Q> c;
-    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, HJ);
     tm.st.prep(c);
     const R hf = uniform((R)c.h);
     f2 xs[EPT];
@@ -995,10 +1047,10 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int SB, typename R, bool GM = false>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (GM && sizeof(R) == 4 ? 1 : 0))) k_adjoint_q32(const SweepArgs A) {
+template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> ((GM && sizeof(R) == 4) || HJ ? 1 : 0))) k_adjoint_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB, R, GM> TM;
+  typedef Team32<Q, SB, R, GM, HJ> TM;
   typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   const DevSys& S = A.S;
@@ -1032,7 +1084,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
       }
     }
     StepC<Q> c;
-    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, HJ);
     tm.st.prep(c);
     const R hf = uniform((R)c.h);
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694).  The primal stage z = x + h/2 k of the sub-step (:640-652) was stored by
@@ -1087,11 +1139,11 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
 }
 
 // single operator application (test hook: qd_apply_rhs with QD_PRECISION_F32MIXED; timing loop of the MFMA measurement)
-template <int Q, int SB, typename R>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_apply_q32(const DevSys S, const double* __restrict__ ctlrow, int transpose,
+template <int Q, int SB, typename R, bool HJ = false>
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (HJ ? 1 : 0))) k_apply_q32(const DevSys S, const double* __restrict__ ctlrow, int transpose,
                                                                                          const double* __restrict__ xin, double* __restrict__ yout, int nrep) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Team32<Q, SB, R> TM;
+  typedef Team32<Q, SB, R, false, HJ> TM;
   typedef typename TM::f2 f2;
   constexpr int EPT = TM::EPT, DIM = TM::DIM;
   TM tm;
@@ -1102,7 +1154,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW)) k_
 #pragma unroll
   for (int j = 0; j < EPT; j++) x[j] = to_r2<R>(make_double2(x0[tm.elem(j)], x0[DIM + tm.elem(j)]));
   StepC<Q> c;
-  load_step_k<Q>(ctlrow, c, false);
+  load_step_k<Q>(ctlrow, c, HJ);
   tm.st.prep(c);
   tm.publish(x);
   if (transpose) tm.template apply_all<true>(x, y);
@@ -1253,31 +1305,31 @@ static int q32_slot_bits(int Q, const TuneOpts& o) {
   return o.f32_sb == 2 ? 2 : 0;
 }
 
-template <int Q, int SB, typename R, bool GM = false>
+template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
 static hipError_t go_fwd(const SweepArgs& a, hipStream_t st) {
   constexpr int nt = Q32<Q, SB, R>::NT;
-  const size_t lds = Team32<Q, SB, R, GM>::lds_bytes();
-  auto kf = k_forward_q32<Q, SB, R, GM>;
+  const size_t lds = Team32<Q, SB, R, GM, HJ>::lds_bytes();
+  auto kf = k_forward_q32<Q, SB, R, GM, HJ>;
   hipError_t e = set_lds32(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(a.nb), dim3(nt), lds, st, a);
   return hipGetLastError();
 }
-template <int Q, int SB, typename R, bool GM = false>
+template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
 static hipError_t go_adj(const SweepArgs& a, hipStream_t st) {
   constexpr int nt = Q32<Q, SB, R>::NT;
-  const size_t lds = Team32<Q, SB, R, GM>::lds_bytes();
-  auto kf = k_adjoint_q32<Q, SB, R, GM>;
+  const size_t lds = Team32<Q, SB, R, GM, HJ>::lds_bytes();
+  auto kf = k_adjoint_q32<Q, SB, R, GM, HJ>;
   hipError_t e = set_lds32(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(a.nb), dim3(nt), lds, st, a);
   return hipGetLastError();
 }
-template <int Q, int SB, typename R>
+template <int Q, int SB, typename R, bool HJ = false>
 static hipError_t go_app(const DevSys& S, const double* ctlrow, int tr, const double* x, double* y, int nb, int nrep, hipStream_t st) {
   constexpr int nt = Q32<Q, SB, R>::NT;
-  const size_t lds = Team32<Q, SB, R>::lds_bytes();
-  auto kf = k_apply_q32<Q, SB, R>;
+  const size_t lds = Team32<Q, SB, R, false, HJ>::lds_bytes();
+  auto kf = k_apply_q32<Q, SB, R, HJ>;
   hipError_t e = set_lds32(kf, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kf, dim3(nb), dim3(nt), lds, st, S, ctlrow, tr, x, y, nrep);
@@ -1334,7 +1386,8 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
 // one (the 4-qubit open system: forward sweep 2.70 -> 2.46 ms against the general kernel, gradient evaluation equal; [r5] two waves of
 // two elements instead of four waves of one: 2.55 against 2.25 ms, not kept)
 bool lean64_available(const DevSys& S, const TuneOpts& o) {
-  if (!S.lindblad || S.dense || S.hasJ || (S.Q != 5 && S.Q != 4)) return false;
+  // (dipole-dipole coupling: in the one-element-per-thread layout only, i.e. the 2^4 system [r5])
+  if (!S.lindblad || S.dense || (S.hasJ && S.Q != 4) || (S.Q != 5 && S.Q != 4)) return false;
   for (int k = 0; k < S.Q; k++)
     if (S.n[k] != 2 || S.ness[k] != 2) return false;
   return !o.no_lean64;
@@ -1348,16 +1401,19 @@ static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
   return a.nb <= 256 ? 1 : 2;
 }
 hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+  if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double, false, true>(a, st);
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves (stationary iterations only)
   if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
   return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
 }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+  if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double, false, true>(a, st);
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double>(a, st);
   if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
   return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);
 }
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
+  if (S.Q == 4 && S.hasJ) return go_app<4, 0, double, true>(S, ctlrow, transpose, x, y, nb, 1, st);
   if (S.Q == 4) return go_app<4, 0, double>(S, ctlrow, transpose, x, y, nb, 1, st);
   return go_app<5, 2, double>(S, ctlrow, transpose, x, y, nb, 1, st);
 }

@@ -401,6 +401,32 @@ def test_five_qubit_kernels_with_two_and_four_elements_per_thread(sb, stepper, p
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("stepper,penalties", [("IMR", True), ("IMR4", False), ("IMR8", False)])
+def test_four_qubit_lean_kernel_with_dipole_dipole_coupling(stepper, penalties):
+    """The fp64 2^4 Lindblad kernel (qd_q32.hip, one element per thread) with the Jkl coupling terms in its stencil [r5]: a single operator
+    application and its transpose, objective parts and gradient against the oracle, and against the general kernels (option no_lean64)."""
+    sp = synthetic_spec([2, 2, 2, 2], lindblad=True, jkl=0.004, detuned=True, init="diagonal, 0, 1, 2", ntime=10, stepper=stepper, penalties=penalties)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((3, 2 * h.dim))
+    for tr in (False, True):
+        y = h.apply_rhs(0.037, x, transpose=tr)
+        oy = orc.apply_rhs(0.037, x, transpose=tr)
+        np.testing.assert_allclose(y, oy, rtol=0, atol=1e-13 * np.abs(oy).max())
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    h.set_option("no_lean64", 1)
+    val2, g2 = opt.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-10, abs=1e-13), k
+    np.testing.assert_allclose(g2, g, rtol=1e-8, atol=1e-11 * np.linalg.norm(g))
+    opt.close(); h.close(); orc.close()
+
+
 STAGE_ONLY_CASES = [
     # (system, penalties, the gradient evaluation stores the primal stages only)
     pytest.param(LEANCOL_SHAPES[0].values[0], False, True, id="3x20-no-penalty"),
