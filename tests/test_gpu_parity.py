@@ -401,11 +401,14 @@ def test_five_qubit_kernels_with_two_and_four_elements_per_thread(sb, stepper, p
     opt.close(); h.close(); orc.close()
 
 
-@pytest.mark.parametrize("stepper,penalties", [("IMR", True), ("IMR4", False), ("IMR8", False)])
-def test_four_qubit_lean_kernel_with_dipole_dipole_coupling(stepper, penalties):
+@pytest.mark.parametrize("stepper,penalties,jkl,detuned", [
+    ("IMR", True, "0.004", True), ("IMR4", False, "0.004", True), ("IMR8", False, "0.004", True),
+    # rotating frames apart (eta_kl != 0: the sine terms and their digit signs), a different J on every pair, two pairs uncoupled
+    ("IMR", True, "0.004, 0.0, 0.007, 0.002, 0.0055, 0.0", False), ("IMR4", False, "0.001, 0.006, 0.0, 0.0035, 0.002, 0.008", False)])
+def test_four_qubit_lean_kernel_with_dipole_dipole_coupling(stepper, penalties, jkl, detuned):
     """The fp64 2^4 Lindblad kernel (qd_q32.hip, one element per thread) with the Jkl coupling terms in its stencil [r5]: a single operator
     application and its transpose, objective parts and gradient against the oracle, and against the general kernels (option no_lean64)."""
-    sp = synthetic_spec([2, 2, 2, 2], lindblad=True, jkl=0.004, detuned=True, init="diagonal, 0, 1, 2", ntime=10, stepper=stepper, penalties=penalties)
+    sp = synthetic_spec([2, 2, 2, 2], lindblad=True, jkl=jkl, detuned=detuned, init="diagonal, 0, 1, 2", ntime=10, stepper=stepper, penalties=penalties)
     h, orc = capi.Handle(sp), Oracle(sp)
     rng = np.random.default_rng(7)
     x = rng.standard_normal((3, 2 * h.dim))
