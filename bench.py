@@ -402,6 +402,7 @@ EXTRA = [
     ("q4", "fwd", "gmres", "f64", {}, 10, {"gmres_split": 0}),  # the Krylov kernel (basis in LDS)
     ("q4", "fwd", "neumann", "f32mixed", {}, 20, {}),
     ("q4j", "fwd", "neumann", "f64", {}, 20, {}),  # the dipole-dipole coupling stencil measured
+    ("c5j", "fwd", "neumann", "f64", {}, 2, {}),  # the same on the 2^5 system (lean kernel with the coupling terms [r5])
     ("c5", "fwd", "neumann", "f64", {}, 3, {}),
     ("c5", "fwd", "gmres", "f64", {}, 2, {}),
     ("c5", "fwd", "gmres", "f64", {}, 2, {"gmres_split": 0}),
@@ -475,7 +476,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5 on one GPU, 3 on several)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 1)")
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "q4", "q4j", "c4", "c5", "d4", "l20", "n4444", "n32"],
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "q4", "q4j", "c4", "c5", "c5j", "d4", "l20", "n4444", "n32"],
                     help="default: c4 (the largest single-GPU configuration of BASELINE.json)")
     ap.add_argument("--mode", default=None, choices=["fwd", "grad"], help="default: fwd (several GPUs: the gradient evaluation is timed as well and reported under \"gradient\")")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32mixed"],

@@ -452,6 +452,21 @@ __device__ __forceinline__ void slot_fence() {
   }
 }
 
+// The same with a value pinned at the fence.  A fence orders memory operations only: the arithmetic of a slot may still sink below the
+// LDS reads of the following slots (and all their neighbours are live at once); a pinned result completes the slot's arithmetic first.
+#ifndef QD_NO_PIN
+template <int EPT>
+__device__ __forceinline__ void slot_fence_pin(double2& v) {
+  if (EPT > 1) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+#else
+template <int EPT>
+__device__ __forceinline__ void slot_fence_pin(double2&) { slot_fence<EPT>(); }
+#endif
+
 template <int EPE> __device__ __forceinline__ int at_use(int v);
 __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
@@ -2081,7 +2096,7 @@ struct Team {
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       y[j] = apply_slot<TRANS, HASJ>(S, vecj(j), c, j, x);
-      if ((j % V::FENCE) == V::FENCE - 1) slot_fence<EPE>();
+      if ((j % V::FENCE) == V::FENCE - 1) slot_fence_pin<EPE>(y[j]);
     }
   }
   template <bool TRANS>
@@ -2112,7 +2127,7 @@ struct Team {
       dloc[icslot(j)] += ok(j) ? dx * dx + dy * dy : 0.0;
       y[j] = w;  // registers only; LDS still holds the old iterate for the other threads
       if (V::DBUF && ok(j)) bufp(cur)[lidx(j)] = w;
-      if ((j % V::FENCE) == V::FENCE - 1) slot_fence<EPE>();
+      if ((j % V::FENCE) == V::FENCE - 1) slot_fence_pin<EPE>(y[j]);
     }
   }
 

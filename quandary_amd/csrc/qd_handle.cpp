@@ -795,7 +795,7 @@ bool qd_handle::adjoint_reads_states(int nb, const qd::DevTarget* tgp) const {
   bool leak = false;
   for (int k = 0; k < S.Q; k++)
     if (pen_on && S.ness[k] < S.n[k]) leak = true;
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && !(S.Q == 4 && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && !((S.Q == 4 || S.hasJ) && cfg.gmres);
   if (precision == QD_PRECISION_F32MIXED || lean64) return wj || leak;
   if (use_col(cfg)) return (wj && tgp->objective_type != QD_OBJ_JMEASURE) || leak;
   return true;
@@ -962,7 +962,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
   // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.Q == 4 && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !((S.Q == 4 || S.hasJ) && cfg.gmres);
   if (a.ztraj) ztraj_fmt = precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, opts, stream));
@@ -1188,7 +1188,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
   // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.Q == 4 && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !((S.Q == 4 || S.hasJ) && cfg.gmres);
   if (a.ztraj && ztraj_fmt != (precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0))
     return fail(QD_ERR_STATE, "qd_adjoint: the primal stages were stored by another kernel family (options or precision changed since the forward sweep): repeat the forward sweep");
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));

@@ -72,9 +72,24 @@ struct Q32 {
   // h += J (sin A + cos (B.y, -B.x)), A = +-x_bra +-x_ket, B = x_bra - x_ket)
   static constexpr int NP = Q * (Q - 1) / 2;
   static constexpr bool JOK = HJ && SB == 0 && sizeof(R) == 8;
+  static_assert(!HJ || (sizeof(R) == 8 && SB <= 1), "coupled systems: fp64, one or two elements per thread");
   unsigned ajb[JOK ? NP : 1], ajk[JOK ? NP : 1];
-  R Jc[JOK ? NP : 1];  // J_kl (wave-uniform)
   R pjs[JOK ? NP : 1], pjc[JOK ? NP : 1], qjs[JOK ? NP : 1], qjc[JOK ? NP : 1];
+  // The 2^5 system (two elements per thread, SB == 1: the ket digit of oscillator 0 is the slot) has no room for four coefficients per
+  // pair beside its stencil: there the pair coefficients stay wave-uniform (J cos, J sin), the digit test moves into the ADDRESS - a
+  // neighbour whose pair of digits is equal is read from an element that holds zero (Team32 keeps one behind the exchange vectors at the
+  // same distance from either of them, for either slot) - and the sign of the sine terms, a property of the digit of oscillator l alone,
+  // is applied once per l to the sum over k < l.
+  static constexpr bool JS1 = HJ && SB == 1 && sizeof(R) == 8;
+  static constexpr bool JANY = JOK || JS1;
+  static constexpr unsigned ZOFF = 2u * (unsigned)DIM * (unsigned)sizeof(f2);  // the zero element, relative to the vector being read
+  unsigned jab[JS1 ? NP : 1], jak[JS1 ? NP : 1][JS1 ? EPT : 1];
+  unsigned alm[JS1 ? Q : 1][2];          // T1 neighbour, forward / transposed, or the zero element where the digit condition fails
+  R g1u[JS1 ? Q : 1];                    // gamma_1 coefficient of the T1 neighbour (wave-uniform)
+  R sgb[JS1 ? Q : 1], sgk[JS1 ? Q : 1];  // -1 where the bra / ket digit of oscillator l is 1, else +1
+  R jc[JS1 ? NP : 1], js[JS1 ? NP : 1];  // J cos / J sin (eta_kl t) of the current sub-step (wave-uniform)
+  R Jc[JANY ? NP : 1];                   // J_kl (wave-uniform)
+  __device__ static constexpr int pairof(int k, int l) { return k * Q - k * (k + 1) / 2 + (l - k - 1); }
   R dw[EPT], dd[EPT];            // Delta = h(I) - h(I'), d = L2 + L1diag (mastereq.hpp:316-433)
   unsigned ab[Q], ak[Q], al[Q];  // byte offsets (slot 0) of the bra / ket (k >= SB) / T1 neighbour of oscillator k
   R l1f[Q], l1t[Q];              // thread part of the T1 off-diagonal coefficient, forward / transposed
@@ -135,6 +150,39 @@ struct Q32 {
           pjs[pair] = pjc[pair] = qjs[pair] = qjc[pair] = (R)0;
         }
     }
+    if constexpr (JS1) {
+#pragma unroll
+      for (int l = 0; l < Q; l++) {
+        const unsigned bb = 1u << brabit(l), kb = 1u << ketbit(l);
+        const bool bra0 = (tid & bb) == 0, ket0 = l < SB || (tid & kb) == 0, ket1 = l < SB || (tid & kb) != 0;
+        sgb[l] = bra0 ? (R)1 : (R)-1;
+        sgk[l] = (l >= SB && (tid & kb)) ? (R)-1 : (R)1;
+        // (k < SB: the ket digit is the slot - the slot condition is a compile-time one in load(), the neighbour sits in the other slot)
+        alm[l][0] = (bra0 && ket0) ? al[l] : ZOFF;
+        alm[l][1] = (!bra0 && ket1) ? al[l] : ZOFF;
+        g1u[l] = uniform((R)S.g1off[l]);
+      }
+#pragma unroll
+      for (int k = 0; k < Q; k++)
+#pragma unroll
+        for (int l = k + 1; l < Q; l++) {
+          const int pr = pairof(k, l);
+          const unsigned bm = (1u << brabit(k)) | (1u << brabit(l));
+          const unsigned a = (tid >> brabit(k)) & 1, b = (tid >> brabit(l)) & 1, bp = (tid >> ketbit(l)) & 1;
+          jab[pr] = a != b ? (tid ^ bm) << ESH : ZOFF;
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            if (k >= SB) {
+              const unsigned ap = (tid >> ketbit(k)) & 1, km = (1u << ketbit(k)) | (1u << ketbit(l));
+              jak[pr][j] = ap != bp ? (tid ^ km) << ESH : ZOFF;
+            } else {  // the ket digit of oscillator k is the slot: the neighbour sits in the other slot (read with that slot's offset)
+              jak[pr][j] = (unsigned)slotbit(j, k) != bp ? (tid ^ (1u << ketbit(l))) << ESH : ZOFF;
+            }
+          }
+          Jc[pr] = uniform((R)S.J[pr]);
+          jc[pr] = js[pr] = (R)0;
+        }
+    }
   }
 
   // once per sub-step: controls as wave-uniform floats, digit signs folded into q
@@ -144,8 +192,10 @@ struct Q32 {
     for (int k = 0; k < Q; k++) {
       p[k] = uniform((R)c.p[k]);
       q[k] = uniform((R)c.q[k]);
-      qb[k] = ((tid >> brabit(k)) & 1) ? -q[k] : q[k];
-      if (k >= SB) qk[k] = ((tid >> ketbit(k)) & 1) ? -q[k] : q[k];
+      if constexpr (!JS1) {
+        qb[k] = ((tid >> brabit(k)) & 1) ? -q[k] : q[k];
+        if (k >= SB) qk[k] = ((tid >> ketbit(k)) & 1) ? -q[k] : q[k];
+      }
     }
     if constexpr (JOK) {
       int pr = 0;
@@ -160,6 +210,13 @@ struct Q32 {
           qjc[pr] = ap != bp ? jc : (R)0;
           qjs[pr] = ap != bp ? (bp ? -js : js) : (R)0;
         }
+    }
+    if constexpr (JS1) {
+#pragma unroll
+      for (int pr = 0; pr < NP; pr++) {
+        jc[pr] = uniform(Jc[pr] * (R)c.cs[pr]);
+        js[pr] = uniform(Jc[pr] * (R)c.sn[pr]);
+      }
     }
   }
 
@@ -183,7 +240,7 @@ struct Q32 {
       n.xb[k] = at(sx, ab[k], j);
       if (k >= SB) n.xk[k] = at(sx, ak[k], j);
       const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
-      if (slot_ok) n.xl[k] = at(sx, al[k], k < SB ? slotflip(j, k) : j);
+      if (slot_ok) n.xl[k] = at(sx, JS1 ? alm[JS1 ? k : 0][TRANS ? 1 : 0] : al[k], k < SB ? slotflip(j, k) : j);
     }
     if constexpr (JOK) {
 #pragma unroll
@@ -198,10 +255,10 @@ struct Q32 {
   __device__ __forceinline__ f2 apply(const f2* __restrict__ sx, int j, const f2 (&xall)[EPT]) const {
     Nb n;
     load<TRANS>(sx, j, n);
-    return apply_nb<TRANS>(j, xall, n);
+    return apply_nb<TRANS>(j, xall, n, sx);
   }
   template <bool TRANS>
-  __device__ __forceinline__ f2 apply_nb(int j, const f2 (&xall)[EPT], const Nb& n) const {
+  __device__ __forceinline__ f2 apply_nb(int j, const f2 (&xall)[EPT], const Nb& n, const f2* __restrict__ sx) const {
     const f2 xs = xall[j];
     R hr = dw[j] * xs.y, hi = -dw[j] * xs.x, gr = 0, gi = 0;
     R l1r = 0, l1i = 0;
@@ -219,10 +276,17 @@ struct Q32 {
       }
       R& ar = (k & 1) ? gr : hr;
       R& ai = (k & 1) ? gi : hi;
-      ar = rfma(qb[k], xb.x, ar);
-      ai = rfma(qb[k], xb.y, ai);
-      ar = rfma(sqk, xk.x, ar);
-      ai = rfma(sqk, xk.y, ai);
+      if constexpr (JS1) {  // digit signs from the +-1 pairs the coupling terms keep anyway: q_k (s_b x_b + s_k x_k)
+        const R sk = k < SB ? (slotbit(j, k) ? (R)-1 : (R)1) : sgk[k];
+        const R gx = rfma(sgb[k], xb.x, sk * xk.x), gy = rfma(sgb[k], xb.y, sk * xk.y);
+        ar = rfma(q[k], gx, ar);
+        ai = rfma(q[k], gy, ai);
+      } else {
+        ar = rfma(qb[k], xb.x, ar);
+        ai = rfma(qb[k], xb.y, ai);
+        ar = rfma(sqk, xk.x, ar);
+        ai = rfma(sqk, xk.y, ai);
+      }
       ar = rfma(p[k], xb.y, ar);
       ai = rfma(-p[k], xb.x, ai);
       ar = rfma(-p[k], xk.y, ar);
@@ -231,7 +295,7 @@ struct Q32 {
       const bool slot_ok = k >= SB || (TRANS ? slotbit(j, k) == 1 : slotbit(j, k) == 0);
       if (slot_ok) {
         const f2 xl = n.xl[k];
-        const R l1 = TRANS ? l1t[k] : l1f[k];
+        const R l1 = JS1 ? g1u[JS1 ? k : 0] : TRANS ? l1t[k] : l1f[k];
         l1r = rfma(l1, xl.x, l1r);
         l1i = rfma(l1, xl.y, l1i);
       }
@@ -244,6 +308,52 @@ struct Q32 {
         const f2 xj = n.xjb[pr], xq = n.xjk[pr];
         hr = rfma(pjs[pr], xj.x, rfma(pjc[pr], xj.y, rfma(qjs[pr], xq.x, rfma(-qjc[pr], xq.y, hr))));
         hi = rfma(pjs[pr], xj.y, rfma(-pjc[pr], xj.x, rfma(qjs[pr], xq.y, rfma(qjc[pr], xq.x, hi))));
+      }
+    }
+    if constexpr (JS1) {
+      // Neighbours read here, one oscillator's pairs (k < l) at a time, one group ahead of the arithmetic: 20 more values in flight do not
+      // fit.  A fence alone orders the LDS reads but lets the arithmetic sink below the next group's reads (all neighbours live at once:
+      // 20 registers per pair, 132 spilt, slower than the general kernel); pinning the sums at the fence completes a group before the
+      // group after the next is read.
+      f2 cj[Q - 1], cq[Q - 1];
+      cj[0] = at(sx, jab[pairof(0, 1)], j);
+      cq[0] = at(sx, jak[pairof(0, 1)][j], 0 < SB ? slotflip(j, 0) : j);
+      asm volatile("" : "+v"(hr), "+v"(hi), "+v"(l1r), "+v"(l1i)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int l = 1; l < Q; l++) {
+        f2 nj[Q - 1], nq[Q - 1];
+        if (l + 1 < Q) {
+#pragma unroll
+          for (int k = 0; k < l + 1; k++) {
+            const int pn = pairof(k, l + 1 < Q ? l + 1 : l);
+            nj[k] = at(sx, jab[pn], j);
+            nq[k] = at(sx, jak[pn][j], k < SB ? slotflip(j, k) : j);
+          }
+        }
+        R sbx = 0, sby = 0, skx = 0, sky = 0;
+#pragma unroll
+        for (int k = 0; k < l; k++) {
+          const int pr = pairof(k, l);
+          const f2 xj = cj[k], xq = cq[k];
+          sbx = rfma(js[pr], xj.x, sbx);
+          sby = rfma(js[pr], xj.y, sby);
+          skx = rfma(js[pr], xq.x, skx);
+          sky = rfma(js[pr], xq.y, sky);
+          hr = rfma(jc[pr], xj.y, rfma(-jc[pr], xq.y, hr));
+          hi = rfma(-jc[pr], xj.x, rfma(jc[pr], xq.x, hi));
+        }
+        hr = rfma(sgb[l], sbx, rfma(sgk[l], skx, hr));
+        hi = rfma(sgb[l], sby, rfma(sgk[l], sky, hi));
+        asm volatile("" : "+v"(hr), "+v"(hi)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (l + 1 < Q) {
+#pragma unroll
+          for (int k = 0; k < l + 1; k++) {
+            cj[k] = nj[k];
+            cq[k] = nq[k];
+          }
+        }
       }
     }
     f2 y;
@@ -319,6 +429,7 @@ struct Q32<Q, SB, float, false> {
   static constexpr int EPT = 1 << SB, TB = 2 * Q - SB, NT = 1 << TB, NW = NT / 64, DIM = 1 << (2 * Q);
   static constexpr bool ONEWAVE = NT == 64;
   static constexpr int BPC = 4;
+  static constexpr bool JS1 = false;  // (no coupled systems in fp32-mixed)
   static constexpr int MINW = (Q == 5 && SB == 1) ? 2 : (BPC * NT / 256 > 0 ? BPC * NT / 256 : 1);
   static constexpr unsigned EB = sizeof(f2), ESH = 3;
   static constexpr unsigned SLOT_BYTES = EB << TB;
@@ -506,15 +617,25 @@ struct Team32 {
 
   __device__ __forceinline__ void init(const DevSys& S, unsigned char* smem, bool trans = false) {
     buf = reinterpret_cast<f2*>(smem);
-    red = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM);
-    acc = reinterpret_cast<double2*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW);
-    ksc = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0));
+    red = reinterpret_cast<double*>(smem + 2 * sizeof(f2) * DIM + ZPAD);
+    acc = reinterpret_cast<double2*>(smem + acc_off());
+    ksc = reinterpret_cast<double*>(smem + acc_off() + (PARK ? sizeof(double2) * DIM : 0));
     cur = 0;
     redslot = 0;
+    if constexpr (ST::JS1) {  // the zero elements (see Q32): at 2 D and 3 D for slot 0, half a vector further for slot 1 (D = bytes of a vector)
+      if (threadIdx.x < 4) *reinterpret_cast<f2*>(smem + (4 + threadIdx.x) * (sizeof(f2) * DIM / 2)) = f2{0, 0};
+    }
     st.init(S, trans);  // (the packed fp32 stencil keeps the T1 coefficients of one direction only)
   }
+  // coupled 2^5 kernels: zero elements at 2 D, 2.5 D, 3 D, 3.5 D behind the two vectors; the reduction scratch sits between the first two,
+  // the parked accumulators behind the last
+  static constexpr size_t ZPAD = ST::JS1 ? 16 : 0;
+  static constexpr size_t acc_off() {
+    return ST::JS1 ? 7 * (sizeof(f2) * DIM / 2) + 16 : 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW;
+  }
+  static_assert(!ST::JS1 || (ZPAD + 2 * sizeof(double) * NRED * NW <= sizeof(f2) * DIM / 2 && !GM && EPT == 2), "layout of the coupled 2^5 kernels");
   static size_t lds_bytes() {
-    return 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW + (PARK ? sizeof(double2) * DIM : 0) + (GM ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
+    return acc_off() + (PARK ? sizeof(double2) * DIM : 0) + (GM ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
   }
   __device__ __forceinline__ int elem(int j) const { return (int)(threadIdx.x | ((unsigned)j << ST::TB)); }
   __device__ __forceinline__ const f2* vec() const { return buf + cur * DIM; }
@@ -1386,8 +1507,8 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
 // one (the 4-qubit open system: forward sweep 2.70 -> 2.46 ms against the general kernel, gradient evaluation equal; [r5] two waves of
 // two elements instead of four waves of one: 2.55 against 2.25 ms, not kept)
 bool lean64_available(const DevSys& S, const TuneOpts& o) {
-  // (dipole-dipole coupling: in the one-element-per-thread layout only, i.e. the 2^4 system [r5])
-  if (!S.lindblad || S.dense || (S.hasJ && S.Q != 4) || (S.Q != 5 && S.Q != 4)) return false;
+  // (dipole-dipole coupling [r5]: instantiations of their own - 2^4 one element per thread, 2^5 two; stationary iterations only)
+  if (!S.lindblad || S.dense || (S.Q != 5 && S.Q != 4)) return false;
   for (int k = 0; k < S.Q; k++)
     if (S.n[k] != 2 || S.ness[k] != 2) return false;
   return !o.no_lean64;
@@ -1402,18 +1523,21 @@ static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
 }
 hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double, false, true>(a, st);
+  if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<5, 1, double, false, true>(a, st);
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves (stationary iterations only)
   if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
   return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
 }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double, false, true>(a, st);
+  if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<5, 1, double, false, true>(a, st);
   if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double>(a, st);
   if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
   return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);
 }
 hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, hipStream_t st) {
   if (S.Q == 4 && S.hasJ) return go_app<4, 0, double, true>(S, ctlrow, transpose, x, y, nb, 1, st);
+  if (S.Q == 5 && S.hasJ) return go_app<5, 1, double, true>(S, ctlrow, transpose, x, y, nb, 1, st);
   if (S.Q == 4) return go_app<4, 0, double>(S, ctlrow, transpose, x, y, nb, 1, st);
   return go_app<5, 2, double>(S, ctlrow, transpose, x, y, nb, 1, st);
 }

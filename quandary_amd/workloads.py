@@ -122,6 +122,9 @@ WORKLOADS = {
     "q4j": ("4-qubit open system with dipole-dipole coupling (2^4 Lindblad, J_kl = 0.001 GHz on all pairs, rotating frames at 4.1 GHz: detuned), 256 basis initial conditions, ntime 1000",
             lambda mode: _qubits(4, True, 1000, 0.01, 30, runtype=mode).replace("Jkl = 0.0", "Jkl = 0.001").replace(
                 "rotfreq = 4.1000,4.2000,4.3000,4.4000", "rotfreq = 4.1,4.1,4.1,4.1")),
+    # the same for five qubits, the rotating frames 0.1 GHz apart (eta_kl != 0: cosine and sine terms) [r5]
+    "c5j": ("5-qubit open system with dipole-dipole coupling (2^5 Lindblad, J_kl = 0.001 GHz on all ten pairs, rotating frames 0.1 GHz apart), 1024 basis initial conditions, ntime 1000",
+            lambda mode: _qubits(5, True, 1000, 0.01, 30, runtype=mode).replace("Jkl = 0.0", "Jkl = 0.001")),
     # the reference's own performance workloads (tests/performance/test_cases.json)
     "n4444": ("reference performance case nlevels_4_4_4_4: 4^4 Schroedinger (dim 256), J_kl on all pairs, one pure state, ntime 500, GMRES",
               lambda mode: _perf([4, 4, 4, 4], 500, runtype=mode)),

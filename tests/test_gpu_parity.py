@@ -430,6 +430,37 @@ def test_four_qubit_lean_kernel_with_dipole_dipole_coupling(stepper, penalties, 
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("stepper,penalties,jkl,detuned", [
+    ("IMR", True, "0.004", True), ("IMR4", False, "0.004", False),
+    ("IMR", False, "0.004, 0.0, 0.007, 0.002, 0.0055, 0.0, 0.003, 0.0065, 0.001, 0.0045", False),
+    ("IMR8", True, "0.0, 0.006, 0.0, 0.0035, 0.002, 0.008, 0.0, 0.0015, 0.005, 0.0025", False)])
+def test_five_qubit_lean_kernel_with_dipole_dipole_coupling(stepper, penalties, jkl, detuned):
+    """The fp64 2^5 Lindblad kernel (qd_q32.hip, two elements per thread: the ket digit of oscillator 0 is the slot) with the Jkl coupling
+    terms [r5] - digit tests folded into the neighbour addresses (zero element), wave-uniform pair coefficients, the sine terms' digit signs
+    applied per oscillator: a single operator application and its transpose, objective parts and gradient against the oracle, and against
+    the general kernels (option no_lean64).  Rotating frames apart (eta_kl != 0) and a different J on every pair in the last two cases."""
+    sp = synthetic_spec([2, 2, 2, 2, 2], lindblad=True, jkl=jkl, detuned=detuned, init="diagonal, 0, 1, 2", ntime=10, stepper=stepper, penalties=penalties)
+    h, orc = capi.Handle(sp), Oracle(sp)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((3, 2 * h.dim))
+    for tr in (False, True):
+        y = h.apply_rhs(0.037, x, transpose=tr)
+        oy = orc.apply_rhs(0.037, x, transpose=tr)
+        np.testing.assert_allclose(y, oy, rtol=0, atol=1e-13 * np.abs(oy).max())
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    oval, og = orc.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(oval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - og) <= 1e-8 * np.linalg.norm(og) + SOLVER_NOISE_ABS
+    h.set_option("no_lean64", 1)
+    val2, g2 = opt.evalGradF(sp.params0)
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-10, abs=1e-13), k
+    np.testing.assert_allclose(g2, g, rtol=1e-8, atol=1e-11 * np.linalg.norm(g))
+    opt.close(); h.close(); orc.close()
+
+
 STAGE_ONLY_CASES = [
     # (system, penalties, the gradient evaluation stores the primal stages only)
     pytest.param(LEANCOL_SHAPES[0].values[0], False, True, id="3x20-no-penalty"),
