@@ -12,6 +12,8 @@ $C r5_c3_grad --workload c3 --mode grad --steps 20 --warmup 2 $B > /dev/null 2>&
 $C r5_c1_grad --workload c1 --mode grad --steps 20 --warmup 2 $B > /dev/null 2>&1
 $C r5_c2_fwd --workload c2 --steps 20 --warmup 2 $B > /dev/null 2>&1
 $C r5_q4_fwd --workload q4 --steps 20 --warmup 2 $B > /dev/null 2>&1
+$C r5_q4j_fwd --workload q4j --steps 20 --warmup 2 $B > /dev/null 2>&1                       # the coupled systems on the lean slot kernels
+$C r5_c5j_fwd --workload c5j --steps 3 --warmup 1 $B > /dev/null 2>&1
 $C r5_c5_fwd --workload c5 --steps 5 --warmup 2 $B > /dev/null 2>&1
 $C r5_c5_grad --workload c5 --mode grad --steps 3 --warmup 1 $B > /dev/null 2>&1
 $C r5_c5_f32_fwd --workload c5 --dtype f32mixed --steps 5 --warmup 2 $B > /dev/null 2>&1
