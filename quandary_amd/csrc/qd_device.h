@@ -2393,6 +2393,10 @@ struct Team {
     const int MRE = poly > 1 ? (GMRES_MR_G - 2) / 2 : GMRES_MR_G;         // restart length
     double2* __restrict__ Zg = Vg + (size_t)(MRE + 1) * dim;               // z_j = P v_j (poly > 1)
     const double2* __restrict__ Sg = poly > 1 ? Zg : Vg;                   // the vectors the solution is a combination of
+    // The right-hand side is parked in the one basis slot neither mode uses (v_k, z_k stop at GMRES_MR_G - 1) and v_0 is stored like every
+    // other basis vector [r5]: b then is not live through the operator applications - one 8-element array (32 registers) less in a kernel
+    // that spills; it is read back for the residual of a restart only.
+    double2* __restrict__ Bg = Vg + (size_t)GMRES_MR_G * dim;
     double2 yy[EPT], r[EPT], v[EPT], w[EPT];
     int napp = 0;
     // t2 <- M z, reading z from the published vector
@@ -2405,6 +2409,7 @@ struct Team {
     for (int j = 0; j < EPT; j++) {
       yy[j] = make_double2(0.0, 0.0);
       r[j] = b[j];
+      if (ok(j)) Bg[at_use<EPE>(st.it[j])] = b[j];
     }
     int its = 0;
     bool have_total = false;  // a restart has parked the accumulated solution in basis slot GMRES_MR_G + 1
@@ -2425,7 +2430,7 @@ struct Team {
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
         v[j] = make_double2(r[j].x * ibeta, r[j].y * ibeta);
-        if (cycle > 0 && ok(j)) Vg[at_use<EPE>(st.it[j])] = v[j];  // (first cycle: v_0 = b / beta is recomputed from registers)
+        if (ok(j)) Vg[at_use<EPE>(st.it[j])] = v[j];
       }
       publish(v);
       double gcur = beta;
@@ -2458,12 +2463,9 @@ struct Team {
         // the orthogonalised vector is NOT taken from ||w||^2 - sum h_k^2: classical Gram-Schmidt loses orthogonality as
         // the residual falls towards 1e-10 and that identity then misjudges h_{j+1,j} - measured: the recurrence residual
         // stops tracking the true one and every solve runs to maxiter.)
-        // Positions of a block: 0 = v_jj (still in registers), 1 = v_0 (first cycle: b / beta, recomputed from registers), then
+        // Positions of a block: 0 = v_jj (still in registers), 1 = v_0, then
         // v_1 .. v_{jj-1} read back from the basis in one branch-free run of loads.
-        auto v0elem = [&](int j) {
-          if (cycle == 0) return make_double2(b[j].x * ibeta, b[j].y * ibeta);
-          return Vg[at_use<EPE>(st.it[j])];
-        };
+        auto v0elem = [&](int j) { return Vg[at_use<EPE>(st.it[j])]; };
         for (int p0 = 0; p0 <= jj; p0 += 4) {
           double h4[4] = {0.0, 0.0, 0.0, 0.0};
           const int np = min(4, jj + 1 - p0);
@@ -2569,10 +2571,9 @@ struct Team {
       for (int j = 0; j < EPT; j++) yy[j] = make_double2(0.0, 0.0);
       if (jj >= 1) {
         const double f = yk[0];
-        const bool fromb = poly == 1 && cycle == 0;
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
-          const double2 vk = fromb ? make_double2(b[j].x * ibeta, b[j].y * ibeta) : Sg[at_use<EPE>(st.it[j])];
+          const double2 vk = Sg[at_use<EPE>(st.it[j])];
           yy[j].x += f * vk.x;
           yy[j].y += f * vk.y;
         }
@@ -2605,7 +2606,10 @@ struct Team {
       else apply_sweep<TRANS, true>(A.S, c, yy, t3);
       napp++;
 #pragma unroll
-      for (int j = 0; j < EPT; j++) r[j] = make_double2(b[j].x - (yy[j].x - alpha * t3[j].x), b[j].y - (yy[j].y - alpha * t3[j].y));
+      for (int j = 0; j < EPT; j++) {
+        const double2 bj = Bg[at_use<EPE>(st.it[j])];
+        r[j] = make_double2(bj.x - (yy[j].x - alpha * t3[j].x), bj.y - (yy[j].y - alpha * t3[j].y));
+      }
       team_sync<V::ONEWAVE>();  // every thread has read the scalars of this cycle before the next one overwrites them
     }
 #pragma unroll
