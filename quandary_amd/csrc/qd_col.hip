@@ -24,6 +24,13 @@
 namespace qd {
 
 constexpr unsigned COLB = 1024;  // bytes per padded column: 64 rows x 16 B
+// Krylov solver of these kernels (ColTeam::kry_*): restart length.  Basis V[0 .. MR], preconditioned basis Z[0 .. MR - 1], the parked
+// right-hand side, the parked total of a restart and the parked state: 2 MR + 4 = 32 vectors = the GMRES_MR_G + 2 slots per workgroup of
+// SweepArgs::kry (krylov_doubles)
+constexpr int KRY_MR = 14;
+constexpr int KRY_NSC = gmres_nsc(KRY_MR);
+constexpr size_t KRY_VEC = 64 * 64;  // double2 per scratch vector of a workgroup: the padded column layout (64 rows x at most 64 columns)
+static_assert(2 * KRY_MR + 4 <= GMRES_MR_G + 2, "slots of the global-memory Krylov buffer");
 
 // Largest workgroup of the EPT-columns-per-wave kernels = their register budget: 16 waves x 128, 12 x 168 (five columns per wave
 // cover N <= 60), 11 x 168, 8 x 256 VGPRs
@@ -333,6 +340,32 @@ struct ColTeam {
     block_sum<NV, false>(v, red + redslot * NRED * nw);
     redslot ^= 1;
   }
+  // Workgroup sum of NV <= 4 values for the Krylov solver [r6]: the wave level is a reduce-scatter (row r of 16 lanes ends up with the
+  // total of value r: ~30 vector instructions for three values where three wave_sum()s are ~70), and behind the barrier ONE LDS read per
+  // lane - lane 16 i + w fetches the partial sum of value i of wave w - and four DPP adds inside the rows replace the nw x NV broadcast
+  // reads and dependent adds of block_sum (36 + 36 for three values on twelve waves).  Every thread returns the same bits.
+  template <int NV>
+  __device__ __forceinline__ void sum_rows(double (&v)[NV]) {
+    static_assert(NV <= 4, "one value per row of 16 lanes");
+    double* r = red + redslot * NRED * nw;  // (NRED nw >= 64 doubles from four waves on)
+    redslot ^= 1;
+    double o[1];
+    wave_reduce_scatter<NV>(v, o);
+    const int lane = (int)(threadIdx.x & 63);
+    if ((lane & 15) == 0) {
+      const int g = wave_scatter_index<NV>(lane >> 4, 0);
+      if (g >= 0) r[g * 16 + (int)(threadIdx.x >> 6)] = o[0];
+    }
+    __syncthreads();
+    double t = ((lane >> 4) < NV && (lane & 15) < nw) ? r[lane] : 0.0;
+    t += dpp_mov<0xB1>(t);
+    t += dpp_mov<0x4E>(t);
+    t += dpp_mov<0x124>(t);
+    t += dpp_mov<0x128>(t);
+    const int lo = __double2loint(t), hi = __double2hiint(t);
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * i), __builtin_amdgcn_readlane(lo, 16 * i));
+  }
   // Workgroup sum in two halves, for values only a few threads need (the 2Q gradient coefficients of a step, written by threads 0 .. 2Q - 1):
   // every wave leaves its partial sums in LDS (wave_reduce_scatter: the total of value g ends up in one row of 16 lanes, 21 vector
   // instructions for the four values of a two-oscillator system where four wave_sum()s are ~120); AFTER a later barrier of the caller (the
@@ -545,6 +578,375 @@ struct ColTeam {
     if (SKIP) lastn = iter + 1;
     return iter + 1;
   }
+
+  // ---------------------------------------------------------------------------------------------
+  // Krylov solver of the lean column kernels [r6]: linearsolver_type = gmres (KSPGMRES, src/timestepper.cpp:541-550, call sites :602,
+  // :652, :674) where the stationary iteration does not stand in for it (option gmres_split = 0, or its gate has failed).
+  //
+  // GMRES on (I - alpha M) y = b, right-preconditioned with the polynomial of the diagonal-split iteration:
+  //   I - alpha M = (I - alpha D) - alpha C,  P = (I - alpha D)^-1,  R_p = sum_{i<p} (P alpha C)^i P,  (I - alpha M) R_p = I - (alpha C P)^p.
+  // The residual of the preconditioned system IS b - (I - alpha M) y, so the reference's stopping rule - residual <= max(rtol ||b||,
+  // abstol) - is unchanged.  z = R_p v is Horner's rule z <- P (v + alpha C z) from z = P v: the SAME pass as the stationary iteration
+  // (one NODIAG application, the iterate and the right-hand side in registers, nothing else live), without its reductions.
+  //
+  // Hot path (one Krylov vector suffices: the host tunes p for that, qd_handle::forward_finish): p passes, then ONE full application
+  // w = (I - alpha M) z fused with the three dot products <b,b>, <r,b>, <r,r> of r = b - w in one workgroup reduction.  With v_0 = b / beta:
+  //   h_00 = <w, v_0> = 1 - a,  a = <r,b> / <b,b>;   h_10^2 = ||w - h_00 v_0||^2 = <r,r> / <b,b> - a^2   (from r, not from ||w||^2 - h_00^2,
+  //   which cancels to nothing at residuals of 1e-10);   y = h_00 / (h_00^2 + h_10^2) z,   residual = beta h_10 / sqrt(h_00^2 + h_10^2).
+  // No basis vector is written, b never leaves its registers (adjoint) / is parked once per step (forward, stage form below).
+  // Slow path (residual above the tolerance after one vector): the solve starts over in kry_generic - classical Gram-Schmidt, Givens
+  // rotations, restart KRY_MR, every vector (basis V, preconditioned basis Z = R_p V, the parked right-hand side) in this WORKGROUP's 32
+  // slots of SweepArgs::kry, each thread touching its own elements only.  Rare by construction of p; its cost is its own.
+  // ---------------------------------------------------------------------------------------------
+  double2* wg;  // this workgroup's scratch vectors in global memory, at this thread's element of slot 0: vector s, slot j = wg[s KRY_VEC + 64 j]
+  // (the vectors keep the PADDED column layout of the exchange buffers - 64 rows per column: idle lanes and idle slots park their zeros
+  //  like everybody else, no guard, no exec mask inside a slot loop, and one base address with immediate offsets per vector)
+  double* ksc;  // Hessenberg scalars of kry_generic (LDS, behind the column table)
+  // Forward hot path: b = M x is formed by the first pass and used by the last one for <b,b> and <r,b> only - quantities that enter
+  // the solution as 1 - <r,b>/<b,b> with <r,b>/<b,b> ~ 1e-10: an fp32 copy serves.  Five columns per wave (N <= 60) leave room for it in
+  // LDS (8 B per element in the padded layout, 30 KB); eight columns per wave (N = 61 .. 64) park b in slot SB, fetched two slots ahead.
+  static constexpr bool BLDS = EPT == 5;
+  unsigned b32;  // LDS byte address of this thread's element of slot 0 of the fp32 copy
+  static __host__ __device__ size_t kry_lds_extra(int N) { return sizeof(double) * KRY_NSC + (BLDS ? 512u * (size_t)ST::ncols(N) : 0u); }
+  static constexpr int SV = 0, SZ = KRY_MR + 1, SB = 2 * KRY_MR + 1, SY = 2 * KRY_MR + 2, SX = 2 * KRY_MR + 3;
+
+  __device__ __forceinline__ void init_kry(const SweepArgs& A) {
+    wg = reinterpret_cast<double2*>(A.kry) + (size_t)blockIdx.x * (GMRES_MR_G + 2) * KRY_VEC + (size_t)st.col0 * 64 + (threadIdx.x & 63);
+    ksc = reinterpret_cast<double*>(st.smem + ST::tab_off(A.S.N) + 48u * (unsigned)ST::ncols(A.S.N));
+    b32 = ST::tab_off(A.S.N) + 48u * (unsigned)ST::ncols(A.S.N) + (unsigned)sizeof(double) * KRY_NSC + (unsigned)st.col0 * 512u + (threadIdx.x & 63) * 8u;
+  }
+  __device__ __forceinline__ double2* vec(int s) const { return wg + (size_t)s * KRY_VEC; }
+  __device__ __forceinline__ void vstore(int s, const double2 (&v)[EPT]) const {
+    double2* p = vec(s);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) p[64 * j] = v[j];
+  }
+  __device__ __forceinline__ void vload(int s, double2 (&v)[EPT]) const {
+    const double2* p = vec(s);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) v[j] = p[64 * j];
+  }
+  __device__ __forceinline__ double2 pmul(int j, const double2 w) const {
+    return make_double2(fma(pr[SPLIT ? j : 0], w.x, -pi[SPLIT ? j : 0] * w.y), fma(pr[SPLIT ? j : 0], w.y, pi[SPLIT ? j : 0] * w.x));
+  }
+  // one pass of Horner's rule: y <- P (rhs + alpha C y); the published vector is y on entry and on exit
+  template <bool TRANS>
+  __device__ __forceinline__ void kry_pass(const StepC<Q>& c, double alpha, const double2 (&rhs)[EPT], double2 (&y)[EPT]) {
+    const unsigned wa = st.tb + (unsigned)st.dlt;
+    double2 prev = y[0];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const double2 own = y[j];
+      const double2 t = st.template apply<TRANS, true>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
+      const double2 w = pmul(j, make_double2(fma(alpha, t.x, rhs[j].x), fma(alpha, t.y, rhs[j].y)));
+      prev = own;
+      y[j] = w;
+      st.st(wa + (unsigned)j * COLB, w);
+      slot_fence<EPT>();
+    }
+    __syncthreads();
+    st.flip();
+  }
+  // h_00 / (h_00^2 + h_10^2) of the one-vector solve, or a negative value where its residual is above the tolerance
+  __device__ __forceinline__ double kry_one_vector(const SweepArgs& A, const double (&d)[3]) const {
+    const double bb = d[0], ab = d[1], ss = d[2];
+    const double ttol2 = fmax(A.reltol * A.reltol * bb, A.abstol * A.abstol);
+    if (bb <= ttol2) return 0.0;  // ||b|| <= tolerance: KSP returns the zero initial guess
+    const double ibb = 1.0 / bb, a = ab * ibb, h00 = 1.0 - a, h10sq = fmax(fma(-a, a, ss * ibb), 0.0), den = fma(h00, h00, h10sq);
+    const bool conv = bb * h10sq <= ttol2 * den || A.maxiter <= 1;
+    return conv ? h00 / den : -1.0;
+  }
+
+  // the generic path: on entry the right-hand side is in v AND in slot SB; on exit y = solution, v = right-hand side
+  template <bool TRANS>
+  __device__ __forceinline__ int kry_generic(const SweepArgs& A, const StepC<Q>& c, double alpha, double2 (&v)[EPT], double2 (&y)[EPT]) {
+    const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
+    double* hc = ksc;                  // [MR + 2] current Hessenberg column
+    double* cs = hc + (KRY_MR + 2);    // [MR]
+    double* sn = cs + KRY_MR;          // [MR]
+    double* g = sn + KRY_MR;           // [MR + 2]
+    double* R = g + (KRY_MR + 2);      // [MR][MR] row-major upper triangle (reciprocal diagonal)
+    double* yk = R + KRY_MR * KRY_MR;  // [MR]
+    int napp = 0, its = 0;
+    bool have_total = false;
+    double ttol = 0.0;
+    for (int cycle = 0;; cycle++) {
+      double t1[1] = {0.0};
+#pragma unroll
+      for (int j = 0; j < EPT; j++) t1[0] = fma(v[j].x, v[j].x, fma(v[j].y, v[j].y, t1[0]));
+      sum_rows<1>(t1);
+      const double ibeta = t1[0] > 0.0 ? rsqrt_nr(t1[0]) : 0.0, beta = t1[0] * ibeta;
+      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+#pragma unroll
+      for (int j = 0; j < EPT; j++) y[j] = make_double2(0.0, 0.0);
+      if (beta <= ttol || its >= A.maxiter) break;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) v[j] = make_double2(v[j].x * ibeta, v[j].y * ibeta);
+      vstore(SV, v);
+      double gcur = beta;
+      int jj = 0;
+      bool conv = false;
+      while (jj < KRY_MR) {
+        // z = R_p v_jj, parked in Z_jj; w = (I - alpha M) z takes its registers
+#pragma unroll
+        for (int j = 0; j < EPT; j++) y[j] = pmul(j, v[j]);
+        publish(y);
+        for (int m = 1; m < poly; m++) kry_pass<TRANS>(c, alpha, v, y);
+        {
+          double2* zp = vec(SZ + jj);
+          double2 prev = y[0];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            const double2 own = y[j];
+            const double2 t = st.template apply<TRANS, false>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
+            zp[64 * j] = own;
+            prev = own;
+            y[j] = make_double2(fma(-alpha, t.x, own.x), fma(-alpha, t.y, own.y));
+            slot_fence<EPT>();
+          }
+        }
+        napp += poly;
+        // classical Gram-Schmidt: every projection against the un-updated w, four per reduction; v_jj is in registers, v_k (k < jj) is read back
+        for (int p0 = 0; p0 <= jj; p0 += 4) {
+          double h4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int k = p0 + q;
+            if (k == jj) {
+#pragma unroll
+              for (int j = 0; j < EPT; j++) h4[q] = fma(y[j].x, v[j].x, fma(y[j].y, v[j].y, h4[q]));
+            } else if (k < jj) {
+              const double2* vp = vec(SV + k);
+#pragma unroll
+              for (int j = 0; j < EPT; j++) {
+                const double2 vk = vp[64 * j];
+                h4[q] = fma(y[j].x, vk.x, fma(y[j].y, vk.y, h4[q]));
+              }
+            }
+          }
+          sum_rows<4>(h4);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (p0 + q <= jj) hc[p0 + q] = h4[q];
+        }
+        {
+          const double h = hc[jj];
+#pragma unroll
+          for (int j = 0; j < EPT; j++) y[j] = make_double2(fma(-h, v[j].x, y[j].x), fma(-h, v[j].y, y[j].y));
+        }
+        for (int k = 0; k < jj; k++) {
+          const double h = hc[k];
+          const double2* vp = vec(SV + k);
+#pragma unroll
+          for (int j = 0; j < EPT; j++) {
+            const double2 vk = vp[64 * j];
+            y[j] = make_double2(fma(-h, vk.x, y[j].x), fma(-h, vk.y, y[j].y));
+          }
+        }
+        double nn[1] = {0.0};
+#pragma unroll
+        for (int j = 0; j < EPT; j++) nn[0] = fma(y[j].x, y[j].x, fma(y[j].y, y[j].y, nn[0]));
+        sum_rows<1>(nn);
+        const double ihn = nn[0] > 0.0 ? rsqrt_nr(nn[0]) : 0.0, hn = nn[0] * ihn;
+        // Givens rotations: redundantly by every thread on workgroup-uniform values, idempotent LDS writes only (Team::gmres_g of qd_device.h)
+        double cur_h = hc[0];
+        for (int k = 0; k < jj; k++) {
+          const double a1 = hc[k + 1], ck = cs[k], sk = sn[k];
+          R[k * KRY_MR + jj] = ck * cur_h + sk * a1;
+          cur_h = -sk * cur_h + ck * a1;
+        }
+        const double s2 = cur_h * cur_h + hn * hn;
+        const double irr = s2 > 0.0 ? rsqrt_nr(s2) : 0.0;
+        const double cj = s2 > 0.0 ? cur_h * irr : 1.0, sj = hn * irr;
+        cs[jj] = cj;
+        sn[jj] = sj;
+        R[jj * KRY_MR + jj] = irr;
+        g[jj] = cj * gcur;
+        gcur = -sj * gcur;
+        its++;
+        jj++;
+        if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
+        if (its >= A.maxiter || jj >= KRY_MR) break;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) v[j] = make_double2(y[j].x * ihn, y[j].y * ihn);
+        vstore(SV + jj, v);
+        __syncthreads();  // (the scalars of this column have been read by every thread before the next one overwrites hc)
+      }
+      for (int rw = jj - 1; rw >= 0; rw--) {
+        double sacc = g[rw];
+        for (int cc = rw + 1; cc < jj; cc++) sacc -= R[rw * KRY_MR + cc] * yk[cc];
+        yk[rw] = sacc * R[rw * KRY_MR + rw];
+      }
+#pragma unroll
+      for (int j = 0; j < EPT; j++) y[j] = make_double2(0.0, 0.0);
+      for (int cc = 0; cc < jj; cc++) {
+        const double f = yk[cc];
+        const double2* zp = vec(SZ + cc);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const double2 zk = zp[64 * j];
+          y[j] = make_double2(fma(f, zk.x, y[j].x), fma(f, zk.y, y[j].y));
+        }
+      }
+      if (conv || its >= A.maxiter) break;
+      // restart: park the accumulated solution, r = b - (I - alpha M) y_total
+      if (have_total) {
+        const double2* tp = vec(SY);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const double2 o = tp[64 * j];
+          y[j].x += o.x;
+          y[j].y += o.y;
+        }
+      }
+      vstore(SY, y);
+      have_total = true;
+      publish(y);
+      {
+        const double2* bp = vec(SB);
+        double2 prev = y[0];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+          const double2 own = y[j];
+          const double2 t = st.template apply<TRANS, false>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
+          const double2 bj = bp[64 * j];
+          v[j] = make_double2(bj.x - fma(-alpha, t.x, own.x), bj.y - fma(-alpha, t.y, own.y));
+          prev = own;
+          slot_fence<EPT>();
+        }
+      }
+      napp++;
+      __syncthreads();  // every thread has read the scalars of this cycle before the next one overwrites them
+    }
+    if (have_total) {
+      const double2* tp = vec(SY);
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 o = tp[64 * j];
+        y[j].x += o.x;
+        y[j].y += o.y;
+      }
+    }
+    vload(SB, v);
+    return napp;
+  }
+
+  // (I - alpha M^{(T)}) y = b for the adjoint sweep: b stays in registers.  Returns the RHS applications.
+  template <bool TRANS>
+  __device__ __forceinline__ int kry_solve(const SweepArgs& A, const StepC<Q>& c, double alpha, double2 (&b)[EPT], double2 (&y)[EPT]) {
+    const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = pmul(j, b[j]);
+    publish(y);
+    for (int m = 1; m < poly; m++) kry_pass<TRANS>(c, alpha, b, y);
+    double d[3] = {0.0, 0.0, 0.0};
+    {
+      double2 prev = y[0];
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 own = y[j];
+        const double2 t = st.template apply<TRANS, false>(c, j, own, prev, y[j + 1 < EPT ? j + 1 : j]);
+        const double rx = b[j].x - fma(-alpha, t.x, own.x), ry = b[j].y - fma(-alpha, t.y, own.y);  // r = b - (I - alpha M) z
+        d[0] = fma(b[j].x, b[j].x, fma(b[j].y, b[j].y, d[0]));
+        d[1] = fma(rx, b[j].x, fma(ry, b[j].y, d[1]));
+        d[2] = fma(rx, rx, fma(ry, ry, d[2]));
+        prev = own;
+        slot_fence<EPT>();
+      }
+    }
+    sum_rows<3>(d);
+    const double fac = kry_one_vector(A, d);
+    if (fac >= 0.0) {
+#pragma unroll
+      for (int j = 0; j < EPT; j++) y[j] = make_double2(fac * y[j].x, fac * y[j].y);
+      return poly;
+    }
+#ifdef QD_KRY_NOCOLD
+    return poly;
+#else
+    vstore(SB, b);
+    return poly + kry_generic<TRANS>(A, c, alpha, b, y);
+#endif
+  }
+
+  // Forward sub-step in stage form (see stage()): the passes run on z = x + alpha y with x as the right-hand side, so the application that
+  // forms b = M x IS the first pass (b = C x + D x is parked in slot SB from there: 16 B per element and step through L2) and the iterate
+  // of the k-system is y = (z - x) / alpha.  Residual of the k-system at y: r = b - (I - alpha M) y = M z - y.  On exit z = x + alpha k.
+  __device__ __forceinline__ int kry_stage(const SweepArgs& A, const StepC<Q>& c, double alpha, double2 (&x)[EPT], double2 (&z)[EPT]) {
+    const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
+    double2* bp = vec(SB);
+    {  // first pass: z_0 = P (x + alpha C x), b = C x + D x
+      const unsigned wa = st.tb + (unsigned)st.dlt;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 own = x[j];
+        const double2 t = st.template apply<false, true>(c, j, own, x[j > 0 ? j - 1 : 0], x[j + 1 < EPT ? j + 1 : j]);
+        double dwj, ddj;
+        st.diag(j, dwj, ddj);
+        const double2 bj = make_double2(fma(dwj, own.y, fma(ddj, own.x, t.x)), fma(-dwj, own.x, fma(ddj, own.y, t.y)));
+        if constexpr (BLDS) *reinterpret_cast<float2*>(st.smem + b32 + 512u * j) = make_float2((float)bj.x, (float)bj.y);
+        else bp[64 * j] = bj;
+        const double2 w = pmul(j, make_double2(fma(alpha, t.x, own.x), fma(alpha, t.y, own.y)));
+        z[j] = w;
+        st.st(wa + (unsigned)j * COLB, w);
+        slot_fence<EPT>();
+      }
+      __syncthreads();
+      st.flip();
+    }
+    for (int m = 1; m < poly; m++) kry_pass<false>(c, alpha, x, z);
+    double d[3] = {0.0, 0.0, 0.0};
+    {
+      const double ia = 1.0 / alpha;
+      double2 prev = z[0];
+      double2 bq[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+      if constexpr (!BLDS) {
+        bq[0] = bp[0];
+        bq[1] = bp[EPT > 1 ? 64 : 0];
+      }
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const double2 own = z[j];
+        double2 bj;
+        if constexpr (BLDS) {
+          const float2 f = *reinterpret_cast<const float2*>(st.smem + b32 + 512u * j);
+          bj = make_double2((double)f.x, (double)f.y);
+        } else {
+          bj = bq[j & 1];
+          if (j + 2 < EPT) bq[j & 1] = bp[64 * (j + 2 < EPT ? j + 2 : 0)];
+        }
+        const double2 t = st.template apply<false, false>(c, j, own, prev, z[j + 1 < EPT ? j + 1 : j]);
+        const double rx = fma(-ia, own.x - x[j].x, t.x), ry = fma(-ia, own.y - x[j].y, t.y);  // r = M z - (z - x) / alpha
+        d[0] = fma(bj.x, bj.x, fma(bj.y, bj.y, d[0]));
+        d[1] = fma(rx, bj.x, fma(ry, bj.y, d[1]));
+        d[2] = fma(rx, rx, fma(ry, ry, d[2]));
+        prev = own;
+        slot_fence<EPT>();
+      }
+    }
+    sum_rows<3>(d);
+    const double fac = kry_one_vector(A, d);
+    if (fac >= 0.0) {
+#pragma unroll
+      for (int j = 0; j < EPT; j++) z[j] = make_double2(fma(fac, z[j].x - x[j].x, x[j].x), fma(fac, z[j].y - x[j].y, x[j].y));
+      return poly + 1;
+    }
+#ifdef QD_KRY_NOCOLD
+    return poly + 1;
+#endif
+    // the solve starts over on the k-system: b = M x again (in fp64), x parked, b in its registers
+    publish(x);
+    apply_all<false>(c, x, z);
+    vstore(SX, x);
+    vstore(SB, z);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = z[j];
+    const int n = 1 + kry_generic<false>(A, c, alpha, x, z);
+    vload(SX, x);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) z[j] = make_double2(fma(alpha, z[j].x, x[j].x), fma(alpha, z[j].y, x[j].y));
+    return poly + 1 + n;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -601,13 +1003,15 @@ __device__ __forceinline__ int slice_start(const SweepArgs& A, int sl) {
 // ---------------------------------------------------------------------------------------------
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, bool SPLIT, bool USLOT = false, bool SKIP = false>
+template <int Q, int EPT, bool SPLIT, bool USLOT = false, bool SKIP = false, bool KRY = false>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const SweepArgs A) {
+  static_assert(!KRY || (SPLIT && !SKIP), "the Krylov solver runs on the diagonal-split form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef ColTeam<Q, EPT, SPLIT, USLOT, SKIP> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
+  if constexpr (KRY) tm.init_kry(A);
   __shared__ unsigned task_slot, carry_slot;
   const int dim = S.dim, ntask = A.nb * A.nslice;
   const bool pen_on = A.gamma_penalty > 1e-13;
@@ -653,7 +1057,8 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     // the sub-step in stage form (ColTeam::stage): x is the right-hand side of the solve and stays in registers
     tm.publish(x);
     double2 z[EPT];
-    napply += tm.stage(A, c, 0.5 * c.h, x, z);
+    if constexpr (KRY) napply += tm.kry_stage(A, c, 0.5 * c.h, x, z);
+    else napply += tm.stage(A, c, 0.5 * c.h, x, z);
     if (A.ztraj && tm.st.rowok) {  // the primal stage, read back by the adjoint sweep instead of repeating this solve: private to
       // this kernel pair, kept interleaved (one 16-byte streaming access per element; qd_handle tags the layout: ztraj_fmt)
       col_d2* dst = reinterpret_cast<col_d2*>(A.ztraj) + ((size_t)s * A.nb + ic) * dim;
@@ -725,13 +1130,15 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
 // ---------------------------------------------------------------------------------------------
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
-template <int Q, int EPT, bool SPLIT, bool USLOT = false, bool SKIP = false>
+template <int Q, int EPT, bool SPLIT, bool USLOT = false, bool SKIP = false, bool KRY = false>
 __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const SweepArgs A) {
+  static_assert(!KRY || (SPLIT && !SKIP), "the Krylov solver runs on the diagonal-split form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef ColTeam<Q, EPT, SPLIT, USLOT, SKIP> TM;
   const DevSys& S = A.S;
   TM tm;
   tm.init(S, smem);
+  if constexpr (KRY) tm.init_kry(A);
   __shared__ unsigned task_slot, carry_slot;
   const int dim = S.dim, ntask = A.nb * A.nslice;
   const bool pen_on = A.gamma_penalty > 1e-13;
@@ -808,7 +1215,8 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z of the sub-step was stored by the forward sweep
     if (SPLIT) tm.template set_alpha<true>(0.5 * c.h);
     double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
-    tm.template neumann<true>(A, c, 0.5 * c.h, xb, kb);
+    if constexpr (KRY) tm.template kry_solve<true>(A, c, 0.5 * c.h, xb, kb);
+    else tm.template neumann<true>(A, c, 0.5 * c.h, xb, kb);
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
       kb[j].x *= c.h;
@@ -934,6 +1342,10 @@ int col_slices(int nb, int ntime, const TuneOpts& o) {
   return best_waste < 0.01 || best > 1 ? best : 1;
 }
 
+// SweepArgs::kry of the Krylov kernels: GMRES_MR_G + 2 padded scratch vectors per RESIDENT workgroup (ColTeam::init_kry), in doubles
+// (a sweep without time slices starts one workgroup per initial condition)
+size_t col_krylov_doubles(int nb, bool sliced) { return (size_t)(sliced ? std::min(nb, 2 * col_cu_count()) : nb) * (GMRES_MR_G + 2) * 2 * KRY_VEC; }
+
 template <typename K>
 static hipError_t set_lds_col(K kern, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -968,6 +1380,7 @@ static int col_grid(K kern, const SweepArgs& a, int threads, size_t lds) {
   int ncu = col_cu_count();
   (void)dev;
   (void)prop;
+  if (a.use_gmres) per_cu = std::min(per_cu, 2);  // (col_krylov_doubles)
   return std::min(a.nb * a.nslice, per_cu * ncu);
 }
 
@@ -984,8 +1397,38 @@ static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
   return hipGetLastError();
 }
+// the Krylov kernels (SweepArgs::use_gmres): five or eight columns per wave only
+template <int Q, int EPT>
+static hipError_t go_fwd_col_k(const SweepArgs& a, hipStream_t st) {
+  if constexpr (EPT == 5 || EPT == 8) {
+    typedef ColLean<Q, EPT> ST;
+    const size_t lds = ST::lds_bytes(a.S.N) + ColTeam<Q, EPT, true>::kry_lds_extra(a.S.N);
+    auto kf = col_uslot<EPT>(a.S) ? k_forward_col<Q, EPT, true, true, false, true> : k_forward_col<Q, EPT, true, false, false, true>;
+    hipError_t e = set_lds_col(kf, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+template <int Q, int EPT>
+static hipError_t go_adj_col_k(const SweepArgs& a, hipStream_t st) {
+  if constexpr (EPT == 5 || EPT == 8) {
+    typedef ColLean<Q, EPT> ST;
+    const size_t lds = ST::lds_bytes(a.S.N) + ColTeam<Q, EPT, true>::kry_lds_extra(a.S.N);
+    auto kf = col_uslot<EPT>(a.S) ? k_adjoint_col<Q, EPT, true, true, false, true> : k_adjoint_col<Q, EPT, true, false, false, true>;
+    hipError_t e = set_lds_col(kf, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kf, dim3(col_grid(kf, a, 64 * (ST::ncols(a.S.N) / EPT), lds)), dim3(64 * (ST::ncols(a.S.N) / EPT)), lds, st, a);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
 template <int Q, int EPT>
 static hipError_t go_fwd_col(const SweepArgs& a, hipStream_t st) {
+  if (a.use_gmres) return go_fwd_col_k<Q, EPT>(a, st);
   return a.neumann_split ? go_fwd_col_s<Q, EPT, true>(a, st) : go_fwd_col_s<Q, EPT, false>(a, st);
 }
 template <int Q, int EPT, bool SPLIT>
@@ -1002,6 +1445,7 @@ static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
 }
 template <int Q, int EPT>
 static hipError_t go_adj_col(const SweepArgs& a, hipStream_t st) {
+  if (a.use_gmres) return go_adj_col_k<Q, EPT>(a, st);
   return a.neumann_split ? go_adj_col_s<Q, EPT, true>(a, st) : go_adj_col_s<Q, EPT, false>(a, st);
 }
 template <int Q, int EPT>
@@ -1043,12 +1487,20 @@ static int col_ept(int N, const TuneOpts& o) {
     return hipErrorInvalidValue;                                  \
   } while (0)
 
-hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+// (the Krylov kernels are built with five and eight columns per wave: the automatic choices)
+static TuneOpts col_opts(const SweepArgs& a, const TuneOpts& o) {
+  TuneOpts t = o;
+  if (a.use_gmres && t.col_ept != 5 && t.col_ept != 8) t.col_ept = 0;
+  return t;
+}
+hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o0, hipStream_t st) {
   const int Qn = a.S.Q, Nn = a.S.N;
+  const TuneOpts o = col_opts(a, o0);
   QD_COL_DISPATCH(go_fwd_col, a, st);
 }
-hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
+hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o0, hipStream_t st) {
   const int Qn = a.S.Q, Nn = a.S.N;
+  const TuneOpts o = col_opts(a, o0);
   QD_COL_DISPATCH(go_adj_col, a, st);
 }
 hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, const TuneOpts& o, hipStream_t st) {

@@ -701,11 +701,17 @@ int qd_handle::gmres_poly_degree() const {
   row_bounds(&dg, &of);
   double amax = 0.0;
   for (double hh : sched_h) amax = std::max(amax, fabs(hh) / 2.0);
+  // the lean column kernels precondition with the polynomial of the diagonal-split iteration [r6]: only the off-diagonal row sum has
+  // to contract (ColTeam::kry_*, qd_col.hip)
+  if (precision == QD_PRECISION_F64 && collean_available(S, opts) && S.N >= 44) return amax * of <= 0.7 ? want : 1;
   return amax * (dg + of) <= 0.7 ? want : 1;
 }
 
+// the lean column kernels: the stationary iterations, and [r6] the Krylov solver wherever the polynomial preconditioner is on (without
+// it - KSPGMRES + PCNONE iteration for iteration - a gmres request stays on the general column kernel)
 bool qd_handle::use_col(const qd::LaunchCfg& cfg) const {
-  return precision == QD_PRECISION_F64 && cfg.var == 9 && !cfg.gmres && collean_available(S, opts) && sol.stepper != QD_STEPPER_EE;
+  if (!(precision == QD_PRECISION_F64 && cfg.var == 9 && collean_available(S, opts) && sol.stepper != QD_STEPPER_EE)) return false;
+  return !cfg.gmres || (cfg.gmres == 2 && !opts.no_col_krylov && gmres_poly_degree() > 1);
 }
 
 // linearsolver_type = gmres on the systems of the lean column kernels.  A Krylov basis of 57.6 KB vectors per initial condition has no
@@ -955,7 +961,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
-    if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
+    if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
@@ -1182,7 +1188,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
   if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
-    if ((r = d_kry.ensure(krylov_doubles(S, nb)))) return r;
+    if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;

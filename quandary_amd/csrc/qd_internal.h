@@ -144,6 +144,7 @@ struct TuneOpts {
                            // at most one state per CU, else 4 on 256; 1 / 2 force)
   int no_lean64 = 0;       // "no_lean64": 2^5 / 2^4 Lindblad on the general slot kernels
   int no_collean = 0;      // "no_collean": 3 x 20-class systems on the general column kernel
+  int no_col_krylov = 0;   // "no_col_krylov": the Krylov solver of 3 x 20-class systems on the general column kernel (A/B against the lean one [r6])
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
   double standin_tau = 1e-3;  // "standin_tau": error-estimate factor of the stationary iterations that serve gmres requests (0 = plain update-norm rule)
   int no_plain = 0;        // "no_plain": 1 / 2 / 3 = forward / adjoint / both sweeps of the small systems on the general instantiation (A/B)
@@ -216,6 +217,7 @@ hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transp
 // lean column kernels (qd_col.hip): Lindblad Neumann sweeps of density matrices with 33..64 rows and runtime level counts
 bool collean_available(const DevSys& S, const TuneOpts& o);
 int col_slices(int nb, int ntime, const TuneOpts& o);  // time slices of a lean column sweep (1 = none)
+size_t col_krylov_doubles(int nb, bool sliced);  // size of SweepArgs::kry for the Krylov solver of the lean column kernels
 hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, const TuneOpts& o, hipStream_t st);

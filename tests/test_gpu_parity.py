@@ -318,7 +318,11 @@ def test_gmres_solver_vs_oracle_gmres(kw):
         kw = {**kw, "init": "basis, 0"}
     if kw["nlevels"] == [2, 2, 2, 2, 2]:
         kw = {**kw, "init": "diagonal, 0, 1"}
-    sp, h, orc = _pair(kw, gmres_mode="0", ntime=30, linsolve="gmres", penalties=True, dt=0.05)
+    sp = with_gmres_mode(synthetic_spec(**{**kw, "ntime": 30, "linsolve": "gmres", "penalties": True, "dt": 0.05}), "0")
+    # (gmres_poly = 1: KSPGMRES + PCNONE iteration for iteration.  With the polynomial preconditioner the 3x20 system runs on the lean column
+    #  kernels' Krylov solver [r6], which is held to the exact discrete solution in test_lean_column_krylov_solver)
+    sp.options = {**sp.options, "gmres_poly": "1"}
+    h, orc = capi.Handle(sp), Oracle(sp)
     opt = capi.Optim(h, sp)
     val, g = opt.evalGradF(sp.params0)
     assert h.last_solver == "krylov"
@@ -358,6 +362,45 @@ def test_gmres_polynomial_preconditioner_on_the_axc_system(poly, monkeypatch):
         assert abs(h.mean_applies - orc.mean_applies) < 0.25
     else:
         assert orc.mean_applies < h.mean_applies < 2.0 * orc.mean_applies  # 1 + 3 x p + 3 applications against ~10
+    opt.close(); h.close(); orc.close()
+
+
+@pytest.mark.parametrize("dt,poly", [(1e-4, "auto"), (1e-4, "3"), (0.002, "auto"), (0.05, "auto"), (0.05, "2")])
+@pytest.mark.parametrize("kw", [pytest.param(dict(nlevels=[3, 20], lindblad=True, target="pure", objective="Jmeasure", init="basis, 0"), id="3x20"),
+                                pytest.param(dict(nlevels=[3, 3, 5], lindblad=True, nessential=[2, 3, 4], target="pure", objective="Jmeasure", init="diagonal, 2"), id="3x3x5-N45"),
+                                pytest.param(dict(nlevels=[4, 4, 4], lindblad=True, nessential=[3, 4, 3], target="pure", objective="Jfrobenius", init="diagonal, 0"), id="4x4x4-guard-eight-columns")])
+def test_lean_column_krylov_solver(kw, dt, poly):
+    """[r6] linearsolver_type = gmres on the lean column kernels (qd_col.hip, ColTeam::kry_*; option gmres_split = 0): GMRES right-preconditioned
+    with the polynomial of the diagonal-split iteration.  The fused one-vector path (dt = 1e-4, tuned degree), the generic path behind it
+    (degree 3 / 2: several Krylov vectors per solve, basis in global memory) and time steps far outside the contraction region of the
+    reference's Neumann series (dt = 0.05: alpha |D| ~ 5) - at the reference tolerances against the oracle, or - where the oracle's GMRES
+    stops at its iteration cap - against the exact solution of the discrete equations."""
+    sp = synthetic_spec(**{**kw, "ntime": 24, "linsolve": "gmres", "penalties": True, "dt": dt})
+    sp.options = {"gmres_split": "0", "gmres_poly": poly}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == "krylov"
+    if dt < 0.05:
+        oval, og = orc.evalGradF(sp.params0)
+        assert check_parity(sp, val, g, oval, og, msg=(kw, dt, poly)) == "plain"
+    else:
+        # the oracle's un-preconditioned GMRES ends at its iteration cap here (3x20: 54 applications per step, gradient 7e-7 from the exact
+        # one): the comparator is the exact solution of the discrete equations (every linear system to 1e-14)
+        from helpers import tight_oracle
+        tight = tight_oracle(sp)
+        tval, tg = tight.evalGradF(sp.params0)
+        tight.close()
+        for k in OBJ_KEYS:
+            assert val[k] == pytest.approx(tval[k], rel=REF_RTOL, abs=1e-12), k
+        assert np.linalg.norm(g - tg) <= 1e-8 * np.linalg.norm(tg)
+    # the same evaluation on the general column kernel (the lean one switched off): same method up to the preconditioner's form
+    h.set_option("no_col_krylov", "1")
+    val2, g2 = opt.evalGradF(sp.params0)
+    if dt < 0.05:  # (at dt = 0.05 the Neumann polynomial of the general kernel diverges: it runs un-preconditioned there and stops at the cap)
+        for k in OBJ_KEYS:
+            assert val2[k] == pytest.approx(val[k], rel=1e-8, abs=1e-11), k
+        assert np.linalg.norm(g2 - g) <= 1e-8 * np.linalg.norm(g) + 1e-12
     opt.close(); h.close(); orc.close()
 
 
