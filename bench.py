@@ -107,7 +107,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(spec, mode, target_wall_s=6.0):
+def cpu_baseline(spec, mode, target_wall_s=6.0, sweep=True):
     """Bounded sample of the same workload on the host cores (rank 0, N=1 only), parallelised like the reference: over initial
     conditions, one worker process per core (np_init = min(ninit, cores), src/main.cpp:145).  A single worker is timed alone first; the
     worker count is then swept over {1/4, 1/2, 1} x the usable cores and the best rate is reported together with the parallel
@@ -138,7 +138,9 @@ def cpu_baseline(spec, mode, target_wall_s=6.0):
     single = k * nt * reps / el1
     best = None
     tried = []
-    for w in sorted({max(1, min(ninit // k, ncore // 4)), max(1, min(ninit // k, ncore // 2)), max(1, min(ninit // k, ncore))}):
+    # (sweep = False - the short samples next to the small workloads: the single worker and the full pool only)
+    counts = {max(1, min(ninit // k, ncore // 4)), max(1, min(ninit // k, ncore // 2)), max(1, min(ninit // k, ncore))} if sweep else {max(1, min(ninit // k, ncore))}
+    for w in sorted(counts):
         workers = w
         while True:
             t0 = time.perf_counter()
@@ -394,10 +396,13 @@ CHECK_TOL = {"f64": 1e-9, "f32mixed": 2e-5}
 EXTRA = [
     ("c4", "fwd", "neumann", "f64", {"ntime": 250}, 2, {"neumann_split": 0}),  # the reference's Neumann iteration on the same kernels
     ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 2, {}),  # gmres request served by the diagonal-split iteration under GMRES's stopping rule
-    ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 1, {"gmres_split": 0}),  # the Krylov kernel (polynomial preconditioner, basis in L2 / HBM)
+    ("c4", "fwd", "gmres", "f64", {"ntime": 250}, 2, {"gmres_split": 0}),  # the Krylov solver of the lean column kernels [r6] (GMRES, split-polynomial preconditioner)
+    ("c4", "grad", "gmres", "f64", {"ntime": 250}, 1, {"gmres_split": 0}),
     ("c4", "grad", "neumann", "f64", {"ntime": 500}, 1, {}),  # stored stages fit (104 GB): no chunking; the full grid is the "gradient" block
     ("c2", "fwd", "neumann", "f64", {}, 20, {}),  # BASELINE configs[1] (the round-1/2 headline): 64 single-wave workgroups
+    ("c2", "grad", "neumann", "f64", {}, 10, {}),
     ("q4", "fwd", "neumann", "f64", {}, 20, {}),  # (3-8 ms per step: enough steps that one host hiccup does not halve the rate)
+    ("q4", "grad", "neumann", "f64", {}, 10, {}),
     ("q4", "fwd", "gmres", "f64", {}, 10, {}),  # served by the Neumann iteration (contraction bound <= 0.3)
     ("q4", "fwd", "gmres", "f64", {}, 10, {"gmres_split": 0}),  # the Krylov kernel (basis in LDS)
     ("q4", "fwd", "neumann", "f32mixed", {}, 20, {}),
@@ -420,14 +425,20 @@ EXTRA = [
     ("n32", "fwd", "gmres", "f64", {}, 1, {"gmres_split": 0}),  # the Krylov kernel: 12 basis vectors of 16 MB through HBM
     ("n32", "grad", "gmres", "f64", {}, 1, {}),
     # small systems: no chip-filling possible (4 / 16 single-wave workgroups); reported so that the bench line says it
+    ("c1", "fwd", "gmres", "f64", {}, 5, {}),
     ("c1", "grad", "gmres", "f64", {}, 3, {}),
+    ("c3", "fwd", "neumann", "f64", {}, 5, {}),
     ("c3", "grad", "neumann", "f64", {}, 3, {}),
 ]
+# the entries that carry a CPU figure of their own (`cpu`, `x` = GPU / CPU, printed also where it is below 1): forward and gradient of every
+# BASELINE configuration and of the 4-qubit open system the north-star sentence names - short samples (about a second of CPU work each)
+CPU_BESIDE = {("c1", "gmres"), ("c2", "neumann"), ("c3", "neumann"), ("c5", "neumann"), ("q4", "neumann")}
 LEGEND = ("n workload, m mode, s linear solver, d dtype, o options (qd_set_option), v timesteps*initconds/s, ms per evaluation (host clock), "
           "kms sweep-kernel ms per evaluation (hipEvents on the handle's stream), A RHS applications per step, nt time steps, ni initial "
           "conditions, dim state dimension, hbm algorithmic bytes / kernel time / 8 TB/s, valu canonical flops / kernel time / measured fp64 "
           "FMA rate (fp32-mixed: 157.3 TF), sol the iteration that solved the linear systems (qd_last_solver), chk max error of the seven partial sums against the CPU oracle on a small sample, wg workgroups "
-          "per initial condition, x gpu_over_cpu")
+          "per initial condition, cpu the CPU restatement of the reference path on this box's host cores in this run (v units/s of the best pool, cores its workers, eff its parallel "
+          "efficiency, one = a single worker), x = v / cpu.v (GPU over CPU; below 1 where the configuration cannot fill the chip)")
 
 
 def _free_port():
@@ -459,9 +470,9 @@ def extra_entry(wn, wm, ws, wd, wo, wsteps, wopt, local_rank, sync, fp64_peak, w
             kk = 8 if r.spec.ninit % 8 == 0 else 1
             nn = 2 if r.spec.dim > 100000 else 20 if r.spec.dim > 256 else 100
             ent["chk"] = _sig(check_against_oracle(r.spec, local_rank, kk, nn, oracle_sample(r.spec, kk, nn), CHECK_TOL[wd]), 2)
-        if with_cpu and (wn, wm, ws, wd) == ("q4", "fwd", "neumann", "f64"):
-            # north_star: >= 10x the CPU baseline for a 4-qubit open system at 1 GPU
-            cb, _ = cpu_baseline(r.spec, wm, target_wall_s=3.0)
+        if with_cpu and wd == "f64" and not wopt and ((wn, ws) in CPU_BESIDE or (wn, wm, ws) == ("c4", "grad", "neumann")):
+            # north_star: the reference path timed on the same box's host cores in the same run (>= 10x for a 4-qubit open system at 1 GPU)
+            cb, _ = cpu_baseline(r.spec, wm, target_wall_s=1.0, sweep=False)
             ent["cpu"] = {"v": _sig(cb["value"]), "cores": cb["cores"], "eff": _sig(cb["parallel_efficiency"], 3),
                           "one": _sig(cb["single_worker_units_per_s"])}
             ent["x"] = _sig(v / cb["value"], 4)
@@ -496,8 +507,10 @@ def main():
                     help="N > 1: strong = split the initial conditions over the GPUs (default); weak = one full set per GPU")
     ap.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "host", "gloo", "auto-fallback"],
                     help="auto: nccl (RCCL over xGMI, called from the library) when every rank has its own GPU, otherwise host (the library's "
-                         "shared-memory backend: several ranks share one GPU, same C++ call sites).  gloo: reductions through torch.distributed "
-                         "on host buffers (Python-level orchestration).  A failing RCCL bootstrap is an ERROR unless auto-fallback is given.")
+                         "shared-memory backend: several ranks share one GPU, same C++ call sites); both bootstrap through a file "
+                         "(qd_comm_create_from_file: no torch.distributed).  gloo: reductions through torch.distributed on host buffers "
+                         "(Python-level orchestration).  A failing bootstrap or all-reduce self-check prints a JSON line with \"error\" and exits "
+                         "non-zero (auto-fallback is accepted as a synonym of auto: nothing falls back).")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -528,20 +541,40 @@ def main():
     import torch
 
     from quandary_amd import capi
-    from quandary_amd.parallel import RcclComm, make_comm
+    from quandary_amd.parallel import FileComm, make_comm
 
     ndev = torch.cuda.device_count()
     backend = args.dist_backend
-    fallback_ok = backend == "auto-fallback"
     if backend in ("auto", "auto-fallback"):
         backend = "nccl" if ndev >= world else "host"
     if multi and backend in ("gloo", "host"):
         local_rank = local_rank % max(ndev, 1)  # ranks may share a GPU in this mode
         if world > max(ndev, 1):  # (the time-sliced sweeps wait longer for a predecessor when other processes use the device: qd_col.hip)
             os.environ.setdefault("QD_DEVICE_SHARERS", str(-(-world // max(ndev, 1))))
+    if multi:
+        os.environ.setdefault("QD_LOCAL_SIZE", os.environ.get("LOCAL_WORLD_SIZE", str(world)))  # (one node: the contract of this script)
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    comm = make_comm(backend, rank, world, local_rank, allow_fallback=fallback_ok) if multi else None
+    comm = None
+    if multi and backend == "gloo":
+        comm = make_comm("gloo", rank, world, local_rank)  # (Python-level orchestration over torch.distributed: CPU-side tests of the sharding)
+    elif multi:
+        # The library's own bootstrap: the ncclUniqueId travels through a file next to the launcher's rendezvous port - no torch.distributed,
+        # no gloo hop (qd_comm_create_from_file) - and eight doubles go through the communicator before any sweep does.
+        def fail_line(msg):
+            if rank == 0:
+                print(json.dumps({"metric": "lindblad_timesteps_x_initconds_per_sec", "value": None, "n_gpus": world, "error": msg,
+                                  "dist_backend": backend, "ranks_expected": world}))
+            sys.stdout.flush()
+            raise SystemExit(f"bench.py rank {rank}: {msg}")
+        path = os.environ.get("QD_COMM_FILE") or os.path.join("/tmp", f"qd_bench_comm_{os.environ.get('MASTER_PORT', 'default')}")
+        try:
+            comm = FileComm(rank, world, local_rank, path, backend={"nccl": "rccl", "host": "host"}[backend], timeout_s=300.0)
+        except Exception as e:  # noqa: BLE001
+            fail_line(f"communicator bootstrap failed ({backend}): {type(e).__name__}: {e}"[:400])
+        ok, got = comm.self_check()
+        if not ok:
+            fail_line(f"all-reduce self-check failed on {world} ranks ({backend}): {got}"[:400])
 
     def sync():
         if torch.cuda.is_available():
@@ -599,8 +632,9 @@ def main():
             out["grad_wall_ms"] = elapsed / steps * 1e3
         if multi:
             out["ranks_seen"] = comm.world_size()
-            out["rccl"] = type(comm) is RcclComm
+            out["rccl"] = bool(getattr(comm, "is_rccl", lambda: False)())
             out["dist_backend"] = comm.describe()
+            out["allreduce_self_check"] = "8 doubles, sum and max over the ranks, before the first sweep: ok" if hasattr(comm, "self_check") else None
             out["allreduce_ms_per_step"] = {"objective_sums": ar_ms[0] / steps, "gradient": ar_ms[1] / steps}
     run.close()
 
@@ -717,11 +751,28 @@ def main():
                 # the CPU baseline runs the REFERENCE's Neumann iteration (~13 applications per step on this system), the headline the
                 # diagonal-split one (~8): gpu_over_cpu folds that algorithmic change in.  The same iteration on both sides:
                 same = [w for w in out["workloads"] if w.get("n") == "c4" and w.get("m") == "fwd" and w.get("o") == {"neumann_split": 0} and "v" in w]
+                cb = out["cpu_baseline"]
+                for w in out["workloads"]:  # the headline's CPU sample beside every C4 forward entry
+                    if w.get("n") == "c4" and w.get("m") == "fwd" and "v" in w:
+                        w["cpu"] = {"v": _sig(cb["value"]), "cores": cb["cores"], "eff": _sig(cb["parallel_efficiency"], 3), "one": _sig(cb["single_worker_units_per_s"])}
+                        w["x"] = _sig(w["v"] / cb["value"], 4)
                 if same:  # lead with the like-for-like ratio; the mixed one keeps its own name
                     out["gpu_over_cpu_mixed_iterations"] = out["gpu_over_cpu"]
                     out["gpu_over_cpu"] = same[0]["v"] / out["cpu_baseline"]["value"]
                     out["gpu_over_cpu_note"] = ("gpu_over_cpu: GPU and CPU both on the reference's Neumann iteration (workloads entry c4 fwd neumann_split=0); "
                                                 "gpu_over_cpu_mixed_iterations: the headline's diagonal-split iteration against the CPU's reference iteration")
+    if rank == 0 and multi:
+        # ---- oracle check of the multi-GPU line: shard 0 of the timed workload on a small sample against the CPU oracle (rank 0 alone, after the
+        # timed region; the other ranks wait in the closing barrier) - the solver path and the kernels that were timed
+        try:
+            k, nt = min(run.spec.ninit, 8), min(run.spec.time.ntime, 20 if run.spec.dim > 256 else 100)
+            while run.spec.ninit % k:
+                k -= 1
+            err = check_against_oracle(run.spec, local_rank, k, nt, oracle_sample(run.spec, k, nt), CHECK_TOL[args.dtype])
+            out["oracle_check"] = {"sample": f"first {k} initial conditions x first {nt} steps, seven partial sums of evalF (rank 0, after the timed region)",
+                                   "max_err_rel_to_max1": err, "tol": CHECK_TOL[args.dtype]}
+        except (Exception, SystemExit) as e:  # noqa: BLE001
+            out["oracle_check"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and multi and not weak:
         # The same workload on ONE GPU (rank 0 alone, after the timed region): the one-GPU point of this strong-scaling series in
         # the same line.

@@ -1049,9 +1049,13 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     }
   };
 
+  double hlast = s_lo > 0 ? kload(A.ctl + (size_t)(s_lo - 1) * A.cs) : 0.0;  // (a time slice continues where its predecessor stopped)
   for (int s = s_lo; s < s_hi; s++) {
     StepC<Q> c;
     load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    // (the skipped stopping tests compare like with like: a sub-step of another size - composite steppers - starts its count over)
+    if (SKIP && A.nstages > 1 && c.h != hlast) tm.lastn = 0;
+    hlast = c.h;
     if (SPLIT) tm.template set_alpha<false>(0.5 * c.h);
     if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
     // the sub-step in stage form (ColTeam::stage): x is the right-hand side of the solve and stays in registers
@@ -1165,6 +1169,7 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
                            : make_double2(0.0, 0.0);
   };
 
+  double hlast = s_hi < A.nsub ? kload(A.ctl + (size_t)s_hi * A.cs) : 0.0;
   for (int s = s_hi - 1; s >= s_lo; s--) {
     // penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227, :300-339)
     if (pen_on && (s + 1) % A.nstages == 0 && (wj_on || leak)) {
@@ -1212,6 +1217,8 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     }
     StepC<Q> c;
     load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
+    if (SKIP && A.nstages > 1 && c.h != hlast) tm.lastna = 0;
+    hlast = c.h;
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z of the sub-step was stored by the forward sweep
     if (SPLIT) tm.template set_alpha<true>(0.5 * c.h);
     double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
@@ -1325,7 +1332,8 @@ int col_cu_count() {
 // of two that brings the idle tail - (ceil(r) - r) / ceil(r) for r = nb k / #CUs rounds - below 1 %, keeping at least 32 steps per slice.
 int col_slices(int nb, int ntime, const TuneOpts& o) {
   if (o.col_slices == 1) return 1;
-  if (o.col_slices > 1) return std::min(o.col_slices, std::max(ntime, 1));
+  // (at most 255 slices: the scheduler word of an initial condition counts completed slices in its low byte, sched_wait / sched_done)
+  if (o.col_slices > 1) return std::min(std::min(o.col_slices, 255), std::max(ntime, 1));
   const int ncu = col_cu_count();
   if (nb <= ncu) return 1;
   int best = 1;

@@ -13,6 +13,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <random>
 
@@ -176,7 +177,12 @@ static bool spin_until(P pred, double timeout_s) {
 // large or chunked gradient evaluation is legitimately long (RCCL has no such limit either).  A wait ends when pred() holds, when a peer
 // PROCESS is gone (checked once a second: kill(pid, 0)), or after QD_COMM_COLLECTIVE_TIMEOUT_S (default one day).
 // (a process that has exited but has not been reaped by its launcher yet still answers kill(pid, 0): state Z in /proc/<pid>/stat)
+// The check assumes that the ranks share ONE PID namespace (ranks of one node started by one launcher: the only way they can share a
+// POSIX segment and a GPU here).  Ranks in separate containers with a common /dev/shm see each other's pids as foreign numbers: set
+// QD_COMM_NO_LIVENESS=1 there (collectives then end on pred() or on the time limit only).
 static bool process_alive(long pid) {
+  static const bool off = [] { const char* e = getenv("QD_COMM_NO_LIVENESS"); return e && atoi(e) != 0; }();
+  if (off) return true;
   if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) return false;
   char path[64], buf[512];
   snprintf(path, sizeof path, "/proc/%ld/stat", pid);
@@ -199,7 +205,9 @@ static int host_wait(qd::HostRing* g, const std::function<bool()>& pred) {
     if (spin_until(pred, 1.0)) return 0;
     for (int r = 0; r < g->nranks; r++) {
       const long p = (long)g->seg->pid[r].v.load(std::memory_order_acquire);
-      if (r != g->rank && p > 0 && !process_alive(p)) return 1 + r;
+      // (a peer that has arrived - or finished its last collective - may exit between the last poll of pred() and this check: look again
+      //  before calling the collective failed)
+      if (r != g->rank && p > 0 && !process_alive(p)) return pred() ? 0 : 1 + r;
     }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return -1;
   }
@@ -466,8 +474,16 @@ extern "C" int qd_comm_create_from_file(const char* path, int rank, int nranks, 
       (void)hipGetLastError();
       ndev = 0;
     }
-    const char* ls = getenv("QD_LOCAL_SIZE");
-    const int local = ls && atoi(ls) > 0 ? atoi(ls) : nranks;
+    // (callers that reach this function through the C or the Python API under a launcher of their own set no QD_LOCAL_SIZE: the usual
+    //  launcher variables stand in, as launch_env() of the config-file driver reads them)
+    int local = nranks;
+    for (const char* key : {"QD_LOCAL_SIZE", "LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE", "PMI_LOCAL_SIZE"}) {
+      const char* ls = getenv(key);
+      if (ls && atoi(ls) > 0) {
+        local = std::min(atoi(ls), nranks);
+        break;
+      }
+    }
     host = local > ndev;
     if (host && local < nranks)
       return fail(QD_ERR_UNSUPPORTED, "qd_comm_create_from_file: more ranks per node than GPUs on a launch that spans nodes (the shared-memory backend is node-local)");

@@ -161,6 +161,58 @@ class HostComm(RcclComm):
         return "host shared-memory all-reduce inside libquandary_amd.so (qd_comm_create_host), same call sites as the RCCL backend"
 
 
+class FileComm(RcclComm):
+    """The library's own bootstrap (qd_comm_create_from_file): rank 0 publishes the ncclUniqueId in a file, every rank confirms it with a
+    nonce of its own, rank 0 releases each rank separately - no torch.distributed, no gloo hop.  `backend`: "rccl", "host" (ranks sharing a
+    GPU: POSIX shared memory) or "auto" (host only when the ranks of this node outnumber its GPUs) - the choice is made inside the library
+    (QD_COMM_BACKEND / QD_LOCAL_SIZE).  Every collective is the library's (qd_comm_allreduce / qd_comm_barrier / qd_optim_eval*_dist)."""
+
+    def __init__(self, rank, world, local_rank, path, backend="auto", timeout_s=300.0):
+        from . import capi
+
+        self.dist = None
+        self._own = False
+        self._bufs = {}
+        self.device = "cpu"
+        os.environ["QD_COMM_BACKEND"] = backend
+        lib = capi.load_library()
+        self.lib = lib
+        self.comm = capi.c_void_p()
+        capi.check(lib.qd_comm_create_from_file(path.encode(), rank, world, local_rank, float(timeout_s), capi.byref(self.comm)), "qd_comm_create_from_file")
+        self._world = world
+        self.path = path
+
+    def is_rccl(self):
+        return int(self.lib.qd_comm_backend(self.comm)) == 0
+
+    def describe(self):
+        how = ("RCCL ncclAllReduce called from libquandary_amd.so (qd_comm_*), device buffers on the handle's stream" if self.is_rccl() else
+               "host shared-memory all-reduce inside libquandary_amd.so, same call sites as the RCCL backend")
+        return how + "; bootstrap through a file (qd_comm_create_from_file), no torch.distributed"
+
+    def barrier(self):
+        from . import capi
+
+        capi.check(self.lib.qd_comm_barrier(self.comm), "qd_comm_barrier")
+
+    def self_check(self):
+        """Eight doubles through the communicator before any sweep: sum and max over the ranks against their closed forms."""
+        world, rank = self.world_size(), int(self.lib.qd_comm_rank(self.comm))
+        v = np.array([rank + 1.0, 1.0, (rank + 1.0) ** 2, -rank, 0.5, 1e-300 * (rank + 1), 1e300, float(rank == 0)])
+        s = self.allreduce_sum(v)
+        m = self.allreduce_max(v)
+        n = float(world)
+        want_s = np.array([n * (n + 1) / 2, n, n * (n + 1) * (2 * n + 1) / 6, -n * (n - 1) / 2, 0.5 * n, 1e-300 * n * (n + 1) / 2, 1e300 * n, 1.0])
+        want_m = np.array([n, 1.0, n * n, 0.0, 0.5, 1e-300 * n, 1e300, 1.0])
+        ok = bool(np.allclose(s, want_s, rtol=1e-14, atol=0.0) and np.array_equal(m, want_m))
+        return ok, {"sum": s.tolist(), "max": m.tolist()}
+
+    def close(self):
+        if self.comm:
+            self.lib.qd_comm_destroy(self.comm)
+            self.comm = None
+
+
 def make_comm(backend, rank, world, local_rank=0, allow_fallback=False):
     if backend == "host":
         return HostComm(rank, world, local_rank)

@@ -70,7 +70,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("kw,world,options", CASES)
-def test_fused_evaluation_with_several_ranks_sharing_the_gpu(kw, world, options):
+def test_fused_evaluation_with_several_ranks_sharing_the_gpu(kw, world, options, monkeypatch):
     import multiprocessing as mp
 
     from quandary_amd import capi, config
@@ -79,7 +79,7 @@ def test_fused_evaluation_with_several_ranks_sharing_the_gpu(kw, world, options)
     precision = kw.pop("precision", "f64")
     options = dict(options, precision=precision)
     if world > 2:
-        os.environ["QD_DEVICE_SHARERS"] = str(world)  # (inherited by the spawned ranks: scheduler time limit of the time-sliced sweeps)
+        monkeypatch.setenv("QD_DEVICE_SHARERS", str(world))  # (inherited by the spawned ranks: scheduler time limit of the time-sliced sweeps; restored after the test)
     cfg_text = synthetic_cfg(**{"ntime": 25, **kw})
     sp = config.build_spec(config.parse_config_text(cfg_text))
     sp.precision = precision

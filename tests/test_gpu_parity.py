@@ -1417,7 +1417,7 @@ def test_rccl_single_rank_communicator_device_resident_path():
 def test_bench_two_ranks_matches_one_rank():
     """`python bench.py --gpus 2` starts its two ranks itself (no launcher), splits the initial conditions (strong scaling)
     and prints the same objective as the one-GPU run.  With fewer than two GPUs visible the ranks share the device and
-    the collectives go through gloo (RCCL refuses two ranks on one device); the log is kept in gpurun_out/."""
+    the collectives go through the library's shared-memory backend (RCCL refuses two ranks on one device); the log is kept in gpurun_out/."""
     import json
     import os
     import subprocess
@@ -1439,6 +1439,10 @@ def test_bench_two_ranks_matches_one_rank():
     assert res[2]["config"]["ninit_per_gpu"] * 2 == res[1]["config"]["ninit"]
     assert res[2]["config"]["objective"] == pytest.approx(res[1]["config"]["objective"], rel=1e-12)
     assert set(res[2]["allreduce_ms_per_step"]) == {"objective_sums", "gradient"}
+    # [r6] the ranks find each other through the library's own file bootstrap (no torch.distributed), eight doubles cross the communicator
+    # before the first sweep, and the multi-rank line validates itself against the CPU oracle (shard 0 on a small sample)
+    assert "qd_comm_create_from_file" in res[2]["dist_backend"] and res[2]["allreduce_self_check"].endswith("ok")
+    assert res[2]["oracle_check"]["max_err_rel_to_max1"] <= res[2]["oracle_check"]["tol"]
     # the default invocation: the forward sweep is the timed step on any number of GPUs (one series), the gradient evaluation is
     # timed in the same run and reported next to it with its own one-GPU point
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "1",
