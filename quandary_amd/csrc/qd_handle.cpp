@@ -137,6 +137,7 @@ extern "C" int qd_create(const qd_system* sys, const qd_controls* ctl, const qd_
   }
   S.N = (int)N;
   S.dim = (int)dim;
+  h->poly_cur = h->poly_start();
   for (int k = 0; k < S.Q; k++) {
     S.post[k] = 1;
     for (int j = k + 1; j < S.Q; j++) S.post[k] *= S.n[j];
@@ -392,7 +393,7 @@ extern "C" int qd_set_option(qd_handle* h, const char* key, const char* value) {
   h->sub_latch = -1;
   if (std::string(key) == "gmres_poly") {  // (any setting of the degree starts the tuner over: `auto` re-tunes at the current parameters)
     h->poly_frozen = false;
-    h->poly_cur = 6;
+    h->poly_cur = h->poly_start();
     h->poly_lo = 1;
     h->poly_hi = 0;
     h->poly_steps = 0;
@@ -696,7 +697,10 @@ int qd_handle::gmres_poly_degree() const {
   const int want = opts.gmres_poly > 0 ? opts.gmres_poly : poly_cur;  // tuned in forward_finish
   // only where the Krylov basis traffic is the cost (dim > 1024: the column / eight-elements-per-thread kernels); below
   // that plain GMRES keeps the oracle's iteration path, and with it results that agree far below the solver tolerance
-  if (want <= 1 || S.dense || S.dim <= 1024) return 1;
+  // [r6] ... except on the lean slot kernels (2^4 / 2^5 Lindblad, fp64): their Krylov solver takes the whole solve in ONE preconditioned
+  // vector and one reduction (Team32::kry1, qd_q32.hip) - faster than the stationary iteration it is asked instead of
+  const bool slot_kry = precision == QD_PRECISION_F64 && lean64_available(S, opts) && !S.hasJ;
+  if (want <= 1 || S.dense || (S.dim <= 1024 && !slot_kry)) return 1;
   double dg, of;
   row_bounds(&dg, &of);
   double amax = 0.0;
@@ -801,7 +805,7 @@ bool qd_handle::adjoint_reads_states(int nb, const qd::DevTarget* tgp) const {
   bool leak = false;
   for (int k = 0; k < S.Q; k++)
     if (pen_on && S.ness[k] < S.n[k]) leak = true;
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && !((S.Q == 4 || S.hasJ) && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && !(S.hasJ && cfg.gmres);
   if (precision == QD_PRECISION_F32MIXED || lean64) return wj || leak;
   if (use_col(cfg)) return (wj && tgp->objective_type != QD_OBJ_JMEASURE) || leak;
   return true;
@@ -960,7 +964,8 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     last_poly = 1;
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
-  if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
+  // (the fp32-mixed GMRES and the fp64 one of the lean slot kernels always keep their basis in global memory)
+  if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && !S.hasJ && sol.stepper != QD_STEPPER_EE)))) {
     if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
@@ -968,7 +973,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
   // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !((S.Q == 4 || S.hasJ) && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.hasJ && cfg.gmres);
   if (a.ztraj) ztraj_fmt = precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0;
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, opts, stream));
@@ -1187,14 +1192,15 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     last_poly = 1;
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
-  if (cfg.gmres == 2 || (cfg.gmres && precision == QD_PRECISION_F32MIXED)) {  // (the fp32-mixed GMRES always keeps its basis in global memory)
+  // (the fp32-mixed GMRES and the fp64 one of the lean slot kernels always keep their basis in global memory)
+  if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && !S.hasJ && sol.stepper != QD_STEPPER_EE)))) {
     if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
   // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !((S.Q == 4 || S.hasJ) && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.hasJ && cfg.gmres);
   if (a.ztraj && ztraj_fmt != (precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0))
     return fail(QD_ERR_STATE, "qd_adjoint: the primal stages were stored by another kernel family (options or precision changed since the forward sweep): repeat the forward sweep");
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));

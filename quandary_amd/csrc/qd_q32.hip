@@ -1018,10 +1018,81 @@ struct Team32 {
     return napp;
   }
 
+  // [r6] GMRES right-preconditioned with the Neumann polynomial P = sum_{i<p} (alpha M)^i, one Krylov vector (fp64 sweeps, A.gmres_poly =
+  // p > 1; as ColTeam::kry_solve of qd_col.hip): z = P b by Horner's rule - the Neumann pass y <- b + alpha M y, p - 1 times, WITHOUT its
+  // reduction - then one application w = (I - alpha M) z fused with <b,b>, <r,b>, <r,r> of r = b - w in ONE workgroup reduction:
+  // h_00 = 1 - a, a = <r,b> / <b,b>, h_10^2 = <r,r> / <b,b> - a^2, y = h_00 / (h_00^2 + h_10^2) z, residual = ||b|| h_10 / sqrt(h_00^2 + h_10^2)
+  // against max(rtol ||b||, abstol) (KSPGMRES, src/timestepper.cpp:541-550).  The true residual of the accepted solution is tested - the
+  // reference's rule - with one reduction per solve where the stationary iteration needs one per pass.  Returns a negative value where one
+  // vector does not reach the tolerance (the caller then runs the plain GMRES from scratch).
+  template <bool TRANS>
+  __device__ __forceinline__ int kry1(const SweepArgs& A, R alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
+    const int poly = A.gmres_poly;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) y[j] = b[j];
+    publish(y);
+    for (int m = 1; m < poly; m++) {
+      const f2* src = vec();
+      f2* dst = buf + (cur ^ 1) * DIM;
+      f2 w[EPT];
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const f2 t = st.template apply<TRANS>(src, j, y);
+        w[j].x = rfma(alpha, t.x, b[j].x);
+        w[j].y = rfma(alpha, t.y, b[j].y);
+        dst[elem(j)] = w[j];
+        q32_fence<EPT>(j);
+      }
+#pragma unroll
+      for (int j = 0; j < EPT; j++) y[j] = w[j];
+      team_sync<ONEWAVE>();
+      cur ^= 1;
+    }
+    double d[3] = {0.0, 0.0, 0.0};
+    {
+      const f2* src = vec();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const f2 t = st.template apply<TRANS>(src, j, y);
+        const double rx = (double)b[j].x - (double)rfma(-alpha, t.x, y[j].x), ry = (double)b[j].y - (double)rfma(-alpha, t.y, y[j].y);
+        d[0] = fma((double)b[j].x, (double)b[j].x, fma((double)b[j].y, (double)b[j].y, d[0]));
+        d[1] = fma(rx, (double)b[j].x, fma(ry, (double)b[j].y, d[1]));
+        d[2] = fma(rx, rx, fma(ry, ry, d[2]));
+        q32_fence<EPT>(j);
+      }
+    }
+    sum<3>(d);
+    const double bb = d[0], ttol2 = fmax(A.reltol * A.reltol * bb, A.abstol * A.abstol);
+    double fac;
+    if (bb <= ttol2) {
+      fac = 0.0;  // ||b|| <= tolerance: KSP returns the zero initial guess
+    } else {
+      const double ibb = 1.0 / bb, a = d[1] * ibb, h00 = 1.0 - a, h10sq = fmax(fma(-a, a, d[2] * ibb), 0.0), den = fma(h00, h00, h10sq);
+      if (!(bb * h10sq <= ttol2 * den || A.maxiter <= 1) || !(h00 > 0.0)) return -1;
+      fac = h00 / den;
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      y[j].x = (R)fac * y[j].x;
+      y[j].y = (R)fac * y[j].y;
+    }
+    return poly;
+  }
+
   template <bool TRANS>
   __device__ __forceinline__ int solve(const SweepArgs& A, R alpha, const f2 (&b)[EPT], f2 (&y)[EPT]) {
-    if constexpr (GM) return gmres<TRANS>(A, alpha, b, y);
-    else return neumann<TRANS>(A, alpha, b, y);
+    if constexpr (GM) {
+      if constexpr (!F32) {
+        if (A.gmres_poly > 1) {
+          const int n = kry1<TRANS>(A, alpha, b, y);
+          if (n >= 0) return n;
+          return A.gmres_poly + gmres<TRANS>(A, alpha, b, y);
+        }
+      }
+      return gmres<TRANS>(A, alpha, b, y);
+    } else {
+      return neumann<TRANS>(A, alpha, b, y);
+    }
   }
 };
 
@@ -1524,14 +1595,14 @@ static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
 hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double, false, true>(a, st);
   if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<5, 1, double, false, true>(a, st);
-  if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves (stationary iterations only)
+  if (a.S.Q == 4) return a.use_gmres ? go_fwd<4, 0, double, true>(a, st) : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves
   if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
   return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
 }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double, false, true>(a, st);
   if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<5, 1, double, false, true>(a, st);
-  if (a.S.Q == 4) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double>(a, st);
+  if (a.S.Q == 4) return a.use_gmres ? go_adj<4, 0, double, true>(a, st) : go_adj<4, 0, double>(a, st);
   if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
   return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);
 }

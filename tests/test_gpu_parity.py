@@ -404,6 +404,32 @@ def test_lean_column_krylov_solver(kw, dt, poly):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("poly", ["auto", "2", "5"])
+@pytest.mark.parametrize("nq,init", [(4, "diagonal, 0, 1"), (5, "diagonal, 0, 1, 2")])
+def test_slot_kernel_krylov_solver(nq, init, poly):
+    """[r6] linearsolver_type = gmres on the lean slot kernels (2^4 / 2^5 Lindblad, fp64; option gmres_split = 0): GMRES right-preconditioned
+    with the Neumann polynomial, the whole solve in one Krylov vector and one reduction (Team32::kry1, qd_q32.hip).  Tuned degree, a degree
+    that is too low (2: the one-vector residual misses the tolerance and the plain GMRES takes over from scratch) and one that is too high
+    (5); objective parts and gradient against the oracle's GMRES, application counts as the degree implies."""
+    sp = synthetic_spec([2] * nq, lindblad=True, init=init, ntime=40, linsolve="gmres", penalties=True)
+    sp.options = {"gmres_split": "0", "gmres_poly": poly}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    for _ in range(5 if poly == "auto" else 1):  # (the degree settles within a few sweeps)
+        val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == "krylov"
+    oval, og = orc.evalGradF(sp.params0)
+    assert check_parity(sp, val, g, oval, og, msg=(nq, poly)) == "plain"
+    opt.evalF(sp.params0)
+    if poly == "5":
+        assert h.mean_applies == pytest.approx(6.0, abs=1e-9)  # b = M x, four passes of Horner's rule, the application that tests the residual
+    elif poly == "2":
+        assert h.mean_applies > 5.0  # 1 + 2 + the plain GMRES
+    else:
+        assert 4.0 <= h.mean_applies <= 5.5
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[1], LEANCOL_SHAPES[3]])
 def test_gmres_request_served_by_the_diagonal_split_iteration(kw):
     """linearsolver_type = gmres on the systems of the lean column kernels (default: option gmres_split = auto): the diagonal-split
