@@ -408,6 +408,10 @@ EXTRA = [
     ("q4", "fwd", "neumann", "f32mixed", {}, 20, {}),
     ("q4j", "fwd", "neumann", "f64", {}, 20, {}),  # the dipole-dipole coupling stencil measured
     ("c5j", "fwd", "neumann", "f64", {}, 2, {}),  # the same on the 2^5 system (lean kernel with the coupling terms [r5])
+    ("c5j", "grad", "neumann", "f64", {}, 1, {}),
+    ("q4j", "fwd", "neumann", "f32mixed", {}, 20, {}),  # [r6] the coupled stencils in fp32-mixed
+    ("c5j", "fwd", "neumann", "f32mixed", {}, 3, {}),
+    ("c5j", "grad", "neumann", "f32mixed", {}, 2, {}),
     ("c5", "fwd", "neumann", "f64", {}, 3, {}),
     ("c5", "fwd", "gmres", "f64", {}, 2, {}),
     ("c5", "fwd", "gmres", "f64", {}, 2, {"gmres_split": 0}),
@@ -457,8 +461,8 @@ def extra_entry(wn, wm, ws, wd, wo, wsteps, wopt, local_rank, sync, fp64_peak, w
         ent["o"] = wopt
     try:
         r = Runner(wn, wm, {**wo, "linearsolver_type": ws}, wd, 0, 1, local_rank, False, None, wopt)
-        # (GMRES with the polynomial preconditioner, 3x20 and 20x20: its degree settles within five sweeps)
-        el, km, apl = r.time(wsteps, 6 if (ws == "gmres" and wn in ("c4", "l20")) else 2 if wn in ("q4", "q4j", "c2") else 1, sync)
+        # (GMRES with the polynomial preconditioner - the Krylov kernels of 3x20, 20x20 and [r6] the lean slot kernels: its degree settles within five sweeps)
+        el, km, apl = r.time(wsteps, 6 if (ws == "gmres" and (wn in ("c4", "l20") or (wopt or {}).get("gmres_split") == 0)) else 2 if wn in ("q4", "q4j", "c2") else 1, sync)
         v, rf, cf = r.report(el, km, apl, wsteps, fp64_peak)
         vk = "fp32_valu" if wd == "f32mixed" else "fp64_valu"
         ent.update({"v": _sig(v), "ms": _sig(el / wsteps * 1e3, 4), "kms": _sig(rf["kernel_ms_per_launch"], 4), "A": _sig(apl, 4),

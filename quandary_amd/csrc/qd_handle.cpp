@@ -412,7 +412,8 @@ extern "C" int qd_set_precision(qd_handle* h, int precision) {
     const DevSys& S = h->S;
     bool qubits = S.lindblad && !S.dense && (S.Q == 3 || S.Q == 4 || S.Q == 5);
     for (int k = 0; k < S.Q; k++) qubits = qubits && S.n[k] == 2 && S.ness[k] == 2;
-    if (!qubits || S.hasJ) return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps are built for all-qubit Lindblad systems with 3, 4 or 5 oscillators without dipole-dipole coupling");
+    if (!qubits || (S.hasJ && S.Q == 3))
+      return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps are built for all-qubit Lindblad systems with 3, 4 or 5 oscillators (dipole-dipole coupling: 4 or 5)");
     if (h->sol.stepper == QD_STEPPER_EE)
       return fail(QD_ERR_UNSUPPORTED, "qd_set_precision: the fp32-mixed sweeps need a stepper of the IMR family");
   }
@@ -975,6 +976,8 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.hasJ && cfg.gmres);
   if (a.ztraj) ztraj_fmt = precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0;
+  if (precision == QD_PRECISION_F32MIXED && S.hasJ && a.use_gmres)
+    return fail(QD_ERR_UNSUPPORTED, "fp32-mixed sweeps of a system with dipole-dipole coupling: the Krylov kernels are not built (option gmres_split = 0); linearsolver_type = gmres is served by the stationary iteration where it contracts");
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_forward_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_forward_lean64(a, opts, stream));
   else if (use_col(cfg)) {
@@ -1203,6 +1206,8 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.hasJ && cfg.gmres);
   if (a.ztraj && ztraj_fmt != (precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0))
     return fail(QD_ERR_STATE, "qd_adjoint: the primal stages were stored by another kernel family (options or precision changed since the forward sweep): repeat the forward sweep");
+  if (precision == QD_PRECISION_F32MIXED && S.hasJ && a.use_gmres)
+    return fail(QD_ERR_UNSUPPORTED, "fp32-mixed sweeps of a system with dipole-dipole coupling: the Krylov kernels are not built (option gmres_split = 0)");
   if (precision == QD_PRECISION_F32MIXED) QD_HIP(launch_adjoint_f32(a, opts, stream));
   else if (lean64) QD_HIP(launch_adjoint_lean64(a, opts, stream));
   else if (use_col(cfg)) {

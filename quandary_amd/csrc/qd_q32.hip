@@ -71,8 +71,9 @@ struct Q32 {
   // (eta_kl t) where the two digits differ (else 0), the sine with the sign of the l digit (QubitStencil::apply of qd_device.h:
   // h += J (sin A + cos (B.y, -B.x)), A = +-x_bra +-x_ket, B = x_bra - x_ket)
   static constexpr int NP = Q * (Q - 1) / 2;
-  static constexpr bool JOK = HJ && SB == 0 && sizeof(R) == 8;
-  static_assert(!HJ || (sizeof(R) == 8 && SB <= 1), "coupled systems: fp64, one or two elements per thread");
+  // ([r6] R = float: the same terms on the unpacked fp32 stencil - the fp32-mixed sweeps of the coupled systems)
+  static constexpr bool JOK = HJ && SB == 0;
+  static_assert(!HJ || SB <= 1, "coupled systems: one or two elements per thread");
   unsigned ajb[JOK ? NP : 1], ajk[JOK ? NP : 1];
   R pjs[JOK ? NP : 1], pjc[JOK ? NP : 1], qjs[JOK ? NP : 1], qjc[JOK ? NP : 1];
   // The 2^5 system (two elements per thread, SB == 1: the ket digit of oscillator 0 is the slot) has no room for four coefficients per
@@ -80,7 +81,7 @@ struct Q32 {
   // neighbour whose pair of digits is equal is read from an element that holds zero (Team32 keeps one behind the exchange vectors at the
   // same distance from either of them, for either slot) - and the sign of the sine terms, a property of the digit of oscillator l alone,
   // is applied once per l to the sum over k < l.
-  static constexpr bool JS1 = HJ && SB == 1 && sizeof(R) == 8;
+  static constexpr bool JS1 = HJ && SB == 1;
   static constexpr bool JANY = JOK || JS1;
   static constexpr unsigned ZOFF = 2u * (unsigned)DIM * (unsigned)sizeof(f2);  // the zero element, relative to the vector being read
   unsigned jab[JS1 ? NP : 1], jak[JS1 ? NP : 1][JS1 ? EPT : 1];
@@ -1536,6 +1537,12 @@ static bool small_batch_sb1(const SweepArgs& a, const TuneOpts& o) {
 
 hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q, o);
+  if (a.S.hasJ) {  // [r6] dipole-dipole coupling: the coupled stencils in fp32 (stationary iterations only)
+    if (a.use_gmres) return hipErrorInvalidValue;
+    if (a.S.Q == 5) return go_fwd<5, 1, float, false, true>(a, st);
+    if (a.S.Q == 4) return go_fwd<4, 0, float, false, true>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (a.use_gmres) {  // Krylov basis in global memory as float2, Hessenberg problem in fp64
     if (a.S.Q == 5) return go_fwd<5, 2, float, true>(a, st);
     if (a.S.Q == 4) return go_fwd<4, 0, float, true>(a, st);
@@ -1549,6 +1556,12 @@ hipError_t launch_forward_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t
 }
 hipError_t launch_adjoint_f32(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
   const int sb = q32_slot_bits(a.S.Q, o);
+  if (a.S.hasJ) {
+    if (a.use_gmres) return hipErrorInvalidValue;
+    if (a.S.Q == 5) return go_adj<5, 1, float, false, true>(a, st);
+    if (a.S.Q == 4) return go_adj<4, 0, float, false, true>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (a.use_gmres) {
     if (a.S.Q == 5) return go_adj<5, 2, float, true>(a, st);
     if (a.S.Q == 4) return go_adj<4, 0, float, true>(a, st);
@@ -1568,6 +1581,11 @@ hipError_t launch_apply_f32(const DevSys& S, const double* ctlrow, int transpose
     return hipGetLastError();
   }
   const int sb = q32_slot_bits(S.Q, o);
+  if (S.hasJ) {
+    if (S.Q == 5) return go_app<5, 1, float, true>(S, ctlrow, transpose, x, y, nb, nrep, st);
+    if (S.Q == 4) return go_app<4, 0, float, true>(S, ctlrow, transpose, x, y, nb, nrep, st);
+    return hipErrorInvalidValue;
+  }
   if (S.Q == 5) return go_app<5, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   if (S.Q == 4) return sb == 2 ? go_app<4, 2, float>(S, ctlrow, transpose, x, y, nb, nrep, st) : go_app<4, 0, float>(S, ctlrow, transpose, x, y, nb, nrep, st);
   if (S.Q == 3) return go_app<3, 0, float>(S, ctlrow, transpose, x, y, nb, nrep, st);

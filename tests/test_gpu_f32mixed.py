@@ -104,6 +104,61 @@ def test_f32_gmres_objective_and_gradient_budget_ntime1000(q, init, penalties, g
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("q,detuned", [(4, False), (4, True), (5, False), (5, True)])
+def test_f32_coupled_operator_application(q, detuned):
+    """[r6] Dipole-dipole coupling in fp32-mixed (include/mastereq.hpp:632-741 for two levels; Q32<Q, SB, float, HJ> of qd_q32.hip): rotating
+    frames 0.1 GHz apart (eta_kl != 0: cosine and sine terms) and all at 4.1 GHz (eta = 0, detuned qubits), a different J on every pair."""
+    sp = synthetic_spec([2] * q, lindblad=True, ntime=10, dt=0.01, nspline=30, init="diagonal, 0", jkl=0.004, detuned=detuned)
+    npairs = q * (q - 1) // 2
+    for i in range(npairs):
+        sp.system.Jkl[i] *= 1.0 + 0.37 * i
+    sp.precision = "f32mixed"
+    h, orc = capi.Handle(sp), Oracle(sp)
+    h.set_params(sp.params0)
+    orc.set_params(sp.params0)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 2 * h.dim))
+    for t in (0.037, 0.083):
+        for tr in (False, True):
+            y, yo = h.apply_rhs(t, x, transpose=tr), orc.apply_rhs(t, x, transpose=tr)
+            assert np.abs(y - yo).max() <= APPLY_TOL * np.abs(yo).max(), (t, tr)
+    h.close(); orc.close()
+
+
+@pytest.mark.parametrize("q,init,penalties,detuned", [(4, "basis, 0, 1", True, False), (4, "diagonal, 0, 1", False, True), (5, "diagonal, 0", False, False), (5, "basis, 4", True, False)])
+def test_f32_coupled_objective_and_gradient_budget_ntime1000(q, init, penalties, detuned):
+    """[r6] The fp32-mixed budget with J_kl != 0 (and eta_kl != 0 where the rotating frames differ) over ntime = 1000 - the c5j / q4j
+    workloads' length - against the fp64 oracle; a gmres request is served by the stationary iteration there, the Krylov kernels are
+    refused (not built for the coupled stencils)."""
+    sp = synthetic_spec([2] * q, lindblad=True, ntime=1000, dt=0.01, nspline=30, init=init, penalties=penalties, jkl=0.001, detuned=detuned)
+    orc = Oracle(sp)
+    oval, og = orc.evalGradF(sp.params0)
+    sp.precision = "f32mixed"
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    errs = {"objective_rel": abs(val["objective"] - oval["objective"]) / abs(oval["objective"]),
+            "fidelity_abs": abs(val["fidelity"] - oval["fidelity"]),
+            "gradient_rel_norm": float(np.linalg.norm(g - og) / np.linalg.norm(og)),
+            "rhs_applications_per_step": h.mean_applies}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "f32_errors.jsonl"), "a") as f:
+        f.write(json.dumps({"q": q, "init": init, "penalties": penalties, "coupled": True, "detuned": detuned, **errs}) + "\n")
+    assert errs["objective_rel"] <= OBJ_RTOL, errs
+    assert errs["fidelity_abs"] <= FID_ATOL, errs
+    # (all frames at 4.1 GHz: qubits detuned by up to 0.3 GHz - |Delta| 1.9 rad/ns against ~0.03 of the controls, five applications per step
+    #  instead of four; the fp32 products of Delta x dominate the budget there: 9e-7 measured, the short-trajectory tolerance applies)
+    assert errs["gradient_rel_norm"] <= (GRAD_TOL_SHORT if detuned else GRAD_TOL), errs
+    opt.close(); h.close(); orc.close()
+    sp.solver.linsolve = capi.LINSOLVE["gmres"]
+    sp.options = {"gmres_split": "0"}
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    with pytest.raises(capi.QuandaryAmdError, match="Krylov kernels are not built"):
+        opt.evalF(sp.params0)
+    opt.close(); h.close()
+
+
 def test_f32_compositional_stepper_and_trajectory():
     """IMR4 sub-steps and the fp32 trajectory store (qd_get_state converts back to the reference layout)."""
     sp = _spec(4, "diagonal, 0, 1", 40, penalties=True, stepper="IMR4")
