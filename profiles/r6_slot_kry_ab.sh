@@ -12,3 +12,10 @@ for w in c5 q4; do
   run $w grad neumann
   run $w grad gmres --option gmres_split=0
 done
+for w in c5j q4j; do
+  run $w fwd neumann
+  run $w fwd gmres
+  run $w fwd gmres --option gmres_split=0 --option gmres_poly=1
+  run $w fwd gmres --option gmres_split=0
+  run $w grad gmres --option gmres_split=0
+done

@@ -700,7 +700,7 @@ int qd_handle::gmres_poly_degree() const {
   // that plain GMRES keeps the oracle's iteration path, and with it results that agree far below the solver tolerance
   // [r6] ... except on the lean slot kernels (2^4 / 2^5 Lindblad, fp64): their Krylov solver takes the whole solve in ONE preconditioned
   // vector and one reduction (Team32::kry1, qd_q32.hip) - faster than the stationary iteration it is asked instead of
-  const bool slot_kry = precision == QD_PRECISION_F64 && lean64_available(S, opts) && !S.hasJ;
+  const bool slot_kry = precision == QD_PRECISION_F64 && lean64_available(S, opts);
   if (want <= 1 || S.dense || (S.dim <= 1024 && !slot_kry)) return 1;
   double dg, of;
   row_bounds(&dg, &of);
@@ -806,7 +806,7 @@ bool qd_handle::adjoint_reads_states(int nb, const qd::DevTarget* tgp) const {
   bool leak = false;
   for (int k = 0; k < S.Q; k++)
     if (pen_on && S.ness[k] < S.n[k]) leak = true;
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && !(S.hasJ && cfg.gmres);
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts);
   if (precision == QD_PRECISION_F32MIXED || lean64) return wj || leak;
   if (use_col(cfg)) return (wj && tgp->objective_type != QD_OBJ_JMEASURE) || leak;
   return true;
@@ -966,15 +966,15 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
   // (the fp32-mixed GMRES and the fp64 one of the lean slot kernels always keep their basis in global memory)
-  if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && !S.hasJ && sol.stepper != QD_STEPPER_EE)))) {
+  if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE)))) {
     if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
   if (!napply_zeroed) QD_HIP(hipMemsetAsync(d_napply, 0, sizeof(unsigned long long), stream));
   QD_HIP(hipEventRecord(ev0, stream));
-  // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.hasJ && cfg.gmres);
+  // (2^4 / 2^5 Lindblad: the lean slot kernels, coupled or not; their Krylov solver keeps its basis in global memory [r6])
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
   if (a.ztraj) ztraj_fmt = precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0;
   if (precision == QD_PRECISION_F32MIXED && S.hasJ && a.use_gmres)
     return fail(QD_ERR_UNSUPPORTED, "fp32-mixed sweeps of a system with dipole-dipole coupling: the Krylov kernels are not built (option gmres_split = 0); linearsolver_type = gmres is served by the stationary iteration where it contracts");
@@ -1196,14 +1196,14 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
     last_team = cfg.var == 16 && cfg.team > 1 && precision != QD_PRECISION_F32MIXED ? cfg.team : 1;
   }
   // (the fp32-mixed GMRES and the fp64 one of the lean slot kernels always keep their basis in global memory)
-  if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && !S.hasJ && sol.stepper != QD_STEPPER_EE)))) {
+  if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE)))) {
     if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
   QD_HIP(hipEventRecord(ev2, stream));
-  // (2^4: the lean kernels for the stationary iterations only - their Krylov variant keeps the basis in global memory, the general one in LDS)
-  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE && !(S.hasJ && cfg.gmres);
+  // (2^4 / 2^5 Lindblad: the lean slot kernels, coupled or not; their Krylov solver keeps its basis in global memory [r6])
+  const bool lean64 = cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE;
   if (a.ztraj && ztraj_fmt != (precision == QD_PRECISION_F32MIXED ? 1 : lean64 ? 2 : use_col(cfg) ? 3 : 0))
     return fail(QD_ERR_STATE, "qd_adjoint: the primal stages were stored by another kernel family (options or precision changed since the forward sweep): repeat the forward sweep");
   if (precision == QD_PRECISION_F32MIXED && S.hasJ && a.use_gmres)

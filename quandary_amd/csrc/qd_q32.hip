@@ -634,7 +634,7 @@ struct Team32 {
   static constexpr size_t acc_off() {
     return ST::JS1 ? 7 * (sizeof(f2) * DIM / 2) + 16 : 2 * sizeof(f2) * DIM + 2 * sizeof(double) * NRED * NW;
   }
-  static_assert(!ST::JS1 || (ZPAD + 2 * sizeof(double) * NRED * NW <= sizeof(f2) * DIM / 2 && !GM && EPT == 2), "layout of the coupled 2^5 kernels");
+  static_assert(!ST::JS1 || (ZPAD + 2 * sizeof(double) * NRED * NW <= sizeof(f2) * DIM / 2 && EPT == 2), "layout of the coupled 2^5 kernels");
   static size_t lds_bytes() {
     return acc_off() + (PARK ? sizeof(double2) * DIM : 0) + (GM ? sizeof(double) * gmres_nsc(GMRES_MR_G) : 0);
   }
@@ -1611,15 +1611,16 @@ static int lean64_sb(const SweepArgs& a, const TuneOpts& o) {
   return a.nb <= 256 ? 1 : 2;
 }
 hipError_t launch_forward_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
-  if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<4, 0, double, false, true>(a, st);
-  if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_fwd<5, 1, double, false, true>(a, st);
+  // ([r6] the Krylov solver of these kernels - Team32::kry1 in front of the plain GMRES - also on the coupled stencils)
+  if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? go_fwd<4, 0, double, true, true>(a, st) : go_fwd<4, 0, double, false, true>(a, st);
+  if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? go_fwd<5, 1, double, true, true>(a, st) : go_fwd<5, 1, double, false, true>(a, st);
   if (a.S.Q == 4) return a.use_gmres ? go_fwd<4, 0, double, true>(a, st) : go_fwd<4, 0, double>(a, st);  // 2^4: one element per thread, four waves
   if (lean64_sb(a, o) == 1) return go_fwd<5, 1, double>(a, st);
   return a.use_gmres ? go_fwd<5, 2, double, true>(a, st) : go_fwd<5, 2, double>(a, st);
 }
 hipError_t launch_adjoint_lean64(const SweepArgs& a, const TuneOpts& o, hipStream_t st) {
-  if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<4, 0, double, false, true>(a, st);
-  if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? hipErrorInvalidValue : go_adj<5, 1, double, false, true>(a, st);
+  if (a.S.Q == 4 && a.S.hasJ) return a.use_gmres ? go_adj<4, 0, double, true, true>(a, st) : go_adj<4, 0, double, false, true>(a, st);
+  if (a.S.Q == 5 && a.S.hasJ) return a.use_gmres ? go_adj<5, 1, double, true, true>(a, st) : go_adj<5, 1, double, false, true>(a, st);
   if (a.S.Q == 4) return a.use_gmres ? go_adj<4, 0, double, true>(a, st) : go_adj<4, 0, double>(a, st);
   if (lean64_sb(a, o) == 1) return go_adj<5, 1, double>(a, st);
   return a.use_gmres ? go_adj<5, 2, double, true>(a, st) : go_adj<5, 2, double>(a, st);
