@@ -49,6 +49,21 @@ def main():
         d["avg_ms_full_grid"] = sum(full) / len(full)
         d["n_full_grid"] = len(full)
         d["total_ms_full_grid"] = sum(full)  # (a chunked gradient evaluation launches each sweep once per chunk: divide by the evaluations)
+    # [r6] the TIMED launches of a one-launch-per-evaluation command: the last `steps` full-grid launches in front of the oracle check's small
+    # one (the warm-up launches of a gmres run tune the preconditioner's degree and differ from one another) - min, max and mean of those
+    try:
+        line = json.loads([l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")][-1])
+        steps = int(line["steps"])
+        for d in launches.values():
+            gmax = max(d["grid_x"])
+            full = [t for t, g in zip(d["durations_ms"], d["grid_x"]) if g == gmax]
+            if len(full) >= steps and len(full) <= steps + int(line["warmup"]) + 1:  # (one launch per evaluation)
+                timed = full[-steps:] if len(full) == steps + int(line["warmup"]) else full[-steps - 1:-1]
+                d["timed_launches_ms"] = timed
+                d["timed_min_ms"], d["timed_max_ms"], d["timed_avg_ms"] = min(timed), max(timed), sum(timed) / len(timed)
+                d["timed_max_over_min"] = max(timed) / min(timed)
+    except Exception:
+        pass
     res["sweep_launches"] = launches
     pmc = {}
     for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):

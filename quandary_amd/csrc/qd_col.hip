@@ -856,7 +856,7 @@ struct ColTeam {
     }
     sum_rows<3>(d);
     const double fac = kry_one_vector(A, d);
-    if (fac >= 0.0) {
+    if (__builtin_expect(fac >= 0.0, 1)) {
 #pragma unroll
       for (int j = 0; j < EPT; j++) y[j] = make_double2(fac * y[j].x, fac * y[j].y);
       return poly;
@@ -926,7 +926,7 @@ struct ColTeam {
     }
     sum_rows<3>(d);
     const double fac = kry_one_vector(A, d);
-    if (fac >= 0.0) {
+    if (__builtin_expect(fac >= 0.0, 1)) {
 #pragma unroll
       for (int j = 0; j < EPT; j++) z[j] = make_double2(fma(fac, z[j].x - x[j].x, x[j].x), fma(fac, z[j].y - x[j].y, x[j].y));
       return poly + 1;
