@@ -1351,8 +1351,8 @@ int col_slices(int nb, int ntime, const TuneOpts& o) {
 }
 
 // SweepArgs::kry of the Krylov kernels: GMRES_MR_G + 2 padded scratch vectors per RESIDENT workgroup (ColTeam::init_kry), in doubles
-// (a sweep without time slices starts one workgroup per initial condition)
-size_t col_krylov_doubles(int nb, bool sliced) { return (size_t)(sliced ? std::min(nb, 2 * col_cu_count()) : nb) * (GMRES_MR_G + 2) * 2 * KRY_VEC; }
+// (a sweep without time slices starts one workgroup per initial condition, a sliced one a resident grid: col_grid)
+size_t col_krylov_doubles(int nb, int nslice) { return (size_t)(nslice > 1 ? std::min(nb * nslice, 2 * col_cu_count()) : nb) * (GMRES_MR_G + 2) * 2 * KRY_VEC; }
 
 template <typename K>
 static hipError_t set_lds_col(K kern, size_t bytes) {

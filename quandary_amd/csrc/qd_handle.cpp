@@ -967,7 +967,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   }
   // (the fp32-mixed GMRES and the fp64 one of the lean slot kernels always keep their basis in global memory)
   if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE)))) {
-    if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
+    if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts)) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;
@@ -1197,7 +1197,7 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   }
   // (the fp32-mixed GMRES and the fp64 one of the lean slot kernels always keep their basis in global memory)
   if (cfg.gmres == 2 || (cfg.gmres && (precision == QD_PRECISION_F32MIXED || (cfg.var != 16 && lean64_available(S, opts) && sol.stepper != QD_STEPPER_EE)))) {
-    if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts) > 1) : krylov_doubles(S, nb)))) return r;
+    if ((r = d_kry.ensure(use_col(cfg) ? col_krylov_doubles(nb, col_slices(nb, tg.ntime, opts)) : krylov_doubles(S, nb)))) return r;
     a.kry = d_kry.p;
   }
   if ((r = check_cfg(cfg))) return r;

@@ -217,7 +217,7 @@ hipError_t launch_apply_lean64(const DevSys& S, const double* ctlrow, int transp
 // lean column kernels (qd_col.hip): Lindblad Neumann sweeps of density matrices with 33..64 rows and runtime level counts
 bool collean_available(const DevSys& S, const TuneOpts& o);
 int col_slices(int nb, int ntime, const TuneOpts& o);  // time slices of a lean column sweep (1 = none)
-size_t col_krylov_doubles(int nb, bool sliced);  // size of SweepArgs::kry for the Krylov solver of the lean column kernels
+size_t col_krylov_doubles(int nb, int nslice);  // size of SweepArgs::kry for the Krylov solver of the lean column kernels
 hipError_t launch_forward_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_adjoint_col(const SweepArgs& a, const TuneOpts& o, hipStream_t st);
 hipError_t launch_apply_col(const DevSys& S, const double* ctlrow, int transpose, const double* x, double* y, int nb, const TuneOpts& o, hipStream_t st);

@@ -404,6 +404,35 @@ def test_lean_column_krylov_solver(kw, dt, poly):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("poly", ["auto", "2"])
+@pytest.mark.parametrize("stepper,ntime", [("IMR4", 7), ("IMR8", 3)])
+@pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[2], LEANCOL_SHAPES[3]])
+def test_lean_column_krylov_solver_composite_steps_and_time_slices(kw, stepper, ntime, poly):
+    """[r6] The Krylov solver of the lean column kernels under composite steps (sub-steps of different, also negative, size: the
+    preconditioner's diagonal factor follows the step size) and time-sliced scheduling (the sliced sweep repeats the unsliced one bit for
+    bit - the solver carries nothing from step to step), one-vector path (tuned degree) and generic path (degree 2), five and eight
+    columns per wave, two and three oscillators, guard levels: against the oracle's GMRES."""
+    sp = synthetic_spec(**{**kw, "ntime": ntime, "penalties": True, "stepper": stepper, "dt": 0.002, "linsolve": "gmres"})
+    sp.options = {"gmres_split": "0", "gmres_poly": poly, "col_slices": 3}
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == "krylov"
+    oval, og = orc.evalGradF(sp.params0)
+    check_parity(sp, val, g, oval, og, msg=(kw, stepper, poly))
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(opt.ninit_local)])
+    h.set_params(sp.params0)
+    res = h.forward(x0)
+    h.set_option("col_slices", 1)
+    h.set_option("gmres_poly", poly)  # (fixed degree: the same path; `auto` starts its tuner over at the same first degree)
+    ref = h.forward(x0)
+    if poly != "auto":
+        np.testing.assert_array_equal(res["final_states"], ref["final_states"])
+    else:
+        np.testing.assert_allclose(res["final_states"], ref["final_states"], rtol=0, atol=1e-12)
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("poly", ["auto", "2", "5"])
 @pytest.mark.parametrize("nq,init", [(4, "diagonal, 0, 1"), (5, "diagonal, 0, 1, 2")])
 def test_slot_kernel_krylov_solver(nq, init, poly):
