@@ -653,7 +653,7 @@ struct ColTeam {
     const double ttol2 = fmax(A.reltol * A.reltol * bb, A.abstol * A.abstol);
     if (bb <= ttol2) return 0.0;  // ||b|| <= tolerance: KSP returns the zero initial guess
     const double ibb = 1.0 / bb, a = ab * ibb, h00 = 1.0 - a, h10sq = fmax(fma(-a, a, ss * ibb), 0.0), den = fma(h00, h00, h10sq);
-    const bool conv = bb * h10sq <= ttol2 * den || A.maxiter <= 1;
+    const bool conv = bb * h10sq <= A.kry_tau2 * ttol2 * den || A.maxiter <= 1;  // (kry_tau: SweepArgs)
     return conv ? h00 / den : -1.0;
   }
 
@@ -676,7 +676,10 @@ struct ColTeam {
       for (int j = 0; j < EPT; j++) t1[0] = fma(v[j].x, v[j].x, fma(v[j].y, v[j].y, t1[0]));
       sum_rows<1>(t1);
       const double ibeta = t1[0] > 0.0 ? rsqrt_nr(t1[0]) : 0.0, beta = t1[0] * ibeta;
-      if (cycle == 0) ttol = fmax(A.reltol * beta, A.abstol);
+      // (the acceptance factor of the one-vector path - SweepArgs::kry_tau2 - here as well: a preconditioned vector takes the residual down
+      //  by the contraction of p passes at once, but the LAST one of a solve lands anywhere below the tolerance; held to kry_tau x the
+      //  tolerance the generic path is as accurate as the reference's GMRES typically is, profiles/r6_kry_seed_sweep.txt)
+      if (cycle == 0) ttol = sqrt(A.kry_tau2) * fmax(A.reltol * beta, A.abstol);
 #pragma unroll
       for (int j = 0; j < EPT; j++) y[j] = make_double2(0.0, 0.0);
       if (beta <= ttol || its >= A.maxiter) break;

@@ -850,6 +850,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.rel2 = (float)(a.reltol * a.reltol);
   a.gmres_poly = h->gmres_poly_degree();
   a.col_noskip = !h->opts.col_skip;
+  a.kry_tau2 = h->opts.krylov_tau * h->opts.krylov_tau;
   a.nslice = 1;
   a.neumann_split = h->neumann_split_on();
   // penalties that need target data are only active when a target has been set
@@ -932,6 +933,7 @@ int qd_handle::forward_launch(const double* dx0, int nb, bool store, const DevTa
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
   last_poly = a.gmres_poly;
+  fwd_poly = a.gmres_poly;
   a.x0 = dx0;
   a.xT = d_xT.p;
   a.traj = full ? d_traj.p : nullptr;
@@ -1162,6 +1164,8 @@ int qd_handle::adjoint_launch(const double* dxbarT, const double* djbar, int nb,
   if ((r = ensure_wj_weights())) return r;
   SweepArgs a;
   fill_sweep(this, a, nb, tgp);
+  // (the adjoint sweep of an evaluation runs on the degree its forward sweep ran on: the tuner moves between the two, forward_finish)
+  if (opts.gmres_poly == 0 && fwd_poly > 1 && a.gmres_poly > 1) a.gmres_poly = fwd_poly;
   last_poly = a.gmres_poly;
   const bool have_states = pending_store ? pending_full : traj_full;
   if (!have_states && adjoint_reads_states(nb, tgp))

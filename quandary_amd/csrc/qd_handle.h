@@ -158,6 +158,7 @@ struct qd_handle {
   int gmres_poly_degree() const;  // > 1 where the Neumann series provably contracts for the current parameters, else 1
   // degree of the polynomial preconditioner, tuned from sweep to sweep (forward_finish): smallest degree with one Krylov vector per solve
   int poly_cur = 6, poly_lo = 1, poly_hi = 0, last_poly = 1, last_var = 0, poly_steps = 0;
+  int fwd_poly = 0;  // degree the last forward sweep ran on (the adjoint sweep of the same evaluation keeps it)
   int poly_start() const { return S.dim <= 1024 ? 3 : 6; }  // first degree the tuner tries (small systems contract fast)
   int poly_slow = 0;         // consecutive sweeps of a frozen degree with more than 1.5 Krylov vectors per solve
   bool poly_frozen = false;  // the bracket has closed: the degree no longer changes (reproducible evaluations)

@@ -561,7 +561,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // options
 // ---------------------------------------------------------------------------------------------
 static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "big_blocked", "f32_sb", "lean64_sb", "no_lean64", "no_collean",
-                                       "col_ept", "col_slices", "no_plain", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb", "standin_tau", "sched_wait_s", "col_skip", "no_col_krylov"};
+                                       "col_ept", "col_slices", "no_plain", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb", "standin_tau", "sched_wait_s", "col_skip", "no_col_krylov", "krylov_tau"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
   const std::string k(key), v(value);
@@ -576,6 +576,12 @@ int TuneOpts::set(const char* key, const char* value) {
     const double d = v == "auto" ? 0.0 : strtod(value, &end);
     if ((v != "auto" && end == value) || d < 0.0) return -1;
     sched_wait_s = d;
+    return 0;
+  }
+  if (k == "krylov_tau") {
+    const double d = v == "auto" ? 0.1 : strtod(value, &end);
+    if ((v != "auto" && end == value) || !(d > 0.0) || d > 1.0) return -1;
+    krylov_tau = d;
     return 0;
   }
   if (k == "standin_tau") {

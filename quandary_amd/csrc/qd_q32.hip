@@ -1069,7 +1069,7 @@ struct Team32 {
       fac = 0.0;  // ||b|| <= tolerance: KSP returns the zero initial guess
     } else {
       const double ibb = 1.0 / bb, a = d[1] * ibb, h00 = 1.0 - a, h10sq = fmax(fma(-a, a, d[2] * ibb), 0.0), den = fma(h00, h00, h10sq);
-      if (!(bb * h10sq <= ttol2 * den || A.maxiter <= 1) || !(h00 > 0.0)) return -1;
+      if (!(bb * h10sq <= A.kry_tau2 * ttol2 * den || A.maxiter <= 1) || !(h00 > 0.0)) return -1;  // (kry_tau: SweepArgs)
       fac = h00 / den;
     }
 #pragma unroll

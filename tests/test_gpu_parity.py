@@ -404,6 +404,45 @@ def test_lean_column_krylov_solver(kw, dt, poly):
     opt.close(); h.close(); orc.close()
 
 
+def _random_krylov_case(seed):
+    """Random systems of the lean kernel families under their Krylov solvers (gmres_split = 0): column kernels (N = 44 .. 64: five and
+    eight columns per wave, two and three oscillators) and slot kernels (2^4 / 2^5, with and without dipole-dipole coupling)."""
+    rng = np.random.default_rng(9000 + seed)
+    shapes = [[3, 20], [4, 12], [8, 8], [3, 3, 5], [2, 4, 7], [7, 9], [5, 11], [2, 3, 9], [2, 2, 2, 2], [2, 2, 2, 2, 2], [2, 2, 2, 2], [2, 2, 2, 2, 2]]
+    nl = shapes[rng.integers(len(shapes))]
+    qubits = all(n == 2 for n in nl)
+    amp = float(rng.choice([0.005, 0.02, 0.05]))
+    kw = dict(nlevels=nl, lindblad=True, target="pure", objective=["Jmeasure", "Jfrobenius", "Jtrace"][rng.integers(3)],
+              init=f"diagonal, {rng.integers(len(nl))}", ntime=30, dt=float(rng.choice([0.0015, 0.004, 0.01])) if not qubits else float(rng.choice([0.01, 0.03])),
+              penalties=bool(rng.integers(2)), stepper=["IMR", "IMR", "IMR4"][rng.integers(3)], linsolve="gmres",
+              ctrl_init=f"random, {amp}", nspline=int(rng.integers(6, 20)), maxiter=int(rng.choice([10, 20, 40])))
+    if qubits and rng.integers(2):
+        kw.update(jkl=float(rng.choice([0.001, 0.004])), detuned=bool(rng.integers(2)))
+    opts = {"gmres_split": "0", "gmres_poly": str(rng.choice(["auto", "auto", "2", "3", "7"]))}
+    if not qubits:
+        opts["col_slices"] = int(rng.choice([1, 3]))
+    return kw, opts
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_systems_on_the_lean_krylov_solvers(seed):
+    """[r6] Seeded sweep of the Krylov solvers of the lean kernels (qd_col.hip ColTeam::kry_*, qd_q32.hip Team32::kry1 + gmres): random
+    shapes, steppers, time steps, iteration caps, preconditioner degrees (tuned, too low: generic path / plain GMRES behind the one-vector
+    path, too high), time slices, coupling - objective parts and gradient through check_parity (the reference tolerances against the
+    oracle; where the oracle's own GMRES stopping error exceeds them, no farther from the exact discrete solution than the oracle).
+    profiles/kry_seed_sweep.py runs the same cases over more seeds."""
+    kw, opts = _random_krylov_case(seed)
+    sp = synthetic_spec(**kw)
+    sp.options = opts
+    h, orc = capi.Handle(sp), Oracle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert h.last_solver == "krylov", (h.last_solver, kw, opts)
+    oval, og = orc.evalGradF(sp.params0)
+    check_parity(sp, val, g, oval, og, msg=(kw, opts))
+    opt.close(); h.close(); orc.close()
+
+
 @pytest.mark.parametrize("poly", ["auto", "2"])
 @pytest.mark.parametrize("stepper,ntime", [("IMR4", 7), ("IMR8", 3)])
 @pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[2], LEANCOL_SHAPES[3]])
