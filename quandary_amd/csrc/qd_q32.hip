@@ -29,6 +29,11 @@
 namespace qd {
 
 constexpr float F32_SOLVER_TOL = 2.384185791015625e-07f;  // 2^-22
+// waves per SIMD the coupled 2^5 fp32-mixed kernels are budgeted for (0 = one 512-thread workgroup per CU like their fp64 form; 4 = two:
+// 128 registers, 77 spilt - c5j forward 25.5 -> 32.1 ms, gradient 57.5 -> 69.5 in one lease [r6]: measurement build only)
+#ifndef QD_F32HJ_W
+#define QD_F32HJ_W 0
+#endif
 // Measurement builds (profiles/q32_ab.sh): scheduling fence after every QD_Q32_FENCE-th slot of a thread (1 in the product)
 #ifndef QD_Q32_FENCE
 #define QD_Q32_FENCE 1
@@ -1146,7 +1151,7 @@ template <> struct ZTraj<double> {
 // forward sweep (TimeStepper::solveODE for every initial condition of the batch)
 // ---------------------------------------------------------------------------------------------
 template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> ((GM && sizeof(R) == 4) || HJ ? 1 : 0))) k_forward_q32(const SweepArgs A) {
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (QD_F32HJ_W > 0 && HJ && !GM && sizeof(R) == 4 && Q == 5 ? QD_F32HJ_W : Q32<Q, SB, R>::MINW >> ((GM && sizeof(R) == 4) || HJ ? 1 : 0))) k_forward_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team32<Q, SB, R, GM, HJ> TM;
   typedef typename TM::f2 f2;
@@ -1241,7 +1246,7 @@ __global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> (
 // adjoint sweep (TimeStepper::solveAdjointODE + ImplMidpoint::evolveBWD + compute_dRHS_dParams)
 // ---------------------------------------------------------------------------------------------
 template <int Q, int SB, typename R, bool GM = false, bool HJ = false>
-__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (Q32<Q, SB, R>::MINW >> ((GM && sizeof(R) == 4) || HJ ? 1 : 0))) k_adjoint_q32(const SweepArgs A) {
+__global__ void __launch_bounds__((Q32<Q, SB, R>::NT), (QD_F32HJ_W > 0 && HJ && !GM && sizeof(R) == 4 && Q == 5 ? QD_F32HJ_W : Q32<Q, SB, R>::MINW >> ((GM && sizeof(R) == 4) || HJ ? 1 : 0))) k_adjoint_q32(const SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Team32<Q, SB, R, GM, HJ> TM;
   typedef typename TM::f2 f2;
