@@ -1052,13 +1052,9 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_forward_col(const Swee
     }
   };
 
-  double hlast = s_lo > 0 ? kload(A.ctl + (size_t)(s_lo - 1) * A.cs) : 0.0;  // (a time slice continues where its predecessor stopped)
   for (int s = s_lo; s < s_hi; s++) {
     StepC<Q> c;
     load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
-    // (the skipped stopping tests compare like with like: a sub-step of another size - composite steppers - starts its count over)
-    if (SKIP && A.nstages > 1 && c.h != hlast) tm.lastn = 0;
-    hlast = c.h;
     if (SPLIT) tm.template set_alpha<false>(0.5 * c.h);
     if (A.traj) store_state(A.traj + ((size_t)s * A.nb + ic) * 2 * dim, x, true);
     // the sub-step in stage form (ColTeam::stage): x is the right-hand side of the solve and stays in registers
@@ -1172,7 +1168,6 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
                            : make_double2(0.0, 0.0);
   };
 
-  double hlast = s_hi < A.nsub ? kload(A.ctl + (size_t)s_hi * A.cs) : 0.0;
   for (int s = s_hi - 1; s >= s_lo; s--) {
     // penalty adjoints at the end of a full step, with the primal x_n (timestepper.cpp:220-227, :300-339)
     if (pen_on && (s + 1) % A.nstages == 0 && (wj_on || leak)) {
@@ -1220,8 +1215,6 @@ __global__ void __launch_bounds__(col_max_threads(EPT)) k_adjoint_col(const Swee
     }
     StepC<Q> c;
     load_step_k<Q>(A.ctl + (size_t)s * A.cs, c, false);
-    if (SKIP && A.nstages > 1 && c.h != hlast) tm.lastna = 0;
-    hlast = c.h;
     // ImplMidpoint::evolveBWD (timestepper.cpp:631-694); the primal stage z of the sub-step was stored by the forward sweep
     if (SPLIT) tm.template set_alpha<true>(0.5 * c.h);
     double2 kb[EPT];  // adjoint stage: (I - h/2 M)^T kbar = xbar ; kbar *= h
@@ -1400,7 +1393,9 @@ static hipError_t go_fwd_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
   // (SKIP: stopping tests skipped, see ColTeam::stage)
-  const bool skip = a.rel2 < 1e-30f && !a.col_noskip;
+  // (implicit midpoint only: the predictor compares the pass count of a sub-step with its predecessor's, and the sub-steps of a composite
+  //  step differ in size - IMR4 / IMR8 test every pass; nothing of this lives in the kernels)
+  const bool skip = a.rel2 < 1e-30f && !a.col_noskip && a.nstages == 1;
   auto kf = col_uslot<EPT>(a.S) ? (skip ? k_forward_col<Q, EPT, SPLIT, true, true> : k_forward_col<Q, EPT, SPLIT, true, false>)
                                 : (skip ? k_forward_col<Q, EPT, SPLIT, false, true> : k_forward_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
@@ -1446,7 +1441,9 @@ template <int Q, int EPT, bool SPLIT>
 static hipError_t go_adj_col_s(const SweepArgs& a, hipStream_t st) {
   typedef ColLean<Q, EPT> ST;
   const size_t lds = ST::lds_bytes(a.S.N);
-  const bool skip = a.rel2 < 1e-30f && !a.col_noskip;
+  // (implicit midpoint only: the predictor compares the pass count of a sub-step with its predecessor's, and the sub-steps of a composite
+  //  step differ in size - IMR4 / IMR8 test every pass; nothing of this lives in the kernels)
+  const bool skip = a.rel2 < 1e-30f && !a.col_noskip && a.nstages == 1;
   auto kf = col_uslot<EPT>(a.S) ? (skip ? k_adjoint_col<Q, EPT, SPLIT, true, true> : k_adjoint_col<Q, EPT, SPLIT, true, false>)
                                 : (skip ? k_adjoint_col<Q, EPT, SPLIT, false, true> : k_adjoint_col<Q, EPT, SPLIT, false, false>);
   hipError_t e = set_lds_col(kf, lds);
