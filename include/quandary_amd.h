@@ -403,7 +403,7 @@ int qd_set_precision(qd_handle* h, int precision);
  * gmres_split (linearsolver_type = gmres served by a stationary iteration under GMRES's stopping rule wherever that iteration provably
  * contracts fast - the reference's Neumann iteration, or the diagonal-split one on 3x20-class systems and on states beyond LDS: auto = there, 0 = always the
  * Krylov kernels), gmres_poly (degree of the polynomial preconditioner, 0 = tuned then frozen, 1 = none), krylov_tau (double: the one-vector
- * path of the lean kernels' Krylov solvers accepts at residual <= krylov_tau x the reference's tolerance, default 0.1), force_neumann, var (kernel variant), no_mfma,
+ * path of the lean kernels' Krylov solvers accepts at residual <= krylov_tau x the reference's tolerance, default 0.1), krylov_restart (restart length of those solvers' generic path, 1 .. 14), force_neumann, var (kernel variant), no_mfma,
  * no_lean64, lean64_sb, no_collean, no_col_krylov, col_ept, col_min_n, big_team, big_spread, big_blocked, f32_sb, traj_budget_mb (double).  Every key is also read from the
  * environment variable QD_<KEY> once, at qd_create (tests, measurements).  Unknown keys: QD_ERR_INVALID. */
 int qd_set_option(qd_handle* h, const char* key, const char* value);

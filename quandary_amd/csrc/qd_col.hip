@@ -661,6 +661,7 @@ struct ColTeam {
   template <bool TRANS>
   __device__ __forceinline__ int kry_generic(const SweepArgs& A, const StepC<Q>& c, double alpha, double2 (&v)[EPT], double2 (&y)[EPT]) {
     const int poly = A.gmres_poly > 1 ? A.gmres_poly : 1;
+    const int mre = A.kry_restart >= 1 && A.kry_restart < KRY_MR ? A.kry_restart : KRY_MR;  // restart length (option krylov_restart)
     double* hc = ksc;                  // [MR + 2] current Hessenberg column
     double* cs = hc + (KRY_MR + 2);    // [MR]
     double* sn = cs + KRY_MR;          // [MR]
@@ -689,7 +690,7 @@ struct ColTeam {
       double gcur = beta;
       int jj = 0;
       bool conv = false;
-      while (jj < KRY_MR) {
+      while (jj < mre) {
         // z = R_p v_jj, parked in Z_jj; w = (I - alpha M) z takes its registers
 #pragma unroll
         for (int j = 0; j < EPT; j++) y[j] = pmul(j, v[j]);
@@ -769,7 +770,7 @@ struct ColTeam {
         its++;
         jj++;
         if (fabs(gcur) <= ttol || hn == 0.0) { conv = true; break; }
-        if (its >= A.maxiter || jj >= KRY_MR) break;
+        if (its >= A.maxiter || jj >= mre) break;
 #pragma unroll
         for (int j = 0; j < EPT; j++) v[j] = make_double2(y[j].x * ihn, y[j].y * ihn);
         vstore(SV + jj, v);

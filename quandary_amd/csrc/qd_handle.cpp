@@ -851,6 +851,7 @@ static void fill_sweep(const qd_handle* h, SweepArgs& a, int nb, const DevTarget
   a.gmres_poly = h->gmres_poly_degree();
   a.col_noskip = !h->opts.col_skip;
   a.kry_tau2 = h->opts.krylov_tau * h->opts.krylov_tau;
+  a.kry_restart = h->opts.krylov_restart;
   a.nslice = 1;
   a.neumann_split = h->neumann_split_on();
   // penalties that need target data are only active when a target has been set

@@ -95,6 +95,7 @@ struct SweepArgs {
   // gradient of norm 1e-4 sat 4e-11 from the exact one where the oracle's GMRES sits at 5e-12 (profiles/r6_kry_seed_sweep.txt); 0.1 (the
   // default, option krylov_tau) costs at most one application more per solve.  The generic paths behind it keep the reference's rule.
   double kry_tau2;
+  int kry_restart;  // restart length of the generic path of the lean column kernels' Krylov solver (<= KRY_MR = 14; option krylov_restart)
   // Gaussian weights of the weighted-J penalty, one per time step: wjw[n] = exp(-((n + 1) dt - T)^2 / param^2) / param
   // (timestepper.cpp:262-270, :304-315); tabulated once per handle so that the sweep kernels of qd_col.hip need no exp() per step
   const double* wjw;
@@ -153,6 +154,7 @@ struct TuneOpts {
   int no_col_krylov = 0;   // "no_col_krylov": the Krylov solver of 3 x 20-class systems on the general column kernel (A/B against the lean one [r6])
   int col_ept = 0;         // "col_ept": columns per wave of the lean column kernels (0 = automatic)
   double standin_tau = 1e-3;  // "standin_tau": error-estimate factor of the stationary iterations that serve gmres requests (0 = plain update-norm rule)
+  int krylov_restart = 14;    // "krylov_restart": restart length of the generic path of the lean column kernels' Krylov solver (1 .. 14; KSPGMRESSetRestart)
   double krylov_tau = 0.1;    // "krylov_tau": the one-vector path of the Krylov solvers accepts at residual <= krylov_tau x the reference's tolerance (1 = at the tolerance itself)
   int no_plain = 0;        // "no_plain": 1 / 2 / 3 = forward / adjoint / both sweeps of the small systems on the general instantiation (A/B)
   int col_skip = 1;        // "col_skip": the lean column solver skips stopping tests up to two / three passes before the previous sub-step's count (0 = test every pass)

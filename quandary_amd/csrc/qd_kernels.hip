@@ -561,7 +561,7 @@ size_t krylov_doubles(const DevSys& S, int nb) { return (size_t)nb * (GMRES_MR_G
 // options
 // ---------------------------------------------------------------------------------------------
 static const char* const kOptKeys[] = {"var", "force_neumann", "no_mfma", "big_team", "big_spread", "big_blocked", "f32_sb", "lean64_sb", "no_lean64", "no_collean",
-                                       "col_ept", "col_slices", "no_plain", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb", "standin_tau", "sched_wait_s", "col_skip", "no_col_krylov", "krylov_tau"};
+                                       "col_ept", "col_slices", "no_plain", "col_min_n", "gmres_poly", "gmres_split", "neumann_split", "traj_budget_mb", "standin_tau", "sched_wait_s", "col_skip", "no_col_krylov", "krylov_tau", "krylov_restart"};
 int TuneOpts::set(const char* key, const char* value) {
   if (!key || !value) return -1;
   const std::string k(key), v(value);
@@ -608,6 +608,7 @@ int TuneOpts::set(const char* key, const char* value) {
   else if (k == "col_skip") col_skip = v == "auto" ? 1 : iv != 0;
   else if (k == "no_collean") no_collean = iv != 0;
   else if (k == "no_col_krylov") no_col_krylov = iv != 0;
+  else if (k == "krylov_restart") krylov_restart = (v == "auto" || iv < 1 || iv > 14) ? 14 : (int)iv;
   else if (k == "col_ept") col_ept = (int)iv;
   else if (k == "no_plain") no_plain = (int)(iv & 3);
   else if (k == "col_slices") col_slices = iv > 0 ? (int)iv : 0;

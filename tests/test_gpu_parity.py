@@ -404,6 +404,37 @@ def test_lean_column_krylov_solver(kw, dt, poly):
     opt.close(); h.close(); orc.close()
 
 
+@pytest.mark.parametrize("restart", ["1", "2", "3"])
+@pytest.mark.parametrize("kw", [LEANCOL_SHAPES[0], LEANCOL_SHAPES[2], LEANCOL_SHAPES[3]])
+def test_lean_column_krylov_solver_restarts(kw, restart):
+    """[r6] The generic path of the lean column kernels' Krylov solver through its RESTART (option krylov_restart - KSPGMRESSetRestart - cut
+    to 1 .. 3 vectors; degree 2, strong controls: several cycles per solve, the accumulated solution parked and the residual re-formed from
+    the parked right-hand side): the same objective and gradient as the un-restarted solve and as the exact discrete solution."""
+    sp = synthetic_spec(**{**kw, "ntime": 10, "penalties": True, "dt": 0.004, "linsolve": "gmres", "ctrl_init": "random, 0.1", "maxiter": 60})
+    sp.options = {"gmres_split": "0", "gmres_poly": "2", "krylov_restart": restart}
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    a_restarted = h.mean_applies
+    assert h.last_solver == "krylov"
+    from helpers import tight_oracle
+    tight = tight_oracle(sp)
+    tval, tg = tight.evalGradF(sp.params0)
+    tight.close()
+    for k in OBJ_KEYS:
+        assert val[k] == pytest.approx(tval[k], rel=REF_RTOL, abs=1e-12), k
+    assert np.linalg.norm(g - tg) <= 1e-8 * np.linalg.norm(tg)
+    h.set_option("krylov_restart", "auto")
+    h.set_option("gmres_poly", "2")
+    val2, g2 = opt.evalGradF(sp.params0)
+    # (restarted GMRES needs more applications: with one vector per cycle the cycles certainly happened; three may already suffice)
+    assert h.mean_applies < a_restarted if restart == "1" else h.mean_applies <= a_restarted
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-9, abs=1e-12), k
+    assert np.linalg.norm(g2 - g) <= 1e-8 * np.linalg.norm(g)
+    opt.close(); h.close()
+
+
 def _random_krylov_case(seed):
     """Random systems of the lean kernel families under their Krylov solvers (gmres_split = 0): column kernels (N = 44 .. 64: five and
     eight columns per wave, two and three oscillators) and slot kernels (2^4 / 2^5, with and without dipole-dipole coupling)."""
