@@ -10,5 +10,6 @@ profiles/r6_shard_of.sh > gpurun_out/r6_shard_of.txt 2>&1
 profiles/small_now.sh > gpurun_out/r6_small_configs.txt 2>&1
 profiles/r6_slot_kry_ab.sh > gpurun_out/r6_slot_kry_ab.txt 2>&1
 bash profiles/r6_kry_ab.sh > gpurun_out/r6_kry_ab.txt 2>&1
+python profiles/kry_seed_sweep.py 0 160 > gpurun_out/r6_kry_seed_sweep.txt 2>&1
 python __graft_entry__.py smoke 2>&1 | tail -3 > gpurun_out/r6_smoke.txt
 cat gpurun_out/r6_gpu_tests.log gpurun_out/r6_bench_time.txt gpurun_out/r6_smoke.txt
