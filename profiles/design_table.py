@@ -47,34 +47,28 @@ def main():
     pmc = load("pmc_latest.json") or {}
     kres = kres_table()
 
-    def prof(key):  # (summary of a profiled workload: dominant sweep kernel, timed launches)
+    def prof(key):  # (summary of a profiled workload: its sweep kernels by total time, each with the mean and max / min of its timed launches)
         s = load(f"{TAG}_{key}_summary.json")
         if not s:
-            return None, None, None
-        best = None
-        for name, d in s.get("sweep_launches", {}).items():
-            tot = sum(d["durations_ms"])
-            if best is None or tot > best[1]:
-                best = (name, tot, d)
-        if not best:
-            return None, None, None
-        name, _, d = best
-        avg = d.get("timed_avg_ms", d.get("avg_ms_full_grid"))
-        spread = d.get("timed_max_over_min")
-        return name.replace("void ", ""), avg, spread
+            return []
+        ks = sorted(s.get("sweep_launches", {}).items(), key=lambda kv: -sum(kv[1]["durations_ms"]))
+        return [(name.replace("void ", ""), d.get("timed_avg_ms", d.get("avg_ms_full_grid")), d.get("timed_max_over_min")) for name, d in ks[:2]]
 
     rows = []
 
     def add(label, key, v, kms, A, valu_spec, valu_meas, hbm, units_per_launch, alg_bytes):
-        kname, pavg, spread = prof(key) if key else (None, None, None)
         ent = pmc.get(key or "", {})
         traffic = ent.get("hbm_bytes_per_unit")
-        kr = kres.get(kname) if kname else None
+        # (the rocprofv3 columns only where the profile is of THIS command: a 250-step variant of the headline shares its kernels and its
+        #  traffic per unit, not its launch durations)
+        own = bool(key) and ent.get("units_per_launch") == units_per_launch
+        ks = prof(key) if key else []
+        names = " + ".join(f"`{k[0]}`" for k in ks) if ks else "-"
+        durs = " + ".join(sig(k[1], 4) + (f" (max/min {k[2]:.3f})" if k[2] else "") for k in ks if k[1]) if (ks and own) else "-"
+        regs = " ; ".join(f"{kres[k[0]][0]} / {kres[k[0]][1]} / {kres[k[0]][2]} / {kres[k[0]][3]} B" for k in ks if k[0] in kres) or "-"
         rows.append("| " + " | ".join([
-            label, f"`{kname}`" if kname else "-", sig(kms, 4), (sig(pavg, 4) + (f" (max/min {spread:.3f})" if spread else "")) if pavg else "-",
-            sig(v, 3), sig(A, 3), sig(valu_spec, 2), sig(valu_meas, 2), sig(hbm, 2),
-            (f"{traffic / alg_bytes:.2g} ({traffic / 1e3:.3g} KB of {alg_bytes / 1e3:.3g} KB)" if traffic and alg_bytes else "-"),
-            (f"{kr[0]} / {kr[1]} / {kr[2]} / {kr[3]} B" if kr else "-")]) + " |")
+            label, names, sig(kms, 4), durs, sig(v, 3), sig(A, 3), sig(valu_spec, 2), sig(valu_meas, 2), sig(hbm, 2),
+            (f"{traffic / alg_bytes:.2g} ({traffic / 1e3:.3g} KB of {alg_bytes / 1e3:.3g} KB)" if traffic and alg_bytes else "-"), regs]) + " |")
 
     r = bench["roofline"]
     vk = "fp64_valu"

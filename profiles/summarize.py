@@ -66,6 +66,7 @@ def main():
         pass
     res["sweep_launches"] = launches
     pmc = {}
+    per_dispatch = {}  # [r6] kernel -> counter -> [(dispatch id, grid size, value)]: the TIMED launches of a command are the last `steps` ones
     for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         for f in find(os.path.join(out, sub), "counter_collection.csv"):
             for r in csv.DictReader(open(f)):
@@ -74,6 +75,7 @@ def main():
                 k = r["Kernel_Name"].split("(")[0]
                 d = pmc.setdefault(k, {}).setdefault(name, [])
                 d.append(float(r["Counter_Value"]))
+                per_dispatch.setdefault(k, {}).setdefault(name, []).append((int(r["Dispatch_Id"]), int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
     sq = {}
     for f in find(os.path.join(out, "pmc_sq"), "counter_collection.csv"):
         for r in csv.DictReader(open(f)):
@@ -108,11 +110,39 @@ def main():
             evals = line["steps"] + line["warmup"]
         except Exception:
             pass
+        steps = None
+        try:
+            steps = int(line["steps"])
+        except Exception:
+            pass
+
+        def timed_mean(k, counter):
+            """mean over the TIMED launches of kernel k, or None where the kernel does not run once per evaluation (chunked gradient)"""
+            v = sorted(per_dispatch.get(k, {}).get(counter, []))
+            if not v or not steps or not evals:
+                return None
+            gmax = max(g for _, g, _ in v)
+            full = [x for _, g, x in v if g == gmax]
+            if len(full) == evals:        # (the oracle check's launch has a smaller grid)
+                return sum(full[-steps:]) / steps
+            if len(full) == evals + 1:    # (a one-state workload: the check launch has the full grid too)
+                return sum(full[-steps - 1:-1]) / steps
+            return None
+
+        timed_only = True
         for k, v in summary.items():
             if ("k_forward" in k or "k_adjoint" in k) and "hbm_bytes_per_launch_fetch_x2" in v:
-                # bytes per EVALUATION: all launches of the run (a chunked gradient launches each sweep once per chunk; the one small launch
-                # of bench.py's oracle check is in the sum as well) over the evaluations of the run
-                tot += v["hbm_bytes_all_launches_fetch_x2"] / evals if evals else v["hbm_bytes_per_launch_fetch_x2"]
+                # bytes per EVALUATION.  [r6] Where the kernel runs once per evaluation: the TIMED launches only (the warm-up launches of a
+                # gmres run tune the preconditioner's degree - generic-path solves with their scratch vectors - and are not what is timed).
+                # Otherwise all launches of the run (a chunked gradient launches each sweep once per chunk; the one small launch of
+                # bench.py's oracle check is in the sum as well) over the evaluations of the run.
+                tf, tw = timed_mean(k, "FETCH_SIZE"), timed_mean(k, "WRITE_SIZE")
+                if tf is not None and tw is not None:
+                    tot += (2.0 * tf + tw) * 1024.0
+                    v["hbm_bytes_per_timed_launch_fetch_x2"] = (2.0 * tf + tw) * 1024.0
+                else:
+                    timed_only = False
+                    tot += v["hbm_bytes_all_launches_fetch_x2"] / evals if evals else v["hbm_bytes_per_launch_fetch_x2"]
                 names.append(k[:60])
         if names:
             latest_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json")
@@ -122,6 +152,7 @@ def main():
             latest[key] = {"csrc_hash": csrc_hash(), "date": datetime.date.today().isoformat(),
                            "hbm_bytes_per_launch": tot, "units_per_launch": units,
                            "hbm_bytes_per_unit": (tot / units) if units else None, "kernels": names, "source": f"profiles/{tag}_summary.json",
+                           "launches_counted": "timed launches" if timed_only else "all launches of the run / evaluations",
                            "correction": "FETCH_SIZE x2 (gfx950, calibrated on this kernel's 8-byte loads) + WRITE_SIZE, units of 1 KiB"}
             json.dump(latest, open(latest_path, "w"), indent=1)
             # gpurun only merges gpurun_out/ back: leave a copy there
