@@ -1539,6 +1539,33 @@ def test_rccl_single_rank_communicator_device_resident_path():
     lib.qd_comm_destroy(comm)
 
 
+def test_file_bootstrap_over_rccl_with_one_rank(tmp_path, monkeypatch):
+    """[r6] The bootstrap bench.py --gpus N uses (quandary_amd.parallel.FileComm -> qd_comm_create_from_file, no torch.distributed) on REAL
+    RCCL with the one rank a one-GPU box allows: id file, ncclCommInitRank, the eight-double self-check (sum and max), barrier, and the
+    library-side evaluation through that communicator against the plain one."""
+    from quandary_amd.parallel import DistributedObjective, FileComm
+
+    monkeypatch.setenv("QD_LOCAL_SIZE", "1")
+    comm = FileComm(0, 1, 0, str(tmp_path / "id"), backend="rccl", timeout_s=60.0)
+    assert comm.is_rccl() and comm.world_size() == 1 and "qd_comm_create_from_file" in comm.describe()
+    ok, got = comm.self_check()
+    assert ok, got
+    comm.barrier()
+    np.testing.assert_array_equal(comm.allreduce_max(np.array([3.0, -1.0])), [3.0, -1.0])
+    sp = synthetic_spec([2, 2, 2], lindblad=True, ntime=25, penalties=True)
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    vd, gd, _ = opt.evalGradF_dist(comm.comm, sp.params0)
+    for k in OBJ_KEYS:
+        assert vd[k] == pytest.approx(val[k], rel=1e-12, abs=1e-15), k
+    np.testing.assert_allclose(gd, g, rtol=1e-11, atol=1e-15)
+    # (a one-rank communicator is no communicator for DistributedObjective: it takes the plain path)
+    assert DistributedObjective(opt, comm).comm is None
+    opt.close(); h.close()
+    comm.close()
+
+
 def test_bench_two_ranks_matches_one_rank():
     """`python bench.py --gpus 2` starts its two ranks itself (no launcher), splits the initial conditions (strong scaling)
     and prints the same objective as the one-GPU run.  With fewer than two GPUs visible the ranks share the device and
