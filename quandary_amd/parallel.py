@@ -25,6 +25,27 @@ import time
 import numpy as np
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 -> 2 for the duration of a library call that may print (C stdio included: flushed before the descriptor returns)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class TorchComm:
     """torch.distributed on host tensors (gloo), or on device tensors (nccl = RCCL) when `device` is a cuda device."""
 
@@ -178,7 +199,10 @@ class FileComm(RcclComm):
         lib = capi.load_library()
         self.lib = lib
         self.comm = capi.c_void_p()
-        capi.check(lib.qd_comm_create_from_file(path.encode(), rank, world, local_rank, float(timeout_s), capi.byref(self.comm)), "qd_comm_create_from_file")
+        # RCCL announces itself on the C library's stdout ("RCCL version : ...", buffered, flushed whenever): keep stdout for the one JSON
+        # line of bench.py - file descriptor 1 points at stderr while the communicator is created, and the C buffers are flushed into it
+        with _stdout_to_stderr():
+            capi.check(lib.qd_comm_create_from_file(path.encode(), rank, world, local_rank, float(timeout_s), capi.byref(self.comm)), "qd_comm_create_from_file")
         self._world = world
         self.path = path
 
@@ -209,7 +233,8 @@ class FileComm(RcclComm):
 
     def close(self):
         if self.comm:
-            self.lib.qd_comm_destroy(self.comm)
+            with _stdout_to_stderr():
+                self.lib.qd_comm_destroy(self.comm)
             self.comm = None
 
 

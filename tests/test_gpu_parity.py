@@ -1566,6 +1566,26 @@ def test_file_bootstrap_over_rccl_with_one_rank(tmp_path, monkeypatch):
     comm.close()
 
 
+def test_rccl_banner_stays_off_stdout(tmp_path):
+    """[r6] RCCL announces itself on the C library's stdout when a communicator is created ("RCCL version : ...", buffered, flushed at exit -
+    i.e. BEHIND whatever Python printed): bench.py's contract is ONE JSON line on stdout, so the bootstrap sends descriptor 1 to stderr
+    and flushes the C buffers while it does."""
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['QD_LOCAL_SIZE'] = '1'\n"
+            "from quandary_amd.parallel import FileComm\n"
+            "c = FileComm(0, 1, 0, %r, backend='rccl', timeout_s=60.0)\n"
+            "assert c.self_check()[0]\nc.close()\nprint('{\"last\": \"line\"}')\n") % (ROOT, str(tmp_path / "id"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert lines == ['{"last": "line"}'], p.stdout
+    assert "RCCL version" in p.stderr
+
+
 def test_bench_two_ranks_matches_one_rank():
     """`python bench.py --gpus 2` starts its two ranks itself (no launcher), splits the initial conditions (strong scaling)
     and prints the same objective as the one-GPU run.  With fewer than two GPUs visible the ranks share the device and
