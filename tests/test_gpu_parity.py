@@ -1693,6 +1693,50 @@ def test_full_batch_properties_at_baseline_size(name, ninit):
     h.close(); orc.close()
 
 
+@pytest.mark.parametrize("name,ninit,poly", [("c4", 3600, "auto"), ("c4", 3600, "9"), ("c5", 1024, "auto")])
+def test_full_batch_on_the_krylov_solvers_at_baseline_size(name, ninit, poly):
+    """[r6] BASELINE configs 4 and 5 at their FULL batch with the reference's default solver on the lean kernels' Krylov solvers
+    (gmres_split = 0; ntime 20): for C4 the first sweep of a fresh handle runs on the tuner's starting degree - every solve on the GENERIC
+    path, 256 resident workgroups each with its own scratch vectors, four time slices per initial condition - and degree 9 is the tuned
+    one (one-vector path).  Size-independent properties of every final state (trace, hermiticity), agreement with the stationary
+    iteration's final states at solver-tolerance level, and sampled shards against the oracle's GMRES."""
+    from quandary_amd.workloads import workload_spec
+    sp = workload_spec(name, "simulation", {"ntime": 20, "linearsolver_type": "gmres"})
+    assert sp.ninit == ninit
+    sp.options = {"gmres_split": "0", "gmres_poly": poly}
+    if name == "c4":
+        sp.options["col_slices"] = 4
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    N, dim = h.dim_rho, h.dim
+    x0 = np.stack([opt.initial_state(i)[0] for i in range(ninit)])
+    h.set_params(sp.params0)
+    fin = h.forward(x0)["final_states"].reshape(ninit, 2, N, N)
+    assert h.last_solver == "krylov"
+    u, v = fin[:, 0], fin[:, 1]
+    tr0 = np.trace(x0.reshape(ninit, 2, N, N)[:, 0], axis1=1, axis2=2)
+    np.testing.assert_allclose(np.trace(u, axis1=1, axis2=2), tr0, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.trace(v, axis1=1, axis2=2), 0.0, rtol=0, atol=1e-9)
+    assert np.abs(u - u.transpose(0, 2, 1)).max() < 1e-9
+    assert np.abs(v + v.transpose(0, 2, 1)).max() < 1e-9
+    h.set_option("gmres_split", "auto")  # the stationary iteration that serves the request by default: the same states to solver tolerance
+    ref = h.forward(x0)["final_states"].reshape(ninit, 2, N, N)
+    assert h.last_solver != "krylov"
+    assert np.abs(fin - ref).max() < 5e-9
+    h.set_option("gmres_split", "0")
+    h.set_option("gmres_poly", poly)
+    opt.close()
+    orc = Oracle(sp)
+    rng = np.random.default_rng(77)
+    for r in sorted(rng.choice(ninit, 8, replace=False)):
+        shard = capi.Optim(h, sp, rank=int(r), nranks=ninit)
+        part = shard.forward_local(sp.params0)
+        shard.close()
+        po = orc.forward_local(sp.params0, int(r), ninit)
+        np.testing.assert_allclose(part, po, rtol=0, atol=1e-9 * np.maximum(1.0, np.abs(po)).max())
+    h.close(); orc.close()
+
+
 @pytest.mark.parametrize("kw", [SHAPES[1], SHAPES[6], SHAPES[7],
                                 pytest.param(dict(nlevels=[2] * 4, lindblad=True, init="diagonal, 0, 1", precision="f32mixed"), id="2^4-lindblad-f32mixed")])
 def test_device_side_observables(kw):
