@@ -1473,6 +1473,26 @@ def test_chunked_gradient_when_the_trajectory_does_not_fit(kw, one_pass):
     opt.close(); h.close()
 
 
+def test_chunked_gradient_on_the_lean_column_krylov_solver():
+    """[r6] The chunked one-pass gradient (traj_budget_mb) with the reference's default solver on the lean column kernels' Krylov solver:
+    the scratch vectors are sized per launch (chunks of different length), the adjoint sweep of every chunk keeps the degree of its
+    forward sweep - the same numbers as the unchunked evaluation at a fixed degree."""
+    sp = synthetic_spec([3, 20], lindblad=True, target="pure", objective="Jmeasure", init="basis, 0", ntime=12, penalties=True, linsolve="gmres", dt=0.002)
+    sp.options = {"gmres_split": "0", "gmres_poly": "5"}
+    h = capi.Handle(sp)
+    opt = capi.Optim(h, sp)
+    val, g = opt.evalGradF(sp.params0)
+    assert opt.last_chunks == 1 and h.last_solver == "krylov"
+    per_ic = (13 + 12) * 2 * h.dim * 8
+    h.set_option("traj_budget_mb", per_ic * 4 / 1048576.0)  # nine initial conditions in chunks of at most four
+    val2, g2 = opt.evalGradF(sp.params0)
+    assert opt.last_chunks >= 2 and h.last_solver == "krylov"  # (stages only: fewer bytes per initial condition than the bound above)
+    for k in OBJ_KEYS:
+        assert val2[k] == pytest.approx(val[k], rel=1e-13, abs=1e-15), k
+    np.testing.assert_allclose(g2, g, rtol=1e-11, atol=1e-15 + 1e-12 * np.linalg.norm(g))
+    opt.close(); h.close()
+
+
 def test_adjoint_refuses_stages_stored_by_another_kernel_family():
     """The stored primal stages are private to a forward / adjoint kernel pair (the 2^5 kernels keep them interleaved, the general kernels
     as [u; v] blocks): an option that changes the kernel family between the two sweeps must not be served silently."""
