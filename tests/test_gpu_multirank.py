@@ -66,6 +66,10 @@ CASES = [
     pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True, ntime=8), 8, {}, id="c5-shard-eight-ranks"),
     pytest.param(dict(nlevels=[2, 2, 2, 2, 2], lindblad=True, ntime=8, precision="f32mixed"), 8, {}, id="c5-shard-eight-ranks-f32mixed"),
     pytest.param(dict(nlevels=[2, 2, 2, 2], lindblad=False, objective="Jtrace", penalties=True), 8, {}, id="c3-eight-ranks-two-collectives"),
+    # [r6] the reference's default solver on the lean column kernels' Krylov solver, three ranks sharing the GPU (every rank its own scratch
+    # vectors; fixed degree: the ranks' tuners would otherwise see different shards)
+    pytest.param(dict(nlevels=[3, 20], lindblad=True, target="pure", objective="Jmeasure", init="basis, 0", penalties=True, linsolve="gmres", ntime=10, dt=0.002), 3,
+                 {"all": {"gmres_split": "0", "gmres_poly": "6"}}, id="3x20-krylov-three-ranks"),
 ]
 
 
@@ -83,6 +87,7 @@ def test_fused_evaluation_with_several_ranks_sharing_the_gpu(kw, world, options,
     cfg_text = synthetic_cfg(**{"ntime": 25, **kw})
     sp = config.build_spec(config.parse_config_text(cfg_text))
     sp.precision = precision
+    sp.options = dict(options.get("all", {}))  # (options that every rank gets also hold for the single-rank comparison)
     h = capi.Handle(sp)
     one = capi.Optim(h, sp)
     ref_val, ref_g = one.evalGradF(sp.params0)
