@@ -99,7 +99,9 @@ def main():
     src = (f"Generated by `profiles/design_table.py {TAG}` from `profiles/{TAG}_bench_default.json` ({bench.get('n_gpus', 1)} GPU, value {bench['value']:.4g} units/s, "
            f"{bench['ms_per_step']:.1f} ms per step), `profiles/pmc_latest.json`, `profiles/{TAG}_*_summary.json`, `profiles/{TAG}_kres.txt`.  "
            "Fractions: canonical flops (SURVEY 8d) / kernel time / 78.6 TF fp64 (157.3 TF fp32-mixed) spec, resp. / the FMA rate measured on the device in the same run; "
-           "rows without a spec fraction come from the compact `workloads` array (which carries the measured-rate fraction only).")
+           "rows without a spec fraction come from the compact `workloads` array (which carries the measured-rate fraction only).  "
+           "These are the BUILDER's lease; the driver's `BENCH_rNN.json` is taken on another box of the pool - the headline moves by a few "
+           "per cent from box to box (round 5: 584.0 ms in the builder's record, 610.8 ms on the driver's box).")
     block = BEGIN + "\n" + src + "\n\n" + head + "\n" + "\n".join(rows) + "\n" + END
     path = os.path.join(ROOT, "DESIGN.md")
     text = open(path).read()
